@@ -1,0 +1,205 @@
+"""ctypes loader for the CPU oracle (oracle/rslf_oracle.c).
+
+TEST INFRASTRUCTURE ONLY.  PARITY UNPINNED (see rslf_oracle.h): the reference
+holds no golden vectors for this path and cannot be built without OpenCV 3.x.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this
+package; the product (remotesensingproject_amd/, include/) never does.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from dataclasses import dataclass
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "librslf_oracle.so")
+_lib = None
+
+
+class OracleParams(C.Structure):
+    """Mirror of oracle_params (= rslf::Depth1DParameters, core.hpp:66-142)."""
+
+    _fields_ = [
+        ("edge_score_threshold", C.c_float),
+        ("raw_score_threshold", C.c_float),
+        ("mean_shift_max_iter", C.c_float),
+        ("edge_confidence_filter_size", C.c_int),
+        ("median_filter_size", C.c_int),
+        ("median_filter_epsilon", C.c_float),
+        ("slope_factor", C.c_float),
+        ("cut_shadows", C.c_int),
+        ("shadow_level", C.c_float),
+        ("kernel_bandwidth", C.c_float),
+    ]
+
+
+def build(force: bool = False) -> str:
+    """Compile the oracle with gcc (oracle/Makefile). Returns the .so path."""
+    src = os.path.join(_HERE, "rslf_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.run(["make", "-C", _HERE, "-B"], check=True, capture_output=True)
+    return _SO
+
+
+_f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
+_u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
+_i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_SO)
+        L.oracle_default_params.argtypes = [C.POINTER(OracleParams)]
+        L.oracle_normalize_u8.argtypes = [_u8p, _f32p, C.c_size_t]
+        L.oracle_normalize_f32.argtypes = [_f32p, _f32p, C.c_size_t, C.c_float]
+        L.oracle_normalize_f32.restype = C.c_float
+        L.oracle_edge_confidence_pile.argtypes = [
+            _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _f32p, _u8p, C.POINTER(OracleParams)]
+        L.oracle_depth_epi.argtypes = [
+            _f32p, C.c_int, C.c_int, C.c_int, _f32p, _f32p, C.c_int, C.c_int,
+            _f32p, _u8p, _f32p, _f32p, _f32p, C.POINTER(OracleParams),
+            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.oracle_selective_median.argtypes = [
+            _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _u8p, C.c_float]
+        L.oracle_depth_epi_pile.argtypes = [
+            _f32p, C.c_int, C.c_int, C.c_int, C.c_int, _f32p, _f32p, C.c_int, C.c_int,
+            _f32p, _u8p, _f32p, _f32p, _f32p, C.POINTER(OracleParams),
+            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.oracle_depth1d_pile_run.argtypes = [
+            _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int,
+            C.POINTER(OracleParams), _f32p, _u8p, _f32p, _f32p, _f32p, _i32p, _f32p, _f32p]
+        L.oracle_num_threads.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def default_params() -> OracleParams:
+    p = OracleParams()
+    lib().oracle_default_params(C.byref(p))
+    return p
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+@dataclass
+class PileResult:
+    """Outputs of Depth1DComputer_pile::run() (dc.hpp:131-135) + parity extras."""
+
+    edge_confidence: np.ndarray   # C_e   [V,U] f32
+    edge_mask: np.ndarray         # mask  [V,U] u8 (0/255)
+    disp_confidence: np.ndarray   # C_d   [V,U] f32
+    depth: np.ndarray             # best depth after the selective median [V,U] f32
+    rbar: np.ndarray              # [V,U,C] f32
+    depth_idx: np.ndarray         # argmax index, -1 if none [V,U] i32
+    score: np.ndarray             # score[d*] [V,U] f32
+    depth_raw: np.ndarray         # best depth before the median [V,U] f32
+
+
+def normalize_u8(x: np.ndarray) -> np.ndarray:
+    x = np.ascontiguousarray(x, dtype=np.uint8)
+    out = np.empty(x.shape, np.float32)
+    lib().oracle_normalize_u8(x.reshape(-1), out.reshape(-1), x.size)
+    return out
+
+
+def normalize_f32(x: np.ndarray, scale: float = -1.0):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    out = np.empty(x.shape, np.float32)
+    s = lib().oracle_normalize_f32(x.reshape(-1), out.reshape(-1), x.size, scale)
+    return out, float(s)
+
+
+def edge_confidence_pile(vol: np.ndarray, s: int, params: OracleParams | None = None):
+    """vol [V,S,U,C] f32 -> (C_e [V,U], mask [V,U])."""
+    vol = np.ascontiguousarray(vol, dtype=np.float32)
+    V, S, U, Cc = vol.shape
+    p = params or default_params()
+    Ce = np.zeros((V, U), np.float32)
+    mask = np.zeros((V, U), np.uint8)
+    lib().oracle_edge_confidence_pile(vol.reshape(-1), V, S, U, Cc, s, Ce.reshape(-1), mask.reshape(-1), C.byref(p))
+    return Ce, mask
+
+
+def selective_median(src, vol, s_hat, mask, size=5, epsilon=np.float32(0.1)):
+    vol = np.ascontiguousarray(vol, dtype=np.float32)
+    V, S, U, Cc = vol.shape
+    src = np.ascontiguousarray(src, dtype=np.float32)
+    mask = np.ascontiguousarray(mask, dtype=np.uint8)
+    dst = np.zeros((V, U), np.float32)
+    lib().oracle_selective_median(src.reshape(-1), dst.reshape(-1), vol.reshape(-1), V, S, U, Cc, s_hat, size,
+                                  mask.reshape(-1), float(epsilon))
+    return dst
+
+
+def depth_epi(epi, dmin_u, dmax_u, dim_d, s_hat, Ce_u, Ce_mask_u, params=None, mask_u=None, want_K=False):
+    """One EPI [S,U,C] (core.hpp:480-661). Returns dict of updated rows."""
+    epi = np.ascontiguousarray(epi, dtype=np.float32)
+    S, U, Cc = epi.shape
+    p = params or default_params()
+    Ce = np.array(Ce_u, np.float32, copy=True)
+    cm = np.array(Ce_mask_u, np.uint8, copy=True)
+    Cd = np.zeros(U, np.float32)
+    depth = np.zeros(U, np.float32)
+    rbar = np.zeros((U, Cc), np.float32)
+    idx = np.full(U, -1, np.int32)
+    score = np.zeros(U, np.float32)
+    K = np.zeros((S, U), np.float32) if want_K else None
+    m = None if mask_u is None else np.array(mask_u, np.uint8, copy=True)
+    lib().oracle_depth_epi(epi.reshape(-1), S, U, Cc,
+                           np.ascontiguousarray(dmin_u, np.float32), np.ascontiguousarray(dmax_u, np.float32),
+                           dim_d, s_hat, Ce, cm, Cd, depth, rbar.reshape(-1), C.byref(p),
+                           _ptr(m), _ptr(idx), _ptr(score), _ptr(K))
+    return dict(Ce=Ce, Ce_mask=cm, Cd=Cd, depth=depth, rbar=rbar, idx=idx, score=score, K=K, mask=m)
+
+
+def depth_epi_pile(vol, dmin_vu, dmax_vu, dim_d, s_hat, Ce_vu, Ce_mask_vu, params=None, mask_vu=None) -> PileResult:
+    """core.hpp:772-893 on caller-supplied C_e / mask planes (copied)."""
+    vol = np.ascontiguousarray(vol, dtype=np.float32)
+    V, S, U, Cc = vol.shape
+    p = params or default_params()
+    Ce = np.array(Ce_vu, np.float32, copy=True)
+    cm = np.array(Ce_mask_vu, np.uint8, copy=True)
+    Cd = np.zeros((V, U), np.float32)
+    depth = np.zeros((V, U), np.float32)
+    rbar = np.zeros((V, U, Cc), np.float32)
+    idx = np.full((V, U), -1, np.int32)
+    score = np.zeros((V, U), np.float32)
+    raw = np.zeros((V, U), np.float32)
+    m = None if mask_vu is None else np.array(mask_vu, np.uint8, copy=True)
+    lib().oracle_depth_epi_pile(vol.reshape(-1), V, S, U, Cc,
+                                np.ascontiguousarray(dmin_vu, np.float32).reshape(-1),
+                                np.ascontiguousarray(dmax_vu, np.float32).reshape(-1),
+                                dim_d, s_hat, Ce.reshape(-1), cm.reshape(-1), Cd.reshape(-1), depth.reshape(-1),
+                                rbar.reshape(-1), C.byref(p), _ptr(m), _ptr(idx), _ptr(score), _ptr(raw))
+    return PileResult(Ce, cm, Cd, depth, rbar, idx, score, raw)
+
+
+def depth1d_pile_run(vol, dmin, dmax, dim_d, s_hat=-1, params=None) -> PileResult:
+    """Depth1DComputer_pile ctor+run() (dc.hpp:425-565) on a normalised volume."""
+    vol = np.ascontiguousarray(vol, dtype=np.float32)
+    V, S, U, Cc = vol.shape
+    p = params or default_params()
+    Ce = np.zeros((V, U), np.float32)
+    cm = np.zeros((V, U), np.uint8)
+    Cd = np.zeros((V, U), np.float32)
+    depth = np.zeros((V, U), np.float32)
+    rbar = np.zeros((V, U, Cc), np.float32)
+    idx = np.full((V, U), -1, np.int32)
+    score = np.zeros((V, U), np.float32)
+    raw = np.zeros((V, U), np.float32)
+    lib().oracle_depth1d_pile_run(vol.reshape(-1), V, S, U, Cc, dmin, dmax, dim_d, s_hat, C.byref(p),
+                                  Ce.reshape(-1), cm.reshape(-1), Cd.reshape(-1), depth.reshape(-1),
+                                  rbar.reshape(-1), idx.reshape(-1), score.reshape(-1), raw.reshape(-1))
+    return PileResult(Ce, cm, Cd, depth, rbar, idx, score, raw)
+
+
+def num_threads() -> int:
+    return int(lib().oracle_num_threads())

@@ -1,0 +1,211 @@
+"""Independent numpy restatement of the hot path, written matrix-pass by
+matrix-pass the way the reference's OpenCV code runs (S x D temporaries per
+pixel), to cross-check oracle/rslf_oracle.c, which restructures the loops.
+
+TEST INFRASTRUCTURE ONLY.  PARITY UNPINNED (see rslf_oracle.h).  Small cases
+only: it is a Python loop over pixels.
+
+All arrays are float32 and every numpy ufunc call on them is one IEEE binary32
+operation per element; sums over s use an explicit sequential loop (np.sum is
+pairwise and would re-associate).
+
+Reference lines followed are given per function; paths are relative to
+/root/reference/RSLightFields/.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+F = np.float32
+SQRT3 = 1.73205080757  # types.cpp:84
+
+
+def default_params() -> dict:
+    """include/rslf_depth_computation_core.hpp:16-31, 74-99."""
+    return dict(
+        edge_score_threshold=F(0.02),
+        raw_score_threshold=F(0.0),
+        mean_shift_max_iter=F(10),
+        edge_confidence_filter_size=9,
+        median_filter_size=5,
+        median_filter_epsilon=F(0.1),
+        slope_factor=F(1.0),
+        cut_shadows=True,
+        shadow_level=F(0.05 * SQRT3),
+        kernel_bandwidth=F(0.2),
+    )
+
+
+def _norm(x: np.ndarray) -> np.ndarray:
+    """norm<float> / norm<Vec3f> over the last axis (src/rslf_types.cpp:80-91)."""
+    if x.shape[-1] == 1:
+        return (np.abs(x[..., 0]).astype(np.float64) * SQRT3).astype(F)
+    return np.sqrt((x.astype(np.float64) ** 2).sum(axis=-1)).astype(F)
+
+
+def _reflect101(i: np.ndarray, n: int) -> np.ndarray:
+    i = i.copy()
+    if n == 1:
+        return np.zeros_like(i)
+    while True:
+        lo, hi = i < 0, i >= n
+        if not (lo.any() or hi.any()):
+            return i
+        i[lo] = -i[lo]
+        i[hi] = 2 * n - 2 - i[hi]
+
+
+def edge_confidence_row(row: np.ndarray, p: dict):
+    """core.hpp:426-478. row [U,C] f32 -> (C_e [U], mask [U])."""
+    U, C = row.shape
+    fs = p["edge_confidence_filter_size"]
+    ctr = (fs - 1) // 2
+    Ce = np.zeros(U, F)
+    u = np.arange(U)
+    for j in range(fs):
+        if j == ctr:
+            continue
+        q = _reflect101(u + j - ctr, U)
+        for c in range(C):
+            t = row[:, c] - row[q, c]          # filter2D, +1 centre / -1 at j
+            Ce = Ce + t * t                    # core.cpp:6-23
+    if p["cut_shadows"]:
+        Ce[_norm(row) < p["shadow_level"]] = F(0)
+    mask = np.where(Ce > p["edge_score_threshold"], 255, 0).astype(np.uint8)
+    return Ce, mask
+
+
+def _kernel(delta: np.ndarray, inv_h2: F, k1: F) -> np.ndarray:
+    """BandwidthKernel::evaluate_mat (src/rslf_kernels.cpp:16-26, 39-54).
+    delta [S,D,C] -> K [S,D]; NaN -> 0."""
+    with np.errstate(invalid="ignore"):
+        if delta.shape[-1] == 1:
+            q = (k1 * delta[..., 0]) * delta[..., 0]
+        else:
+            qc = (inv_h2 * delta) * delta
+            q = (qc[..., 0] + qc[..., 2]) + qc[..., 1]   # OpenCV 3.x reduceC_ order
+        o = F(1.0) - q
+        return np.where(o > 0, o, F(0)).astype(F)
+
+
+def scan_pixel(epi: np.ndarray, u: int, dmin: F, dmax: F, D: int, s_hat: int, p: dict):
+    """core.hpp:527-625 for one pixel. epi [S,U,C]. Returns (Dv, score, rbar, K)."""
+    S, U, C = epi.shape
+    h = F(p["kernel_bandwidth"])
+    inv_h2 = F(1.0 / np.float64(h * h))        # kernels.hpp:43
+    k1 = F(3.0) * inv_h2                       # kernels.cpp:21
+
+    Sv = (s_hat - np.arange(S)).astype(F)      # core.hpp:542
+    d = np.arange(D).astype(F)
+    Dv = F(dmin) + (d * (F(dmax) - F(dmin))) / F(D - 1)   # core.hpp:548
+    I = Sv[:, None] * Dv[None, :]              # core.hpp:550 (gemm, K = 1)
+    I = I * F(p["slope_factor"])               # core.hpp:551
+    I = I + F(u)                               # core.hpp:552
+
+    i0 = np.floor(I).astype(np.int64)          # interp.hpp:179-181
+    i1 = np.ceil(I).astype(np.int64)
+    t = I - i0.astype(F)
+    valid = ~((i0 < 0) | (i1 > U - 1))         # interp.hpp:182
+    i0c, i1c = np.clip(i0, 0, U - 1), np.clip(i1, 0, U - 1)
+    rows = np.arange(S)[:, None]
+    R = (F(1) - t)[..., None] * epi[rows, i0c] + t[..., None] * epi[rows, i1c]   # interp.hpp:184
+    R = np.where(valid[..., None], R, F(np.nan)).astype(F)
+    card = np.zeros(D, F)
+    for s in range(S):
+        card = card + valid[s].astype(F)       # interp.hpp:185
+
+    rbar = R[s_hat].copy()                     # core.hpp:577  [D,C]
+    with np.errstate(invalid="ignore"):
+        R0 = np.where(R > 0, R, F(0)).astype(F)  # core.hpp:580
+
+    n_iter = 0
+    while F(n_iter) < p["mean_shift_max_iter"]:   # core.hpp:584 (float bound)
+        n_iter += 1
+    K = None
+    B = None
+    for _ in range(n_iter):
+        with np.errstate(invalid="ignore"):
+            delta = R - rbar[None]             # core.hpp:591
+        K = _kernel(delta, inv_h2, k1)         # core.hpp:595
+        P = R0 * K[..., None]                  # core.hpp:599
+        A = P[0].copy()                        # core.hpp:602: sequential rows
+        B = K[0].copy()                        # core.hpp:603
+        for s in range(1, S):
+            A = A + P[s]
+            B = B + K[s]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            q = np.where(B[:, None] != 0, A / B[:, None], F(0)).astype(F)   # core.hpp:606 (3.x: /0 -> 0)
+        rbar = np.where(q > 0, q, F(0)).astype(F)                            # core.hpp:609
+    with np.errstate(divide="ignore", invalid="ignore"):
+        score = np.where(card != 0, B / card, F(0)).astype(F)               # core.hpp:616-620
+    score = np.where(score > 0, score, F(0)).astype(F)                      # core.hpp:622
+    return Dv, score, rbar, K
+
+
+def depth_epi(epi, dmin_u, dmax_u, D, s_hat, Ce_u, Ce_mask_u, p, mask_u=None):
+    """core.hpp:480-661 for one EPI [S,U,C]."""
+    S, U, C = epi.shape
+    Ce = Ce_u.astype(F).copy()
+    cm = Ce_mask_u.astype(np.uint8).copy()
+    scan_mask = cm if mask_u is None else (cm & mask_u)      # core.hpp:510-513
+    scan_mask = scan_mask.copy()
+    Cd = np.zeros(U, F)
+    depth = np.zeros(U, F)
+    rbar_o = np.zeros((U, C), F)
+    idx = np.full(U, -1, np.int32)
+    score_o = np.zeros(U, F)
+    for u in np.flatnonzero(scan_mask):                      # core.hpp:516, 527
+        Dv, score, rbar, _ = scan_pixel(epi, int(u), dmin_u[u], dmax_u[u], D, s_hat, p)
+        best = int(np.argmax(score))                         # first maximum (core.hpp:634)
+        mx = np.float64(score[best])
+        if mx > np.float64(p["raw_score_threshold"]):       # core.hpp:636
+            depth[u] = Dv[best]
+            mean = score.astype(np.float64).sum() / D
+            Cd[u] = F(np.float64(Ce[u]) * abs(mx - mean))    # core.hpp:641
+            rbar_o[u] = rbar[best]
+            idx[u] = best
+            score_o[u] = score[best]
+        else:
+            Ce[u] = 0                                        # core.hpp:655-656
+            cm[u] = 0
+    return dict(Ce=Ce, Ce_mask=cm, Cd=Cd, depth=depth, rbar=rbar_o, idx=idx, score=score_o)
+
+
+def selective_median(src, vol, s_hat, mask, size, eps):
+    """core.hpp:663-718. vol [V,S,U,C]."""
+    V, S, U, C = vol.shape
+    w = (size - 1) // 2
+    dst = np.zeros((V, U), F)
+    ref = vol[:, s_hat]                                      # [V,U,C]
+    for v in range(V):
+        for u in range(U):
+            if not mask[v, u]:
+                continue
+            k0, k1 = max(0, v - w), min(V, v + w + 1)
+            l0, l1 = max(0, u - w), min(U, u + w + 1)
+            diff = ref[v, u][None, None] - ref[k0:k1, l0:l1]
+            ok = (mask[k0:k1, l0:l1] != 0) & (_norm(diff) < F(eps))
+            vals = np.sort(src[k0:k1, l0:l1][ok])
+            dst[v, u] = vals[len(vals) // 2]                 # nth_element at n/2
+    return dst
+
+
+def depth1d_pile_run(vol, dmin, dmax, D, s_hat=-1, p=None):
+    """Depth1DComputer_pile ctor + run() (dc.hpp:425-565) on a normalised volume."""
+    p = p or default_params()
+    V, S, U, C = vol.shape
+    if s_hat < 0 or s_hat > S - 1:
+        s_hat = int(np.floor((0.0 + S) / 2))
+    out = dict(Ce=np.zeros((V, U), F), Ce_mask=np.zeros((V, U), np.uint8), Cd=np.zeros((V, U), F),
+               depth_raw=np.zeros((V, U), F), rbar=np.zeros((V, U, C), F),
+               idx=np.full((V, U), -1, np.int32), score=np.zeros((V, U), F))
+    dmin_u = np.full(U, dmin, F)
+    dmax_u = np.full(U, dmax, F)
+    for v in range(V):
+        Ce, m = edge_confidence_row(vol[v, s_hat], p)
+        r = depth_epi(vol[v], dmin_u, dmax_u, D, s_hat, Ce, m, p)
+        out["Ce"][v], out["Ce_mask"][v], out["Cd"][v] = r["Ce"], r["Ce_mask"], r["Cd"]
+        out["depth_raw"][v], out["rbar"][v], out["idx"][v], out["score"][v] = r["depth"], r["rbar"], r["idx"], r["score"]
+    out["depth"] = selective_median(out["depth_raw"], vol, s_hat, out["Ce_mask"],
+                                    p["median_filter_size"], p["median_filter_epsilon"])
+    return out

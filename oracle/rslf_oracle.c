@@ -1,0 +1,562 @@
+/*
+ * rslf_oracle.c -- CPU restatement of the RSLightFields 1-D EPI depth scan.
+ *
+ * TEST INFRASTRUCTURE ONLY (see rslf_oracle.h).  PARITY UNPINNED: the
+ * reference ships no golden vectors and cannot be built in this image.
+ *
+ * Every float operation below is one IEEE-754 binary32 operation, in the order
+ * the reference performs it; build with -ffp-contract=off -fno-fast-math and
+ * WITHOUT an FMA-enabling -march (see oracle/Makefile).  Sums over s are
+ * sequential, ascending s, as cv::reduce(...,0,REDUCE_SUM) does
+ * (rslf_depth_computation_core.hpp:602-603).  Loops run d-innermost so the
+ * compiler can vectorise across hypotheses without re-associating anything.
+ */
+#include "rslf_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define SQRT3_D 1.73205080757 /* literal used by the reference: types.cpp:84, core.hpp:31 */
+
+void oracle_default_params(oracle_params* p)
+{
+    /* rslf_depth_computation_core.hpp:74-99 with the #defines of :16-31 */
+    p->edge_score_threshold = (float)0.02;
+    p->raw_score_threshold = (float)0;
+    p->mean_shift_max_iter = (float)10;
+    p->edge_confidence_filter_size = 9;
+    p->median_filter_size = 5;
+    p->median_filter_epsilon = (float)0.1;
+    p->slope_factor = (float)1.0;
+    p->cut_shadows = 1;
+    p->shadow_level = (float)(0.05 * SQRT3_D);
+    p->kernel_bandwidth = (float)0.2;
+}
+
+int oracle_num_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+/* ---- dc.hpp:442-477 --------------------------------------------------- */
+
+void oracle_normalize_u8(const uint8_t* in, float* out, size_t n)
+{
+    /* epi.convertTo(epi2, CV_32F, 1.0/255.0): float scale, dc.hpp:470 */
+    const float sc = (float)(1.0 / 255.0);
+    for (size_t i = 0; i < n; i++)
+        out[i] = (float)in[i] * sc;
+}
+
+float oracle_normalize_f32(const float* in, float* out, size_t n, float scale)
+{
+    if (scale < 0) {
+        /* dc.hpp:442-460: epi_scale_factor = max over all EPIs */
+        for (size_t i = 0; i < n; i++)
+            if (in[i] > scale)
+                scale = in[i];
+    }
+    /* convertTo(..., 1.0/epi_scale_factor): double quotient, cast to float
+     * inside cvtScale, dc.hpp:474 */
+    const float sc = (float)(1.0 / (double)scale);
+    for (size_t i = 0; i < n; i++)
+        out[i] = in[i] * sc;
+    return scale;
+}
+
+/* ---- types.cpp:80-91 -------------------------------------------------- */
+
+static inline float norm_px(const float* x, int C)
+{
+    if (C == 1) {
+        /* std::abs(x) * 1.73205080757 : float*double, returned as float */
+        return (float)((double)fabsf(x[0]) * SQRT3_D);
+    }
+    /* cv::norm(Vec3f): sqrt of a double sum of squares, returned as float */
+    double s = 0.0;
+    for (int c = 0; c < C; c++)
+        s += (double)x[c] * (double)x[c];
+    return (float)sqrt(s);
+}
+
+/* cv::BORDER_REFLECT_101 (core.hpp:458) */
+static inline int reflect101(int p, int len)
+{
+    if (len == 1)
+        return 0;
+    while (p < 0 || p >= len) {
+        if (p < 0)
+            p = -p;
+        else
+            p = 2 * len - 2 - p;
+    }
+    return p;
+}
+
+/* ---- core.hpp:426-478 ------------------------------------------------- */
+
+void oracle_edge_confidence_row(const float* row, int U, int C,
+                                float* Ce_u, uint8_t* mask_u,
+                                const oracle_params* p)
+{
+    const int fs = p->edge_confidence_filter_size;
+    const int center = (fs - 1) / 2; /* core.hpp:440 */
+
+    for (int j = 0; j < fs; j++) { /* core.hpp:449 */
+        if (j == center)
+            continue;
+        for (int u = 0; u < U; u++) {
+            /* filter2D with +1 at centre, -1 at j  => E[u] - E[u+j-centre] */
+            const int q = reflect101(u + j - center, U);
+            /* _square_sum_channels_into: per channel, dst += t*t (core.cpp:6-23) */
+            for (int c = 0; c < C; c++) {
+                const float t = row[(size_t)u * C + c] - row[(size_t)q * C + c];
+                const float t2 = t * t;
+                Ce_u[u] = Ce_u[u] + t2;
+            }
+        }
+    }
+
+    if (p->cut_shadows) { /* core.hpp:464-474 */
+        for (int u = 0; u < U; u++) {
+            const float n = norm_px(row + (size_t)u * C, C);
+            if (n < p->shadow_level)
+                Ce_u[u] = 0.0f;
+        }
+    }
+
+    for (int u = 0; u < U; u++) /* core.hpp:476 */
+        mask_u[u] = (Ce_u[u] > p->edge_score_threshold) ? 255 : 0;
+}
+
+/* ---- core.hpp:728-770 ------------------------------------------------- */
+
+void oracle_edge_confidence_pile(const float* vol, int V, int S, int U, int C,
+                                 int s, float* Ce_vu, uint8_t* mask_vu,
+                                 const oracle_params* p)
+{
+#pragma omp parallel for schedule(static)
+    for (int v = 0; v < V; v++) { /* core.hpp:743 */
+        const float* row = vol + (((size_t)v * S + s) * U) * C;
+        oracle_edge_confidence_row(row, U, C, Ce_vu + (size_t)v * U,
+                                   mask_vu + (size_t)v * U, p);
+    }
+    /* par_edge_confidence_opening_size == 1: no morphology (core.hpp:759, :29) */
+}
+
+/* ---- core.hpp:480-661 ------------------------------------------------- */
+
+typedef struct scan_scratch {
+    float* R;    /* [C][S][D] radiances, NaN where out of range */
+    float* R0;   /* [C][S][D] NaN -> 0 (core.hpp:580) */
+    float* Kmat; /* [S][D] last kernel values */
+    float* Dv;   /* [D] hypothesis values */
+    float* card; /* [D] */
+    float* rbar; /* [C][D] */
+    float* A;    /* [C][D] */
+    float* B;    /* [D] */
+    float* score;/* [D] */
+    float* x;    /* [D] temp */
+} scan_scratch;
+
+static int scratch_alloc(scan_scratch* w, int S, int D, int C)
+{
+    size_t sd = (size_t)S * D;
+    w->R = (float*)malloc(sizeof(float) * sd * C);
+    w->R0 = (float*)malloc(sizeof(float) * sd * C);
+    w->Kmat = (float*)malloc(sizeof(float) * sd);
+    w->Dv = (float*)malloc(sizeof(float) * D);
+    w->card = (float*)malloc(sizeof(float) * D);
+    w->rbar = (float*)malloc(sizeof(float) * D * C);
+    w->A = (float*)malloc(sizeof(float) * D * C);
+    w->B = (float*)malloc(sizeof(float) * D);
+    w->score = (float*)malloc(sizeof(float) * D);
+    w->x = (float*)malloc(sizeof(float) * D);
+    return w->R && w->R0 && w->Kmat && w->Dv && w->card && w->rbar && w->A && w->B && w->score && w->x;
+}
+
+static void scratch_free(scan_scratch* w)
+{
+    free(w->R); free(w->R0); free(w->Kmat); free(w->Dv); free(w->card);
+    free(w->rbar); free(w->A); free(w->B); free(w->score); free(w->x);
+}
+
+/* BandwidthKernel::evaluate_mat (kernels.cpp:16-26 / 39-54) over one s-row of
+ * hypotheses; delta_c = R_c - rbar_c is formed here (core.hpp:591). */
+static inline void kernel_row(const float* const* Rrow, const float* const* rbar,
+                              int D, int C, float inv_h2, float k1, float* K)
+{
+    if (C == 1) {
+        const float* r = Rrow[0];
+        const float* rb = rbar[0];
+        for (int d = 0; d < D; d++) {
+            const float delta = r[d] - rb[d];
+            /* cv::multiply(src, src, dst, 3*inv_m_h_sq): (scale*a)*b */
+            const float t = k1 * delta;
+            const float q = t * delta;
+            /* cv::subtract(1.0, dst, dst) */
+            const float o = 1.0f - q;
+            /* cv::max(dst, 0.0, dst), NaN -> 0 */
+            K[d] = (o > 0.0f) ? o : 0.0f;
+        }
+    } else {
+        for (int d = 0; d < D; d++) {
+            float q[3];
+            for (int c = 0; c < 3; c++) {
+                const float delta = Rrow[c][d] - rbar[c][d];
+                const float t = inv_h2 * delta;
+                q[c] = t * delta;
+            }
+            /* cv::reduce(dst, dst, 1, REDUCE_SUM) over 3 columns:
+             * OpenCV 3.x reduceC_ keeps two accumulators: (q0 + q2) + q1 */
+            float a0 = q[0] + q[2];
+            a0 = a0 + q[1];
+            const float o = 1.0f - a0;
+            K[d] = (o > 0.0f) ? o : 0.0f;
+        }
+    }
+}
+
+static void scan_pixel(const float* epi, int S, int U, int C, int u,
+                       float dmin, float dmax, int D, int s_hat,
+                       const oracle_params* p, scan_scratch* w,
+                       float inv_h2, float k1, int n_iter)
+{
+    const size_t SD = (size_t)S * D;
+
+    /* core.hpp:545-548: D[d] = dmin + d * (dmax - dmin) / (dim_d - 1) */
+    const float range = dmax - dmin;
+    const float denom = (float)(D - 1);
+    for (int d = 0; d < D; d++) {
+        const float num = (float)d * range;
+        const float quo = num / denom;
+        w->Dv[d] = dmin + quo;
+    }
+
+    memset(w->card, 0, sizeof(float) * D);
+
+    /* core.hpp:550-552 + interp.hpp:155-193 */
+    const float uf = (float)u;
+    const float Um1 = (float)(U - 1);
+    (void)Um1;
+    for (int s = 0; s < S; s++) {
+        const float Ss = (float)(s_hat - s); /* core.hpp:542 */
+        const float* erow = epi + (size_t)s * U * C;
+        for (int d = 0; d < D; d++) {
+            float xi = Ss * w->Dv[d];       /* I = S * D (gemm, K=1)    */
+            xi = xi * p->slope_factor;      /* I *= par_slope_factor    */
+            xi = xi + uf;                   /* I += u                   */
+            const int i0 = (int)floorf(xi); /* interp.hpp:179           */
+            const int i1 = (int)ceilf(xi);  /* interp.hpp:180           */
+            const float t = xi - (float)i0; /* interp.hpp:181           */
+            if (!(i0 < 0 || i1 > U - 1)) {  /* interp.hpp:182           */
+                const float omt = 1.0f - t;
+                for (int c = 0; c < C; c++) {
+                    const float a = omt * erow[(size_t)i0 * C + c];
+                    const float b = t * erow[(size_t)i1 * C + c];
+                    const float r = a + b;  /* interp.hpp:184           */
+                    w->R[c * SD + (size_t)s * D + d] = r;
+                    /* cv::max(R, 0) (core.hpp:580) */
+                    w->R0[c * SD + (size_t)s * D + d] = (r > 0.0f) ? r : 0.0f;
+                }
+                w->card[d] = w->card[d] + 1.0f;
+            } else {
+                for (int c = 0; c < C; c++) {
+                    w->R[c * SD + (size_t)s * D + d] = NAN; /* interp.hpp:189 */
+                    w->R0[c * SD + (size_t)s * D + d] = 0.0f;
+                }
+            }
+        }
+    }
+
+    /* core.hpp:577: r_bar <- R[s_hat,:] */
+    for (int c = 0; c < C; c++)
+        memcpy(w->rbar + (size_t)c * D, w->R + c * SD + (size_t)s_hat * D, sizeof(float) * D);
+
+    const float* rbarp[3];
+    for (int c = 0; c < C; c++)
+        rbarp[c] = w->rbar + (size_t)c * D;
+
+    /* core.hpp:584-610 */
+    for (int it = 0; it < n_iter; it++) {
+        for (int s = 0; s < S; s++) {
+            const float* Rrow[3];
+            for (int c = 0; c < C; c++)
+                Rrow[c] = w->R + c * SD + (size_t)s * D;
+            float* K = w->Kmat + (size_t)s * D;
+            kernel_row(Rrow, rbarp, D, C, inv_h2, k1, K);
+            /* r*K (core.cpp:25-37) and the column sums (core.hpp:602-603):
+             * cv::reduce starts from row 0 and adds rows in order */
+            if (s == 0) {
+                for (int c = 0; c < C; c++) {
+                    const float* r0 = w->R0 + c * SD;
+                    float* A = w->A + (size_t)c * D;
+                    for (int d = 0; d < D; d++)
+                        A[d] = r0[d] * K[d];
+                }
+                for (int d = 0; d < D; d++)
+                    w->B[d] = K[d];
+            } else {
+                for (int c = 0; c < C; c++) {
+                    const float* r0 = w->R0 + c * SD + (size_t)s * D;
+                    float* A = w->A + (size_t)c * D;
+                    for (int d = 0; d < D; d++) {
+                        const float pr = r0[d] * K[d];
+                        A[d] = A[d] + pr;
+                    }
+                }
+                for (int d = 0; d < D; d++)
+                    w->B[d] = w->B[d] + K[d];
+            }
+        }
+        /* _divide_multi_channel (core.cpp:39-51): OpenCV 3.x, divisor 0 -> 0;
+         * then cv::max(r_bar, 0) (core.hpp:609) */
+        for (int c = 0; c < C; c++) {
+            float* rb = w->rbar + (size_t)c * D;
+            const float* A = w->A + (size_t)c * D;
+            for (int d = 0; d < D; d++) {
+                float q = (w->B[d] != 0.0f) ? (A[d] / w->B[d]) : 0.0f;
+                rb[d] = (q > 0.0f) ? q : 0.0f;
+            }
+        }
+    }
+
+    /* core.hpp:616-622: K is re-evaluated on the last r - r_bar, i.e. it
+     * equals the last iteration's K, and its column sum the last B. */
+    for (int d = 0; d < D; d++) {
+        float sc = (w->card[d] != 0.0f) ? (w->B[d] / w->card[d]) : 0.0f;
+        w->score[d] = (sc > 0.0f) ? sc : 0.0f;
+    }
+}
+
+static int iter_count(float max_iter)
+{
+    /* for (int i=0; i < par_mean_shift_max_iter; i++) with a float bound
+     * (core.hpp:584, :115) */
+    int n = 0;
+    while ((float)n < max_iter)
+        n++;
+    return n;
+}
+
+static void kernel_consts(const oracle_params* p, float* inv_h2, float* k1)
+{
+    /* kernels.hpp:43: inv_m_h_sq = 1.0 / (m_h_ * m_h_) -- float product,
+     * double quotient, float store */
+    const float h = p->kernel_bandwidth;
+    const float hh = h * h;
+    *inv_h2 = (float)(1.0 / (double)hh);
+    /* kernels.cpp:21: 3 * inv_m_h_sq (float), passed as double scale, used as float */
+    *k1 = 3.0f * (*inv_h2);
+}
+
+static void depth_epi_impl(const float* epi, int S, int U, int C,
+                           const float* dmin_u, const float* dmax_u,
+                           int dim_d, int s_hat,
+                           float* Ce_u, uint8_t* Ce_mask_u,
+                           float* Cd_u, float* depth_u, float* rbar_u,
+                           const oracle_params* p, uint8_t* mask_u,
+                           int32_t* idx_u, float* score_u, float* K_su,
+                           scan_scratch* w)
+{
+    float inv_h2, k1;
+    kernel_consts(p, &inv_h2, &k1);
+    const int n_iter = iter_count(p->mean_shift_max_iter);
+    const int D = dim_d;
+
+    /* core.hpp:510-513 */
+    if (mask_u) {
+        for (int u = 0; u < U; u++)
+            mask_u[u] = Ce_mask_u[u] & mask_u[u];
+    }
+    const uint8_t* scan_mask = mask_u ? mask_u : Ce_mask_u;
+
+    for (int u = 0; u < U; u++) { /* core.hpp:527 (findNonZero order = ascending u) */
+        if (idx_u)
+            idx_u[u] = -1;
+        if (score_u)
+            score_u[u] = 0.0f;
+        if (!scan_mask[u])
+            continue;
+
+        scan_pixel(epi, S, U, C, u, dmin_u[u], dmax_u[u], D, s_hat, p, w, inv_h2, k1, n_iter);
+
+        /* core.hpp:630-634: minMaxLoc, first maximum */
+        int best = 0;
+        float bestv = w->score[0];
+        for (int d = 1; d < D; d++) {
+            if (w->score[d] > bestv) {
+                bestv = w->score[d];
+                best = d;
+            }
+        }
+        const double maxVal = (double)bestv;
+        if (maxVal > (double)p->raw_score_threshold) { /* core.hpp:636 */
+            depth_u[u] = w->Dv[best];                  /* core.hpp:638 */
+            /* core.hpp:641: C_e * |max - mean(score)| in double */
+            double sum = 0.0;
+            for (int d = 0; d < D; d++)
+                sum += (double)w->score[d];
+            const double mean = sum / (double)D;
+            Cd_u[u] = (float)((double)Ce_u[u] * fabs(maxVal - mean));
+            for (int c = 0; c < C; c++)                /* core.hpp:644 */
+                rbar_u[(size_t)u * C + c] = w->rbar[(size_t)c * D + best];
+            if (K_su) {                                /* core.hpp:647-651 */
+                for (int s = 0; s < S; s++)
+                    K_su[(size_t)s * U + u] = w->Kmat[(size_t)s * D + best];
+            }
+            if (idx_u)
+                idx_u[u] = best;
+            if (score_u)
+                score_u[u] = bestv;
+        } else {                                       /* core.hpp:653-657 */
+            Ce_u[u] = 0.0f;
+            Ce_mask_u[u] = 0;
+        }
+    }
+}
+
+void oracle_depth_epi(const float* epi, int S, int U, int C,
+                      const float* dmin_u, const float* dmax_u,
+                      int dim_d, int s_hat,
+                      float* Ce_u, uint8_t* Ce_mask_u,
+                      float* Cd_u, float* depth_u, float* rbar_u,
+                      const oracle_params* p, uint8_t* mask_u,
+                      int32_t* idx_u, float* score_u, float* K_su)
+{
+    scan_scratch w;
+    if (!scratch_alloc(&w, S, dim_d, C))
+        abort();
+    depth_epi_impl(epi, S, U, C, dmin_u, dmax_u, dim_d, s_hat, Ce_u, Ce_mask_u,
+                   Cd_u, depth_u, rbar_u, p, mask_u, idx_u, score_u, K_su, &w);
+    scratch_free(&w);
+}
+
+/* ---- core.hpp:663-718 ------------------------------------------------- */
+
+static int cmp_float(const void* a, const void* b)
+{
+    const float x = *(const float*)a, y = *(const float*)b;
+    return (x > y) - (x < y);
+}
+
+void oracle_selective_median(const float* src_vu, float* dst_vu,
+                             const float* vol, int V, int S, int U, int C,
+                             int s_hat, int size, const uint8_t* mask_vu,
+                             float epsilon)
+{
+    const int width = (size - 1) / 2; /* core.hpp:686 */
+#pragma omp parallel for schedule(static)
+    for (int v = 0; v < V; v++) {
+        float* buf = (float*)malloc(sizeof(float) * (size_t)size * size);
+        for (int u = 0; u < U; u++) {
+            if (!mask_vu[(size_t)v * U + u]) /* core.hpp:695 */
+                continue;
+            const float* pc = vol + (((size_t)v * S + s_hat) * U + u) * C;
+            int n = 0;
+            const int k0 = v - width < 0 ? 0 : v - width;
+            const int k1 = v + width + 1 > V ? V : v + width + 1;
+            const int l0 = u - width < 0 ? 0 : u - width;
+            const int l1 = u + width + 1 > U ? U : u + width + 1;
+            for (int k = k0; k < k1; k++) {
+                for (int l = l0; l < l1; l++) {
+                    if (!mask_vu[(size_t)k * U + l])
+                        continue;
+                    const float* pn = vol + (((size_t)k * S + s_hat) * U + l) * C;
+                    float df[3];
+                    for (int c = 0; c < C; c++)
+                        df[c] = pc[c] - pn[c];
+                    if (norm_px(df, C) < epsilon) /* core.hpp:703-706 */
+                        buf[n++] = src_vu[(size_t)k * U + l];
+                }
+            }
+            /* std::nth_element(..., n/2): the n/2-th order statistic */
+            qsort(buf, (size_t)n, sizeof(float), cmp_float);
+            dst_vu[(size_t)v * U + u] = buf[n / 2];
+        }
+        free(buf);
+    }
+}
+
+/* ---- core.hpp:772-893 ------------------------------------------------- */
+
+void oracle_depth_epi_pile(const float* vol, int V, int S, int U, int C,
+                           const float* dmin_vu, const float* dmax_vu,
+                           int dim_d, int s_hat,
+                           float* Ce_vu, uint8_t* Ce_mask_vu,
+                           float* Cd_vu, float* depth_vu, float* rbar_vu,
+                           const oracle_params* p, uint8_t* mask_vu,
+                           int32_t* idx_vu, float* score_vu,
+                           float* depth_raw_vu)
+{
+#pragma omp parallel
+    {
+        scan_scratch w;
+        if (!scratch_alloc(&w, S, dim_d, C))
+            abort();
+#pragma omp for schedule(dynamic, 1)
+        for (int v = 0; v < V; v++) { /* core.hpp:799 */
+            const size_t o = (size_t)v * U;
+            depth_epi_impl(vol + (size_t)v * S * U * C, S, U, C,
+                           dmin_vu + o, dmax_vu + o, dim_d, s_hat,
+                           Ce_vu + o, Ce_mask_vu + o, Cd_vu + o, depth_vu + o,
+                           rbar_vu + o * C, p, mask_vu ? mask_vu + o : NULL,
+                           idx_vu ? idx_vu + o : NULL,
+                           score_vu ? score_vu + o : NULL, NULL, &w);
+        }
+        scratch_free(&w);
+    }
+
+    if (depth_raw_vu)
+        memcpy(depth_raw_vu, depth_vu, sizeof(float) * (size_t)V * U);
+
+    /* core.hpp:881-892: the median reads the EDGE mask, output starts at 0,
+     * and replaces best_depth */
+    float* tmp = (float*)calloc((size_t)V * U, sizeof(float));
+    oracle_selective_median(depth_vu, tmp, vol, V, S, U, C, s_hat,
+                            p->median_filter_size, Ce_mask_vu,
+                            p->median_filter_epsilon);
+    memcpy(depth_vu, tmp, sizeof(float) * (size_t)V * U);
+    free(tmp);
+}
+
+/* ---- dc.hpp:425-565 --------------------------------------------------- */
+
+void oracle_depth1d_pile_run(const float* vol, int V, int S, int U, int C,
+                             float dmin, float dmax, int dim_d, int s_hat,
+                             const oracle_params* p,
+                             float* Ce_vu, uint8_t* Ce_mask_vu,
+                             float* Cd_vu, float* depth_vu, float* rbar_vu,
+                             int32_t* idx_vu, float* score_vu,
+                             float* depth_raw_vu)
+{
+    const size_t n = (size_t)V * U;
+    if (s_hat < 0 || s_hat > S - 1)
+        s_hat = (int)floor((0.0 + S) / 2); /* dc.hpp:490-494 */
+
+    float* dmin_vu = (float*)malloc(sizeof(float) * n);
+    float* dmax_vu = (float*)malloc(sizeof(float) * n);
+    for (size_t i = 0; i < n; i++) { /* dc.hpp:486-487 */
+        dmin_vu[i] = dmin;
+        dmax_vu[i] = dmax;
+    }
+    memset(Ce_vu, 0, sizeof(float) * n); /* the reference leaves this uninitialised (dc.hpp:501) */
+    memset(Cd_vu, 0, sizeof(float) * n);
+    memset(depth_vu, 0, sizeof(float) * n);       /* dc.hpp:507 */
+    memset(rbar_vu, 0, sizeof(float) * n * C);    /* dc.hpp:510 */
+
+    oracle_edge_confidence_pile(vol, V, S, U, C, s_hat, Ce_vu, Ce_mask_vu, p); /* dc.hpp:538 */
+    oracle_depth_epi_pile(vol, V, S, U, C, dmin_vu, dmax_vu, dim_d, s_hat,     /* dc.hpp:547 */
+                          Ce_vu, Ce_mask_vu, Cd_vu, depth_vu, rbar_vu, p, NULL,
+                          idx_vu, score_vu, depth_raw_vu);
+    free(dmin_vu);
+    free(dmax_vu);
+}

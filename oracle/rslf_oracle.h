@@ -1,0 +1,127 @@
+/*
+ * rslf_oracle.h -- CPU restatement of the RSLightFields 1-D EPI depth scan.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This is the checker the HIP path is compared
+ * against; nothing under remotesensingproject_amd/ or include/ may call it.
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it.
+ *
+ * PARITY UNPINNED: the reference (14chanwa/remotesensingProject) holds no
+ * golden vectors, known-answer tests or assertions for this path, and it
+ * cannot be built here (it needs OpenCV 3.x, which this image lacks).  The
+ * oracle is therefore a restatement of the reference's source, op for op,
+ * pinned only by (a) an analytic known-answer case, (b) an independent numpy
+ * restatement (oracle/oracle_np.py) agreeing bit for bit, and (c) the c1 anchor
+ * of SURVEY.md 8c.  OpenCV 3.x primitive semantics it relies on are listed in
+ * DESIGN.md.
+ *
+ * Layout: the light-field volume is [V][S][U][C] float32, C interleaved --
+ * the reference's Vec<Mat> of V EPIs, each an S x U Mat of C channels
+ * (rslf_io.cpp:194-227), stored back to back.
+ *
+ * Reference files followed (paths relative to RSLightFields/):
+ *   include/rslf_depth_computation_core.hpp:426-478  edge confidence
+ *   include/rslf_depth_computation_core.hpp:480-661  per-EPI scan
+ *   include/rslf_depth_computation_core.hpp:663-718  selective median
+ *   include/rslf_depth_computation_core.hpp:728-893  pile drivers
+ *   include/rslf_interpolation.hpp:155-193           linear gather
+ *   src/rslf_kernels.cpp:16-26,39-54                 bandwidth kernel
+ *   src/rslf_depth_computation_core.cpp:6-51         channel helpers
+ *   src/rslf_types.cpp:80-91                         norm<>
+ *   include/rslf_depth_computation.hpp:425-565       ctor normalisation + run()
+ */
+#ifndef RSLF_ORACLE_H
+#define RSLF_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Mirrors rslf::Depth1DParameters (rslf_depth_computation_core.hpp:66-142).
+ * Field names follow the reference's par_* members. */
+typedef struct oracle_params {
+    float edge_score_threshold;      /* _EDGE_SCORE_THRESHOLD 0.02      core.hpp:20  */
+    float raw_score_threshold;       /* _RAW_SCORE_THRESHOLD 0          core.hpp:23  */
+    float mean_shift_max_iter;       /* declared float in the reference core.hpp:115 */
+    int   edge_confidence_filter_size;/* 9                              core.hpp:17  */
+    int   median_filter_size;        /* 5                               core.hpp:18  */
+    float median_filter_epsilon;     /* 0.1                             core.hpp:19  */
+    float slope_factor;              /* 1.0                             core.hpp:95  */
+    int   cut_shadows;               /* true                            core.hpp:97  */
+    float shadow_level;              /* 0.05*sqrt(3)                    core.hpp:31  */
+    float kernel_bandwidth;          /* h = 0.2                         core.hpp:26  */
+} oracle_params;
+
+void oracle_default_params(oracle_params* p);
+
+/* dc.hpp:442-477.  u8: x*float(1/255).  f32: x*float(1/double(scale)); when
+ * scale<0 it is first replaced by the max over the whole volume. Returns the
+ * scale used. */
+void  oracle_normalize_u8(const uint8_t* in, float* out, size_t n);
+float oracle_normalize_f32(const float* in, float* out, size_t n, float scale);
+
+/* core.hpp:426-478 for one row.  Ce_u accumulates INTO the caller's buffer
+ * (core.cpp:10) -- pass zeros.  row = U*C interleaved floats. */
+void oracle_edge_confidence_row(const float* row, int U, int C,
+                                float* Ce_u, uint8_t* mask_u,
+                                const oracle_params* p);
+
+/* core.hpp:728-770 (opening size 1 => no morphology). vol = [V][S][U][C]. */
+void oracle_edge_confidence_pile(const float* vol, int V, int S, int U, int C,
+                                 int s, float* Ce_vu, uint8_t* mask_vu,
+                                 const oracle_params* p);
+
+/* core.hpp:480-661 for one EPI.
+ * epi [S][U][C]; dmin_u/dmax_u [U]; Ce_u, Ce_mask_u in/out;
+ * mask_u nullable (then the edge mask is the scan mask, core.hpp:510-513);
+ * when non-null it is AND-ed in place with the edge mask (core.hpp:511).
+ * Extra outputs (nullable), not in the reference, used by parity tests:
+ *   idx_u       argmax index d*, -1 where not scanned or rejected
+ *   score_u     score[d*]
+ *   K_su [S][U] K(r - rbar) column of d* (core.hpp:647-651), nullable */
+void oracle_depth_epi(const float* epi, int S, int U, int C,
+                      const float* dmin_u, const float* dmax_u,
+                      int dim_d, int s_hat,
+                      float* Ce_u, uint8_t* Ce_mask_u,
+                      float* Cd_u, float* depth_u, float* rbar_u,
+                      const oracle_params* p, uint8_t* mask_u,
+                      int32_t* idx_u, float* score_u, float* K_su);
+
+/* core.hpp:663-718. dst must be zero-filled by the caller (core.hpp:678-679). */
+void oracle_selective_median(const float* src_vu, float* dst_vu,
+                             const float* vol, int V, int S, int U, int C,
+                             int s_hat, int size, const uint8_t* mask_vu,
+                             float epsilon);
+
+/* core.hpp:772-893: scan every EPI (OpenMP over v), then the selective median
+ * replaces depth_vu (core.hpp:892).  depth_raw_vu (nullable) receives the
+ * pre-median plane.  mask_vu nullable as above.  */
+void oracle_depth_epi_pile(const float* vol, int V, int S, int U, int C,
+                           const float* dmin_vu, const float* dmax_vu,
+                           int dim_d, int s_hat,
+                           float* Ce_vu, uint8_t* Ce_mask_vu,
+                           float* Cd_vu, float* depth_vu, float* rbar_vu,
+                           const oracle_params* p, uint8_t* mask_vu,
+                           int32_t* idx_vu, float* score_vu,
+                           float* depth_raw_vu);
+
+/* Depth1DComputer_pile ctor + run() (dc.hpp:425-565) on an already
+ * normalised volume: zero-inits outputs (fixing the reference's
+ * uninitialised C_e, dc.hpp:501), constant dmin/dmax planes, s_hat<0 =>
+ * floor(S/2), edge confidence, scan, median. */
+void oracle_depth1d_pile_run(const float* vol, int V, int S, int U, int C,
+                             float dmin, float dmax, int dim_d, int s_hat,
+                             const oracle_params* p,
+                             float* Ce_vu, uint8_t* Ce_mask_vu,
+                             float* Cd_vu, float* depth_vu, float* rbar_vu,
+                             int32_t* idx_vu, float* score_vu,
+                             float* depth_raw_vu);
+
+int oracle_num_threads(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
