@@ -1,0 +1,199 @@
+/*
+ * rslf_hip.h -- C-ABI of the MI355X-native EPI depth scan.
+ *
+ * This is the drop-in boundary for ONE path of RSLightFields
+ * (14chanwa/remotesensingProject): everything below
+ * rslf::Depth1DComputer_pile<T>::run() -- the scanline-parallel edge
+ * confidence, the per-pixel x per-hypothesis EPI-slope scan with its mean
+ * shift, and the selective median -- runs as hand-written HIP kernels for
+ * gfx950.  The reference has no FFI of its own (it is one C++11/OpenCV/OpenMP
+ * library); the seam is the template free-function signatures cited per entry
+ * point below (paths relative to /root/reference/RSLightFields/).  The C++11
+ * host class that keeps the reference's constructor/run() shape is
+ * include/rslf_hip.hpp; the binding a maintainer would add on the reference
+ * side is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *  - plain C, no C++/torch/OpenCV types; every function returns an rslf_status
+ *    (0 = ok, <0 = error) and never throws across the boundary.  (The
+ *    reference returns void and has no error convention: SURVEY.md 8b.)
+ *  - pointers named d_* are DEVICE pointers, h_* are HOST pointers; all
+ *    buffers are caller-owned; planes are dense row-major [V][U].
+ *  - work is enqueued on the context's stream (rslf_ctx_set_stream, a
+ *    hipStream_t passed as void*); *_host entry points synchronise before
+ *    returning, device entry points do not.
+ *  - a context is not re-entrant; use one per host thread / stream.
+ *  - there is NO CPU fallback behind this ABI.
+ */
+#ifndef RSLF_HIP_H
+#define RSLF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RSLF_ABI_VERSION 1
+
+typedef enum rslf_status {
+    RSLF_OK = 0,
+    RSLF_ERR_INVALID_ARG = -1,   /* null pointer, bad dimension, dim_d < 2, ... */
+    RSLF_ERR_UNSUPPORTED = -2,   /* channel count other than 1 or 3, filter sizes the kernels do not cover */
+    RSLF_ERR_HIP = -3,           /* a HIP runtime call failed; see rslf_last_error() */
+    RSLF_ERR_NO_DEVICE = -4,     /* no gfx950 device visible */
+    RSLF_ERR_ALLOC = -5
+} rslf_status;
+
+/* Mirrors rslf::Depth1DParameters<T> -- include/rslf_depth_computation_core.hpp:66-142
+ * (defaults :16-31, :74-99).  Same member meaning, par_ prefix dropped.  The two
+ * polymorphic plug-ins (:108-109) are fixed to the reference's defaults:
+ * Interpolation1DLinear (include/rslf_interpolation.hpp:155-193) and
+ * BandwidthKernel(h) (src/rslf_kernels.cpp:16-54), h = kernel_bandwidth. */
+typedef struct rslf_params {
+    float edge_score_threshold;         /* 0.02 */
+    float line_score_threshold;         /* 0.02  (unused by this path, kept for 1:1 layout) */
+    float disp_score_threshold;         /* 0.01  (unused by this path) */
+    float raw_score_threshold;          /* 0 */
+    float mean_shift_max_iter;          /* 10; a float in the reference (:115) */
+    int   edge_confidence_filter_size;  /* 9 */
+    int   edge_confidence_opening_type; /* cv::MORPH_ELLIPSE = 2 (unused: size 1) */
+    int   edge_confidence_opening_size; /* 1 = no morphological opening; >1 is RSLF_ERR_UNSUPPORTED */
+    int   median_filter_size;           /* 5 (odd, <= 7) */
+    float median_filter_epsilon;        /* 0.1 */
+    float propagation_epsilon;          /* 0.1 (unused by this path) */
+    float slope_factor;                 /* 1.0 */
+    int   cut_shadows;                  /* 1 */
+    float shadow_level;                 /* 0.05 * 1.73205080757 */
+    float kernel_bandwidth;             /* 0.2 (_BANDWIDTH_KERNEL_PARAMETER, :26) */
+} rslf_params;
+
+typedef struct rslf_ctx rslf_ctx;       /* device, stream, scratch */
+typedef struct rslf_volume rslf_volume; /* light-field slab resident in HBM */
+
+typedef struct rslf_volume_desc {
+    int V, S, U, C;       /* scanlines, views, columns, channels */
+    int pitch;            /* floats per (v,s,c) row, multiple of 64, > U (zero padded) */
+    void* d_base;         /* device address of element (v=0,s=0,c=0,u=0) */
+    size_t bytes;         /* allocation size */
+    float min_value;      /* over the normalised volume */
+    float max_value;
+} rslf_volume_desc;
+
+/* Per-call statistics (nullable wherever taken). */
+typedef struct rslf_stats {
+    int64_t pixels_scanned;   /* pixels whose scan mask was set on entry (core.hpp:515-527) */
+    int64_t units;            /* pixels_scanned * dim_d  = (pixel, hypothesis) pairs */
+    int     scan_kernel;      /* which K2 variant ran: see RSLF_SCAN_* */
+    int     s_pad;            /* register slots per lane of the register variant, else 0 */
+} rslf_stats;
+
+#define RSLF_SCAN_GENERIC   0  /* any S, C in {1,3}, any sign: re-gathers every mean-shift pass */
+#define RSLF_SCAN_REG_1CH   1  /* C=1, S<=128, volume >= 0: samples held in VGPRs */
+
+int         rslf_abi_version(void);
+const char* rslf_status_string(int status);
+const char* rslf_last_error(void);       /* thread-local text of the last failure */
+int         rslf_device_count(void);
+/* rslf::Depth1DParameters<T>::Depth1DParameters() -- core.hpp:74-99 */
+void        rslf_default_params(rslf_params* p);
+
+/* ---- context ---------------------------------------------------------- */
+int rslf_ctx_create(int device, rslf_ctx** out);
+int rslf_ctx_destroy(rslf_ctx* ctx);
+int rslf_ctx_set_stream(rslf_ctx* ctx, void* hip_stream);   /* NULL = default stream */
+int rslf_ctx_synchronize(rslf_ctx* ctx);
+
+/* ---- volume: replaces Depth1DComputer_pile's constructor --------------- */
+/* include/rslf_depth_computation.hpp:425-477: the constructor copies the
+ * caller's Vec<Mat> of V EPIs (each S x U, C channels interleaved) into float
+ * Mats scaled to [0,1].  Here the copy lands in one HBM slab laid out
+ * [V][S][C][pitch] (channel-planar rows, so a wavefront reading 64 consecutive
+ * u of one row touches 2-3 cache lines). */
+int rslf_volume_create(rslf_ctx* ctx, int V, int S, int U, int C, rslf_volume** out);
+int rslf_volume_destroy(rslf_volume* vol);
+int rslf_volume_describe(const rslf_volume* vol, rslf_volume_desc* out);
+
+/* Host EPIs as the reference holds them: h_epis[v] -> S rows of U*C values,
+ * row_stride_bytes apart (cv::Mat::step).  u8: x * float(1/255) (dc.hpp:470).
+ * f32: x * float(1/double(scale)); scale < 0 => the max over all EPIs
+ * (dc.hpp:442-460, :474).  scale_used is nullable. */
+int rslf_volume_upload_epis_f32(rslf_volume* vol, const float* const* h_epis, size_t row_stride_bytes,
+                                float epi_scale_factor, float* scale_used);
+int rslf_volume_upload_epis_u8(rslf_volume* vol, const uint8_t* const* h_epis, size_t row_stride_bytes);
+/* Host image stack as read from disk, h_imgs[s] -> V rows of U*C values: the
+ * input of rslf::build_epis_from_imgs (src/rslf_io.cpp:194-227); the
+ * [s][v][u] -> [v][s][u] transposition happens on the device. */
+int rslf_volume_upload_images_f32(rslf_volume* vol, const float* const* h_imgs, size_t row_stride_bytes,
+                                  float epi_scale_factor, float* scale_used);
+int rslf_volume_upload_images_u8(rslf_volume* vol, const uint8_t* const* h_imgs, size_t row_stride_bytes);
+/* Device-resident dense [V][S][U][C] float32 (already on this GPU). */
+int rslf_volume_pack_device_f32(rslf_volume* vol, const float* d_vsuc, float epi_scale_factor, float* scale_used);
+
+/* ---- the hot path, device pointers ------------------------------------ */
+/* rslf::compute_1D_edge_confidence_pile -- core.hpp:279-287, impl :728-770
+ * (per row :426-478).  d_Ce_vu [V][U] f32 is IN/OUT: the reference accumulates
+ * into the caller's plane (src/rslf_depth_computation_core.cpp:10), pass zeros.
+ * d_Ce_mask_vu [V][U] u8 out (0/255). */
+int rslf_edge_confidence_pile(rslf_ctx* ctx, const rslf_volume* vol, int s, const rslf_params* p,
+                              float* d_Ce_vu, uint8_t* d_Ce_mask_vu);
+
+/* rslf::compute_1D_depth_epi_pile -- core.hpp:293-310, impl :772-893
+ * (per EPI :480-661, selective median :663-718).
+ *   d_dmin_vu/d_dmax_vu  [V][U] f32 per-pixel hypothesis range; both NULL =>
+ *                        the scalars dmin/dmax (what dc.hpp:486-487 fills in)
+ *   d_Ce_vu, d_Ce_mask_vu  in/out: a pixel whose best score is not above
+ *                        raw_score_threshold gets C_e = 0, mask = 0 (:653-657)
+ *   d_Cd_vu, d_depth_vu, d_rbar_vu  in/out, written only at scanned pixels;
+ *                        d_rbar_vu is [V][U][C]; d_depth_vu is then REPLACED by
+ *                        the selective median of itself (:881-892), 0 where the
+ *                        edge mask is 0
+ *   d_mask_vu            nullable in/out scan mask, AND-ed with the edge mask
+ *                        in place (:510-511); NULL => edge mask alone (:513)
+ *   d_idx_vu             nullable out, int32 argmax index d*, -1 if none
+ *                        (not in the reference; the bit-exactness witness)
+ *   d_score_vu           nullable out, score[d*]
+ *   d_depth_raw_vu       nullable out, d_depth_vu before the median */
+int rslf_depth_epi_pile(rslf_ctx* ctx, const rslf_volume* vol,
+                        const float* d_dmin_vu, const float* d_dmax_vu, float dmin, float dmax,
+                        int dim_d, int s_hat,
+                        float* d_Ce_vu, uint8_t* d_Ce_mask_vu, float* d_Cd_vu, float* d_depth_vu,
+                        float* d_rbar_vu, const rslf_params* p, uint8_t* d_mask_vu,
+                        int32_t* d_idx_vu, float* d_score_vu, float* d_depth_raw_vu,
+                        rslf_stats* stats);
+
+/* rslf::selective_median_filter -- core.hpp:366-375, impl :663-718.
+ * d_dst_vu must not alias d_src_vu; it is fully written (0 where mask is 0). */
+int rslf_selective_median(rslf_ctx* ctx, const rslf_volume* vol, const float* d_src_vu, float* d_dst_vu,
+                          int s_hat, int size, const uint8_t* d_mask_vu, float epsilon);
+
+/* rslf::Depth1DComputer_pile<T>::run() -- include/rslf_depth_computation.hpp:513-565
+ * with the output allocation of the constructor (:486-510): zero-fills the
+ * outputs (the reference leaves C_e and C_d uninitialised, :501-504), s_hat < 0
+ * or > S-1 => floor(S/2) (:490-498), then the two calls above, no scan mask. */
+int rslf_depth1d_pile_run(rslf_ctx* ctx, const rslf_volume* vol, float dmin, float dmax, int dim_d, int s_hat,
+                          const rslf_params* p,
+                          float* d_Ce_vu, uint8_t* d_Ce_mask_vu, float* d_Cd_vu, float* d_depth_vu,
+                          float* d_rbar_vu, int32_t* d_idx_vu, float* d_score_vu, float* d_depth_raw_vu,
+                          rslf_stats* stats);
+
+/* ---- the hot path, host pointers (cv::Mat::data in / out) -------------- */
+/* Same as rslf_depth1d_pile_run with host result planes: runs on the device,
+ * copies back, synchronises.  Any output may be NULL. */
+int rslf_depth1d_pile_run_host(rslf_ctx* ctx, const rslf_volume* vol, float dmin, float dmax, int dim_d, int s_hat,
+                               const rslf_params* p,
+                               float* h_Ce_vu, uint8_t* h_Ce_mask_vu, float* h_Cd_vu, float* h_depth_vu,
+                               float* h_rbar_vu, int32_t* h_idx_vu, float* h_score_vu, float* h_depth_raw_vu,
+                               rslf_stats* stats);
+
+/* ---- measurement ------------------------------------------------------ */
+/* Duration in milliseconds of the last scan-kernel launch (K2) of this
+ * context, from HIP events recorded on the context's stream around that
+ * launch.  Blocks until the launch has finished. */
+int rslf_last_scan_kernel_ms(rslf_ctx* ctx, float* ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RSLF_HIP_H */

@@ -1,0 +1,191 @@
+// K0 (pack), K1 (edge confidence) and the confident-pixel compaction.
+//
+// These touch each voxel / pixel a constant number of times: HBM-bound,
+// coalesced along u, negligible next to the scan.
+#pragma once
+
+#include "rslf_device.hpp"
+
+namespace rslf {
+
+// ---- K0: normalise + planarise into the slab ------------------------------
+// Replaces Depth1DComputer_pile's constructor copy/convertTo
+// (include/rslf_depth_computation.hpp:463-477) and, for the image-major source,
+// rslf::build_epis_from_imgs (src/rslf_io.cpp:194-227).
+//   EPI-major   source: element (v,s,u,c) at src[((v*S + s)*U + u)*C + c]
+//   image-major source: element (v,s,u,c) at src[((s*V + v)*U + u)*C + c]
+// One block per (v, s) row; block-level min/max partials for the volume range.
+template <typename SrcT, bool IMAGE_MAJOR>
+__global__ __launch_bounds__(256) void k0_pack(const SrcT* __restrict__ src, float* __restrict__ dst,
+                                              int V0, int Vn, int Vsrc, int S, int U, int C, int pitch,
+                                              float scale, float* __restrict__ partial_minmax)
+{
+    const int row = blockIdx.x;   // over Vn * S
+    const int vl = row / S;       // local scanline of this chunk
+    const int s = row - vl * S;
+    const int v = V0 + vl;
+    const long long src_row = IMAGE_MAJOR ? ((long long)s * Vsrc + vl) : ((long long)vl * S + s);
+    const SrcT* in = src + src_row * (long long)U * C;
+    float* out = dst + ((long long)v * S + s) * (long long)C * pitch;
+
+    float mn = INFINITY, mx = -INFINITY;
+    for (int c = 0; c < C; c++) {
+        for (int u = threadIdx.x; u < pitch; u += blockDim.x) {
+            float x = 0.0f;   // zero padding beyond U (a 0-weight tap must stay finite)
+            if (u < U) {
+                // dc.hpp:470 / :474: convertTo with a float scale
+                x = (float)in[(long long)u * C + c] * scale;
+                mn = fminf(mn, x);
+                mx = fmaxf(mx, x);
+            }
+            out[(long long)c * pitch + u] = x;
+        }
+    }
+    // block reduce
+    for (int o = 32; o > 0; o >>= 1) {
+        mn = fminf(mn, __shfl_xor(mn, o));
+        mx = fmaxf(mx, __shfl_xor(mx, o));
+    }
+    __shared__ float smn[4], smx[4];
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        smn[w] = mn;
+        smx[w] = mx;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < (int)(blockDim.x >> 6); i++) {
+            mn = fminf(mn, smn[i]);
+            mx = fmaxf(mx, smx[i]);
+        }
+        partial_minmax[2 * (long long)row] = mn;
+        partial_minmax[2 * (long long)row + 1] = mx;
+    }
+}
+
+// Folds the per-row partials into minmax[0..1] (running values, so chunks chain).
+__global__ __launch_bounds__(256) void k0_minmax_final(const float* __restrict__ partial, int n, float* __restrict__ minmax)
+{
+    float mn = INFINITY, mx = -INFINITY;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        mn = fminf(mn, partial[2 * i]);
+        mx = fmaxf(mx, partial[2 * i + 1]);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        mn = fminf(mn, __shfl_xor(mn, o));
+        mx = fmaxf(mx, __shfl_xor(mx, o));
+    }
+    __shared__ float smn[4], smx[4];
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        smn[w] = mn;
+        smx[w] = mx;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < 4; i++) {
+            mn = fminf(mn, smn[i]);
+            mx = fmaxf(mx, smx[i]);
+        }
+        minmax[0] = fminf(minmax[0], mn);
+        minmax[1] = fmaxf(minmax[1], mx);
+    }
+}
+
+// ---- K1: edge confidence ---------------------------------------------------
+// rslf::compute_1D_edge_confidence (core.hpp:426-478) for every scanline
+// (core.hpp:728-757).  One thread per pixel, grid (ceil(U/256), V).
+//   C_e(u) += sum_{j != centre} sum_c (E_c[u] - E_c[refl101(u + j - centre)])^2
+// accumulated in that order into the caller's plane (core.cpp:6-23), shadow cut
+// (core.hpp:464-474), mask = C_e > threshold (core.hpp:476).
+template <int C>
+__global__ __launch_bounds__(256) void k1_edge_confidence(VolView vol, int s, EdgeConsts ec,
+                                                         float* __restrict__ Ce, uint8_t* __restrict__ mask)
+{
+    const int v = blockIdx.y;
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= vol.U)
+        return;
+    const float* r0 = vol.row(v, s, 0);
+    const int centre = (ec.filter_size - 1) / 2;
+    const long long o = (long long)v * vol.U + u;
+
+    float e[C];
+#pragma unroll
+    for (int c = 0; c < C; c++)
+        e[c] = r0[(long long)c * vol.pitch + u];
+
+    float ce = Ce[o];
+    for (int j = 0; j < ec.filter_size; j++) {
+        if (j == centre)
+            continue;
+        const int q = reflect101(u + j - centre, vol.U);
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            const float t = e[c] - r0[(long long)c * vol.pitch + q];
+            const float t2 = t * t;
+            ce = ce + t2;
+        }
+    }
+    if (ec.cut_shadows) {
+        float n;
+        if (C == 1)
+            n = norm1(e[0]);
+        else
+            n = norm3(e[0], e[C > 1 ? 1 : 0], e[C > 2 ? 2 : 0]);
+        if (n < ec.shadow_level)
+            ce = 0.0f;
+    }
+    Ce[o] = ce;
+    mask[o] = (ce > ec.edge_thr) ? 255 : 0;
+}
+
+// ---- compaction of the scan mask -------------------------------------------
+// core.hpp:510-516: scan mask = edge mask (& caller mask, written back in
+// place), then findNonZero.  One block per scanline writes the ascending list
+// of confident u into list[v][0..count[v]) so that scan wavefronts stay full
+// when the mask is sparse.  Also adds count[v] to *total.
+__global__ __launch_bounds__(256) void k_compact_mask(const uint8_t* __restrict__ edge_mask, uint8_t* __restrict__ scan_mask,
+                                                     int U, int* __restrict__ list, int* __restrict__ count,
+                                                     unsigned long long* __restrict__ total)
+{
+    const int v = blockIdx.x;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __shared__ int wave_tot[4];
+    __shared__ int base_s;
+    if (threadIdx.x == 0)
+        base_s = 0;
+    __syncthreads();
+    for (int u0 = 0; u0 < U; u0 += 256) {
+        const int u = u0 + threadIdx.x;
+        bool f = false;
+        if (u < U) {
+            uint8_t m = edge_mask[(long long)v * U + u];
+            if (scan_mask) {
+                m &= scan_mask[(long long)v * U + u];
+                scan_mask[(long long)v * U + u] = m;
+            }
+            f = m != 0;
+        }
+        const unsigned long long b = __ballot(f);
+        const int rank = __popcll(b & ((1ull << lane) - 1ull));
+        if (lane == 0)
+            wave_tot[w] = __popcll(b);
+        __syncthreads();
+        int off = base_s;
+        for (int i = 0; i < w; i++)
+            off += wave_tot[i];
+        if (f)
+            list[(long long)v * U + off + rank] = u;
+        __syncthreads();
+        if (threadIdx.x == 0)
+            base_s += wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        count[v] = base_s;
+        atomicAdd(total, (unsigned long long)base_s);
+    }
+}
+
+}  // namespace rslf

@@ -1,0 +1,401 @@
+// K2: the (pixel, hypothesis) EPI-slope scan.
+//
+// rslf::compute_1D_depth_epi (include/rslf_depth_computation_core.hpp:480-661)
+// for every scanline (core.hpp:799-854), with Interpolation1DLinear
+// (include/rslf_interpolation.hpp:155-193) and BandwidthKernel
+// (src/rslf_kernels.cpp:16-54) inlined.
+//
+// Work mapping (both variants)
+//   wavefront = 64 consecutive entries of one scanline's confident-pixel list
+//   lane      = one pixel u; the lane walks all dim_d hypotheses itself
+// so a wave's 64 gathers per (s, d) are 64 neighbouring floats of one EPI row
+// (coalesced along u), the argmax / mean over d never leaves the lane, and the
+// sum over s is the reference's sequential float sum.  Four such waves make a
+// 256-thread workgroup with no LDS and no barrier; logical workgroups are
+// dealt to XCDs in contiguous scanline ranges (rslf_device.hpp).
+//
+// This kernel is FP32-VALU bound: per (pixel, hypothesis, view,
+// mean-shift pass) the register variant issues 7 vector instructions and no
+// memory instruction.
+#pragma once
+
+#include "rslf_device.hpp"
+
+namespace rslf {
+
+struct ScanArgs {
+    VolView vol;
+    const int* list;        // [V][U] ascending confident u per scanline
+    const int* count;       // [V]
+    const float* dmin_vu;   // nullable => dmin/dmax scalars
+    const float* dmax_vu;
+    float dmin, dmax;
+    int dim_d, s_hat;
+    ScanConsts k;
+    float* Ce;              // [V][U] in/out
+    uint8_t* Ce_mask;       // [V][U] in/out
+    uint8_t* scan_mask;     // nullable: the caller's mask plane (cleared like Ce_mask? no: core.hpp:655-656 clears the edge mask only)
+    float* Cd;              // [V][U]
+    float* depth;           // [V][U]
+    float* rbar;            // [V][U][C]
+    int32_t* idx;           // nullable
+    float* score;           // nullable
+    int tiles_per_row;      // ceil(U / 64)
+    int logical_blocks;     // ceil(V * tiles_per_row / 4)
+    int per_xcd;            // ceil(logical_blocks / 8)
+};
+
+// Which pixel does this lane own?  Returns false when the whole wave has none.
+__device__ __forceinline__ bool scan_tile(const ScanArgs& a, int& v, int& u, bool& active)
+{
+    const int lane = threadIdx.x & 63;
+    // wave-uniform by construction; readfirstlane lets the compiler keep v and row bases in SGPRs
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lb = xcd_logical_block(blockIdx.x, a.per_xcd);
+    if (lb >= a.logical_blocks)
+        return false;
+    const int T = lb * 4 + wave;
+    v = T / a.tiles_per_row;
+    if (v >= a.vol.V)
+        return false;
+    const int j = T - v * a.tiles_per_row;
+    const int n = a.count[v];
+    if (j * 64 >= n)
+        return false;
+    const int e = j * 64 + lane;
+    active = e < n;
+    // idle lanes of the last tile shadow its last pixel so their addresses stay valid
+    u = a.list[(long long)v * a.vol.U + (active ? e : n - 1)];
+    return true;
+}
+
+// core.hpp:545-548: D[d] = dmin + d * (dmax - dmin) / (dim_d - 1)
+__device__ __forceinline__ float hypothesis(float dmin, float range, float denom, int d)
+{
+    const float num = (float)d * range;
+    const float quo = num / denom;
+    return dmin + quo;
+}
+
+// core.hpp:630-657 for one lane once all hypotheses are scored.
+template <int C>
+__device__ __forceinline__ void scan_epilogue(const ScanArgs& a, int v, int u, bool active, float best, int best_d,
+                                              float best_D, const float (&best_rbar)[C], double sum)
+{
+    if (!active)
+        return;
+    const long long o = (long long)v * a.vol.U + u;
+    if ((double)best > (double)a.k.raw_thr) {
+        a.depth[o] = best_D;
+        const double mean = sum / (double)a.dim_d;
+        a.Cd[o] = (float)((double)a.Ce[o] * fabs((double)best - mean));
+#pragma unroll
+        for (int c = 0; c < C; c++)
+            a.rbar[o * C + c] = best_rbar[c];
+        if (a.idx)
+            a.idx[o] = best_d;
+        if (a.score)
+            a.score[o] = best;
+    } else {
+        a.Ce[o] = 0.0f;
+        a.Ce_mask[o] = 0;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Generic variant: any S, C in {1,3}, negative radiances allowed.  Nothing is
+// kept between mean-shift passes: every pass re-gathers its samples from the
+// slab (L1/L2 hits).  ~3x the instructions of the register variant.
+// ---------------------------------------------------------------------------
+template <int C>
+__global__ __launch_bounds__(256) void k2_scan_generic(ScanArgs a)
+{
+    int v, u;
+    bool active;
+    if (!scan_tile(a, v, u, active))
+        return;
+
+    const VolView& vol = a.vol;
+    const float* epi = vol.row(v, 0, 0);
+    const float uf = (float)u;
+    const int Um1 = vol.U - 1;
+    const long long o = (long long)v * vol.U + u;
+    const float dmin = a.dmin_vu ? a.dmin_vu[o] : a.dmin;
+    const float dmax = a.dmax_vu ? a.dmax_vu[o] : a.dmax;
+    const float range = dmax - dmin;
+    const float denom = (float)(a.dim_d - 1);
+
+    float best = -1.0f, best_D = 0.0f;   // scores are >= 0, so d = 0 always takes the lead
+    int best_d = 0;
+    float best_rbar[C];
+#pragma unroll
+    for (int c = 0; c < C; c++)
+        best_rbar[c] = 0.0f;
+    double sum = 0.0;
+
+    for (int d = 0; d < a.dim_d; d++) {
+        const float Dd = hypothesis(dmin, range, denom, d);
+        float rbar[C];
+#pragma unroll
+        for (int c = 0; c < C; c++)   // core.hpp:577: R[s_hat] is E[s_hat][u] exactly
+            rbar[c] = epi[(long long)a.s_hat * vol.stride_s + (long long)c * vol.pitch + u];
+        float B = 0.0f, card = 0.0f;
+        for (int it = 0; it < a.k.n_iter; it++) {
+            float A[C];
+#pragma unroll
+            for (int c = 0; c < C; c++)
+                A[c] = 0.0f;
+            B = 0.0f;
+            card = 0.0f;
+            for (int s = 0; s < vol.S; s++) {
+                float x = (float)(a.s_hat - s) * Dd;   // I = S * D
+                x = x * a.k.slope;                     // I *= slope_factor
+                x = x + uf;                            // I += u
+                const float fl = floorf(x);
+                const int i0 = (int)fl;
+                const int i1 = (int)ceilf(x);
+                const float t = x - fl;
+                const bool valid = !(i0 < 0 || i1 > Um1);
+                const int j0 = min(max(i0, 0), Um1), j1 = min(max(i1, 0), Um1);
+                const float* row = epi + (long long)s * vol.stride_s;
+                const float omt = 1.0f - t;
+                float K;
+                float R0[C];
+                if (C == 1) {
+                    const float m0 = omt * row[j0];
+                    const float m1 = t * row[j1];
+                    float R = m0 + m1;
+                    R = valid ? R : NAN;
+                    R0[0] = (R > 0.0f) ? R : 0.0f;          // cv::max(R, 0), NaN -> 0
+                    const float delta = R - rbar[0];
+                    const float q = (a.k.k1 * delta) * delta;
+                    const float one_m = 1.0f - q;
+                    K = (one_m > 0.0f) ? one_m : 0.0f;      // NaN -> 0
+                } else {
+                    float q[C];
+#pragma unroll
+                    for (int c = 0; c < C; c++) {
+                        const float m0 = omt * row[(long long)c * vol.pitch + j0];
+                        const float m1 = t * row[(long long)c * vol.pitch + j1];
+                        float R = m0 + m1;
+                        R = valid ? R : NAN;
+                        R0[c] = (R > 0.0f) ? R : 0.0f;
+                        const float delta = R - rbar[c];
+                        q[c] = (a.k.inv_h2 * delta) * delta;
+                    }
+                    float qs = q[0] + q[C > 2 ? 2 : 0];     // OpenCV 3.x reduceC_: (q0 + q2) + q1
+                    qs = qs + q[C > 1 ? 1 : 0];
+                    const float one_m = 1.0f - qs;
+                    K = (one_m > 0.0f) ? one_m : 0.0f;
+                }
+#pragma unroll
+                for (int c = 0; c < C; c++) {
+                    const float pr = R0[c] * K;
+                    A[c] = A[c] + pr;
+                }
+                B = B + K;
+                card = card + (valid ? 1.0f : 0.0f);
+            }
+#pragma unroll
+            for (int c = 0; c < C; c++) {
+                const float q = (B != 0.0f) ? (A[c] / B) : 0.0f;   // OpenCV 3.x divide: /0 -> 0
+                rbar[c] = (q > 0.0f) ? q : 0.0f;
+            }
+        }
+        float sc = (card != 0.0f) ? (B / card) : 0.0f;
+        sc = (sc > 0.0f) ? sc : 0.0f;
+        sum += (double)sc;
+        if (sc > best) {   // strict: first maximum wins (cv::minMaxLoc)
+            best = sc;
+            best_d = d;
+            best_D = Dd;
+#pragma unroll
+            for (int c = 0; c < C; c++)
+                best_rbar[c] = rbar[c];
+        }
+    }
+    scan_epilogue<C>(a, v, u, active, best, best_d, best_D, best_rbar, sum);
+}
+
+// ---------------------------------------------------------------------------
+// Register variant: C = 1, S <= SPAD <= 128, every radiance in [0, 1e6].
+//
+// The S samples of one (pixel, hypothesis) are gathered once into SPAD VGPRs
+// and the mean-shift passes run out of registers:
+//     delta = R - rbar ; t = k1*delta ; q = t*delta ; K = max(1 - q, 0)
+//     P = R*K ; A += P ; B += K                      (7 VALU, no memory)
+// Out-of-range samples (the reference's NaN, interp.hpp:189) and the padding
+// slots s >= S hold kSentinel = 1e30: then q = +inf, K = max(-inf, 0) = 0 and
+// P = 1e30 * 0 = 0 exactly, so they add +0 to both sums -- bit-identical to the
+// reference's "NaN -> K = 0, R0 = 0" without a second register per sample.
+// Needs R == max(R, 0), hence the non-negative-volume precondition checked by
+// the host (rslf_abi.hip: pick_scan_kernel).
+// ---------------------------------------------------------------------------
+constexpr int kGatherBatch = 8;   // samples whose loads are in flight together
+
+template <int SPAD, bool BORDER>
+__device__ __forceinline__ void scan_reg_body(const ScanArgs& a, int v, int u, bool active)
+{
+    const VolView& vol = a.vol;
+    const float* epi = vol.row(v, 0, 0);
+    const float uf = (float)u;
+    const int Um1 = vol.U - 1;
+    const float Um1f = (float)Um1;
+    const int S = vol.S;
+    const long long o = (long long)v * vol.U + u;
+    const float dmin = a.dmin_vu ? a.dmin_vu[o] : a.dmin;
+    const float dmax = a.dmax_vu ? a.dmax_vu[o] : a.dmax;
+    const float range = dmax - dmin;
+    const float denom = (float)(a.dim_d - 1);
+    const float k1 = a.k.k1;
+    const float slope = a.k.slope;
+    const int stride_s = (int)vol.stride_s;
+
+    float best = -1.0f, best_D = 0.0f;
+    int best_d = 0;
+    float best_rbar[1] = {0.0f};
+    double sum = 0.0;
+
+#pragma unroll 1
+    for (int d = 0; d < a.dim_d; d++) {
+        const float Dd = hypothesis(dmin, range, denom, d);
+        float R[SPAD];
+        int card = BORDER ? 0 : S;
+        // The gather is fully unrolled (R[] must be register-indexed).  Everything in it that
+        // does not depend on d would otherwise be hoisted out of the d loop -- SPAD row
+        // pointers and SPAD float(s_hat - s) values pinned in registers for the whole kernel.
+        // Two values re-made opaque per hypothesis keep that state to two registers: the
+        // view offset of s = 0 as a float, and the running row offset.
+        float Ss0 = (float)a.s_hat;
+        asm volatile("" : "+v"(Ss0));
+        int rowoff = 0;
+        asm volatile("" : "+s"(rowoff));
+#pragma unroll
+        for (int g = 0; g < SPAD / kGatherBatch; g++) {
+            float tt[kGatherBatch], e0[kGatherBatch], e1[kGatherBatch];
+            bool ok[kGatherBatch];
+            // issue the batch's loads back to back, then blend
+#pragma unroll
+            for (int j = 0; j < kGatherBatch; j++) {
+                const int s = g * kGatherBatch + j;
+                tt[j] = 0.0f;
+                e0[j] = kSentinel;
+                e1[j] = 0.0f;
+                ok[j] = false;
+                if (s < SPAD - 8 || s < S) {
+                    float x = (Ss0 - (float)s) * Dd;   // float(s_hat - s) * D[d]   core.hpp:542,550
+                    x = x * slope;                     // core.hpp:551
+                    x = x + uf;                        // core.hpp:552
+                    const float fl = floorf(x);        // interp.hpp:179
+                    tt[j] = x - fl;                    // interp.hpp:181
+                    int i0 = (int)fl;
+                    ok[j] = true;
+                    if (BORDER) {
+                        // floor(x) >= 0 <=> x >= 0 ; ceil(x) <= U-1 <=> x <= U-1   (interp.hpp:182)
+                        ok[j] = (x >= 0.0f) && (x <= Um1f);
+                        i0 = min(max(i0, 0), Um1);
+                    }
+                    // 32-bit byte offset off the EPI's scalar base: one global_load_dwordx2 per sample
+                    const unsigned byteoff = (unsigned)(i0 + rowoff) << 2;
+                    const float* p = (const float*)((const char*)epi + byteoff);
+                    // second tap = p[1]: for integral x the reference reads p[0] twice with weights
+                    // 1 and 0; 0 * p[1] is the same +0 (rows are zero padded, so p[1] is finite)
+                    e0[j] = p[0];
+                    e1[j] = p[1];
+                }
+                rowoff += stride_s;
+            }
+#pragma unroll
+            for (int j = 0; j < kGatherBatch; j++) {
+                const int s = g * kGatherBatch + j;
+                const float m0 = (1.0f - tt[j]) * e0[j];   // interp.hpp:184
+                const float m1 = tt[j] * e1[j];
+                const float r = m0 + m1;
+                if (BORDER) {
+                    R[s] = ok[j] ? r : kSentinel;
+                    card += ok[j] ? 1 : 0;
+                } else {
+                    R[s] = (s < SPAD - 8 || s < S) ? r : kSentinel;
+                }
+            }
+            // Pin this batch: its eight results must exist here, and the next batch's address
+            // state is re-made opaque here, so the compiler cannot turn the unrolled gather into
+            // "all loads first, all blends last" (which parks 2*SPAD loaded values in scratch).
+            {
+                const int b = g * kGatherBatch;
+                asm volatile(""
+                             : "+v"(R[b + 0]), "+v"(R[b + 1]), "+v"(R[b + 2]), "+v"(R[b + 3]), "+v"(R[b + 4]),
+                               "+v"(R[b + 5]), "+v"(R[b + 6]), "+v"(R[b + 7]), "+s"(rowoff), "+v"(Ss0));
+            }
+        }
+
+        // core.hpp:577: rbar <- R[s_hat] = E[s_hat][u]
+        float rbar = epi[(long long)a.s_hat * vol.stride_s + u];
+        float B = 0.0f;
+#pragma unroll 1
+        for (int it = 0; it < a.k.n_iter; it++) {
+            float A = 0.0f;
+            B = 0.0f;
+#pragma unroll
+            for (int s = 0; s < SPAD; s++) {
+                const float delta = R[s] - rbar;
+                const float tq = k1 * delta;
+                const float q = tq * delta;
+                const float one_m = 1.0f - q;
+                const float K = fmaxf(one_m, 0.0f);
+                const float pr = R[s] * K;
+                A = A + pr;
+                B = B + K;
+            }
+            const float qd = (B != 0.0f) ? (A / B) : 0.0f;
+            rbar = (qd > 0.0f) ? qd : 0.0f;
+        }
+        const float cardf = (float)card;
+        float sc = (card != 0) ? (B / cardf) : 0.0f;
+        sc = (sc > 0.0f) ? sc : 0.0f;
+        sum += (double)sc;
+        if (sc > best) {
+            best = sc;
+            best_d = d;
+            best_D = Dd;
+            best_rbar[0] = rbar;
+        }
+    }
+    scan_epilogue<1>(a, v, u, active, best, best_d, best_D, best_rbar, sum);
+}
+
+// Waves per SIMD the register budget allows: SPAD sample slots + ~64 working registers
+// (a batch of 8 in-flight samples, the per-pixel state, SGPR overflow lanes), in the
+// hardware's 8-register granules, 512 registers per SIMD lane.
+constexpr int scan_reg_waves(int spad)
+{
+    const int regs = ((spad + 64 + 7) / 8) * 8;
+    const int w = 512 / regs;
+    return w > 8 ? 8 : (w < 1 ? 1 : w);
+}
+
+template <int SPAD>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(scan_reg_waves(SPAD), scan_reg_waves(SPAD))))
+void k2_scan_reg(ScanArgs a)
+{
+    int v, u;
+    bool active;
+    if (!scan_tile(a, v, u, active))
+        return;
+    // A wave whose every sample line stays inside [0, U-1] for every hypothesis
+    // needs no validity test: |x - u| <= max|s_hat - s| * max|d| * slope.
+    bool interior = false;
+    if (!a.dmin_vu) {
+        const float max_ds = (float)max(a.s_hat, a.vol.S - 1 - a.s_hat);
+        const float max_d = fmaxf(fabsf(a.dmin), fabsf(a.dmax));
+        const float reach = max_ds * max_d * fabsf(a.k.slope) + 2.0f;
+        const float uf = (float)u;
+        interior = __all((uf - reach >= 0.0f) && (uf + reach <= (float)(a.vol.U - 1)));
+    }
+    if (interior)
+        scan_reg_body<SPAD, false>(a, v, u, active);
+    else
+        scan_reg_body<SPAD, true>(a, v, u, active);
+}
+
+}  // namespace rslf

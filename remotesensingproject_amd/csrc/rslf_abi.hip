@@ -1,0 +1,811 @@
+// C-ABI of the gfx950 EPI depth scan (include/rslf_hip.h) -- host side of
+// librslf_hip.so: contexts, the HBM slab, kernel selection and launches.
+// No OpenCV, no torch, no CPU compute path.
+#include "../../include/rslf_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "k1_edge.hpp"
+#include "k2_scan.hpp"
+#include "k3_median.hpp"
+
+using namespace rslf;
+
+// ---- errors ---------------------------------------------------------------
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                               \
+    do {                                                                                            \
+        hipError_t e_ = (expr);                                                                     \
+        if (e_ != hipSuccess)                                                                       \
+            return fail(RSLF_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+// ---- objects --------------------------------------------------------------
+
+struct rslf_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    // scratch, grown on demand (never inside a timed launch sequence after the first call)
+    int* list = nullptr;
+    int* count = nullptr;
+    float* depth_tmp = nullptr;
+    size_t plane_cap = 0;   // pixels list/depth_tmp can hold
+    int count_cap = 0;
+    unsigned long long* total = nullptr;   // device counter
+    float* partial = nullptr;              // pack min/max partials
+    size_t partial_cap = 0;
+    float* minmax = nullptr;               // device [2]
+    void* staging = nullptr;
+    size_t staging_cap = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool ev_valid = false;
+};
+
+struct rslf_volume {
+    rslf_ctx* ctx = nullptr;
+    int V = 0, S = 0, U = 0, C = 0, pitch = 0;
+    float* base = nullptr;
+    size_t bytes = 0;
+    float min_value = 0.0f, max_value = 0.0f;
+    bool filled = false;
+};
+
+static VolView view_of(const rslf_volume* vol)
+{
+    VolView w;
+    w.base = vol->base;
+    w.V = vol->V;
+    w.S = vol->S;
+    w.U = vol->U;
+    w.C = vol->C;
+    w.pitch = vol->pitch;
+    w.stride_s = (long long)vol->C * vol->pitch;
+    w.stride_v = (long long)vol->S * w.stride_s;
+    return w;
+}
+
+static int ensure_plane_scratch(rslf_ctx* ctx, int V, int U)
+{
+    const size_t n = (size_t)V * U;
+    if (n > ctx->plane_cap) {
+        if (ctx->list)
+            HIP_TRY(hipFree(ctx->list));
+        if (ctx->depth_tmp)
+            HIP_TRY(hipFree(ctx->depth_tmp));
+        ctx->list = nullptr;
+        ctx->depth_tmp = nullptr;
+        ctx->plane_cap = 0;
+        HIP_TRY(hipMalloc(&ctx->list, n * sizeof(int)));
+        HIP_TRY(hipMalloc(&ctx->depth_tmp, n * sizeof(float)));
+        ctx->plane_cap = n;
+    }
+    if (V > ctx->count_cap) {
+        if (ctx->count)
+            HIP_TRY(hipFree(ctx->count));
+        ctx->count = nullptr;
+        ctx->count_cap = 0;
+        HIP_TRY(hipMalloc(&ctx->count, (size_t)V * sizeof(int)));
+        ctx->count_cap = V;
+    }
+    return RSLF_OK;
+}
+
+// ---- misc -----------------------------------------------------------------
+
+extern "C" int rslf_abi_version(void) { return RSLF_ABI_VERSION; }
+
+extern "C" const char* rslf_status_string(int status)
+{
+    switch (status) {
+    case RSLF_OK: return "ok";
+    case RSLF_ERR_INVALID_ARG: return "invalid argument";
+    case RSLF_ERR_UNSUPPORTED: return "unsupported configuration";
+    case RSLF_ERR_HIP: return "HIP runtime error";
+    case RSLF_ERR_NO_DEVICE: return "no gfx950 device";
+    case RSLF_ERR_ALLOC: return "allocation failed";
+    default: return "unknown status";
+    }
+}
+
+extern "C" const char* rslf_last_error(void) { return g_err; }
+
+extern "C" int rslf_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess)
+        return 0;
+    return n;
+}
+
+extern "C" void rslf_default_params(rslf_params* p)
+{
+    if (!p)
+        return;
+    // include/rslf_depth_computation_core.hpp:16-31, :74-99
+    p->edge_score_threshold = (float)0.02;
+    p->line_score_threshold = (float)0.02;
+    p->disp_score_threshold = (float)0.01;
+    p->raw_score_threshold = (float)0;
+    p->mean_shift_max_iter = (float)10;
+    p->edge_confidence_filter_size = 9;
+    p->edge_confidence_opening_type = 2;
+    p->edge_confidence_opening_size = 1;
+    p->median_filter_size = 5;
+    p->median_filter_epsilon = (float)0.1;
+    p->propagation_epsilon = (float)0.1;
+    p->slope_factor = (float)1.0;
+    p->cut_shadows = 1;
+    p->shadow_level = (float)(0.05 * 1.73205080757);
+    p->kernel_bandwidth = (float)0.2;
+}
+
+static ScanConsts make_scan_consts(const rslf_params* p)
+{
+    ScanConsts k;
+    k.slope = p->slope_factor;
+    const float h = p->kernel_bandwidth;
+    const float hh = h * h;
+    k.inv_h2 = (float)(1.0 / (double)hh);   // include/rslf_kernels.hpp:43
+    k.k1 = 3.0f * k.inv_h2;                 // src/rslf_kernels.cpp:21
+    k.raw_thr = p->raw_score_threshold;
+    int n = 0;
+    while ((float)n < p->mean_shift_max_iter && n < (1 << 20))   // core.hpp:584, float bound
+        n++;
+    k.n_iter = n;
+    return k;
+}
+
+static int check_params(const rslf_params* p)
+{
+    if (!p)
+        return fail(RSLF_ERR_INVALID_ARG, "params is NULL");
+    if (p->edge_confidence_opening_size > 1)
+        return fail(RSLF_ERR_UNSUPPORTED, "edge_confidence_opening_size > 1 (morphological opening) is not implemented; "
+                                          "the reference default is 1 = off (core.hpp:29, :759)");
+    if (p->edge_confidence_filter_size < 1 || (p->edge_confidence_filter_size & 1) == 0)
+        return fail(RSLF_ERR_INVALID_ARG, "edge_confidence_filter_size must be odd and >= 1");
+    if (p->median_filter_size < 1 || (p->median_filter_size & 1) == 0 || p->median_filter_size > kMedianMaxSize)
+        return fail(RSLF_ERR_UNSUPPORTED, "median_filter_size must be odd and <= %d", kMedianMaxSize);
+    if (!(p->kernel_bandwidth > 0.0f))
+        return fail(RSLF_ERR_INVALID_ARG, "kernel_bandwidth must be > 0");
+    if (!(p->mean_shift_max_iter > 0.0f))
+        return fail(RSLF_ERR_INVALID_ARG, "mean_shift_max_iter must be > 0");
+    return RSLF_OK;
+}
+
+// ---- context --------------------------------------------------------------
+
+extern "C" int rslf_ctx_create(int device, rslf_ctx** out)
+{
+    if (!out)
+        return fail(RSLF_ERR_INVALID_ARG, "out is NULL");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return fail(RSLF_ERR_NO_DEVICE, "no HIP device visible");
+    if (device < 0 || device >= n)
+        return fail(RSLF_ERR_INVALID_ARG, "device %d out of range (0..%d)", device, n - 1);
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(RSLF_ERR_NO_DEVICE, "device %d is %s; this library holds gfx950 code objects only", device, prop.gcnArchName);
+    HIP_TRY(hipSetDevice(device));
+    rslf_ctx* ctx = new (std::nothrow) rslf_ctx();
+    if (!ctx)
+        return fail(RSLF_ERR_ALLOC, "out of host memory");
+    ctx->device = device;
+    hipError_t e = hipMalloc(&ctx->total, sizeof(unsigned long long));
+    if (e == hipSuccess)
+        e = hipMalloc(&ctx->minmax, 2 * sizeof(float));
+    if (e == hipSuccess)
+        e = hipEventCreate(&ctx->ev0);
+    if (e == hipSuccess)
+        e = hipEventCreate(&ctx->ev1);
+    if (e != hipSuccess) {
+        delete ctx;
+        return fail(RSLF_ERR_HIP, "context setup failed: %s", hipGetErrorString(e));
+    }
+    *out = ctx;
+    return RSLF_OK;
+}
+
+extern "C" int rslf_ctx_destroy(rslf_ctx* ctx)
+{
+    if (!ctx)
+        return RSLF_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(ctx->list);
+    (void)hipFree(ctx->count);
+    (void)hipFree(ctx->depth_tmp);
+    (void)hipFree(ctx->total);
+    (void)hipFree(ctx->partial);
+    (void)hipFree(ctx->minmax);
+    (void)hipFree(ctx->staging);
+    if (ctx->ev0)
+        (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1)
+        (void)hipEventDestroy(ctx->ev1);
+    delete ctx;
+    return RSLF_OK;
+}
+
+extern "C" int rslf_ctx_set_stream(rslf_ctx* ctx, void* hip_stream)
+{
+    if (!ctx)
+        return fail(RSLF_ERR_INVALID_ARG, "ctx is NULL");
+    ctx->stream = (hipStream_t)hip_stream;
+    return RSLF_OK;
+}
+
+extern "C" int rslf_ctx_synchronize(rslf_ctx* ctx)
+{
+    if (!ctx)
+        return fail(RSLF_ERR_INVALID_ARG, "ctx is NULL");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return RSLF_OK;
+}
+
+// ---- volume ---------------------------------------------------------------
+
+extern "C" int rslf_volume_create(rslf_ctx* ctx, int V, int S, int U, int C, rslf_volume** out)
+{
+    if (!ctx || !out)
+        return fail(RSLF_ERR_INVALID_ARG, "ctx/out is NULL");
+    *out = nullptr;
+    if (V < 1 || S < 1 || U < 1)
+        return fail(RSLF_ERR_INVALID_ARG, "bad dimensions V=%d S=%d U=%d", V, S, U);
+    if (C != 1 && C != 3)
+        return fail(RSLF_ERR_UNSUPPORTED, "C=%d: the reference instantiates float and cv::Vec3f only (dc.hpp:149-154)", C);
+    HIP_TRY(hipSetDevice(ctx->device));
+    rslf_volume* vol = new (std::nothrow) rslf_volume();
+    if (!vol)
+        return fail(RSLF_ERR_ALLOC, "out of host memory");
+    vol->ctx = ctx;
+    vol->V = V;
+    vol->S = S;
+    vol->U = U;
+    vol->C = C;
+    vol->pitch = ((U + 1 + 63) / 64) * 64;   // > U: the second lerp tap of u = U-1 lands on a zero
+    vol->bytes = (size_t)V * S * C * vol->pitch * sizeof(float);
+    hipError_t e = hipMalloc(&vol->base, vol->bytes);
+    if (e != hipSuccess) {
+        delete vol;
+        return fail(RSLF_ERR_ALLOC, "hipMalloc(%zu) for the volume failed: %s", vol->bytes, hipGetErrorString(e));
+    }
+    *out = vol;
+    return RSLF_OK;
+}
+
+extern "C" int rslf_volume_destroy(rslf_volume* vol)
+{
+    if (!vol)
+        return RSLF_OK;
+    (void)hipSetDevice(vol->ctx->device);
+    (void)hipStreamSynchronize(vol->ctx->stream);
+    (void)hipFree(vol->base);
+    delete vol;
+    return RSLF_OK;
+}
+
+extern "C" int rslf_volume_describe(const rslf_volume* vol, rslf_volume_desc* out)
+{
+    if (!vol || !out)
+        return fail(RSLF_ERR_INVALID_ARG, "vol/out is NULL");
+    out->V = vol->V;
+    out->S = vol->S;
+    out->U = vol->U;
+    out->C = vol->C;
+    out->pitch = vol->pitch;
+    out->d_base = vol->base;
+    out->bytes = vol->bytes;
+    out->min_value = vol->min_value;
+    out->max_value = vol->max_value;
+    return RSLF_OK;
+}
+
+static int ensure_partial(rslf_ctx* ctx, size_t rows)
+{
+    if (rows > ctx->partial_cap) {
+        if (ctx->partial)
+            HIP_TRY(hipFree(ctx->partial));
+        ctx->partial = nullptr;
+        ctx->partial_cap = 0;
+        HIP_TRY(hipMalloc(&ctx->partial, rows * 2 * sizeof(float)));
+        ctx->partial_cap = rows;
+    }
+    return RSLF_OK;
+}
+
+static int ensure_staging(rslf_ctx* ctx, size_t bytes)
+{
+    if (bytes > ctx->staging_cap) {
+        if (ctx->staging)
+            HIP_TRY(hipFree(ctx->staging));
+        ctx->staging = nullptr;
+        ctx->staging_cap = 0;
+        HIP_TRY(hipMalloc(&ctx->staging, bytes));
+        ctx->staging_cap = bytes;
+    }
+    return RSLF_OK;
+}
+
+static int minmax_begin(rslf_ctx* ctx)
+{
+    const float init[2] = {INFINITY, -INFINITY};
+    HIP_TRY(hipMemcpyAsync(ctx->minmax, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));   // `init` is a stack temporary
+    return RSLF_OK;
+}
+
+static int minmax_end(rslf_volume* vol)
+{
+    rslf_ctx* ctx = vol->ctx;
+    float mm[2];
+    HIP_TRY(hipMemcpyAsync(mm, ctx->minmax, sizeof(mm), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    vol->min_value = mm[0];
+    vol->max_value = mm[1];
+    vol->filled = true;
+    return RSLF_OK;
+}
+
+// Pack rows [V0, V0+Vn) from a device buffer holding just those rows.
+template <typename SrcT>
+static int pack_chunk(rslf_volume* vol, const SrcT* d_src, int V0, int Vn, bool image_major, float scale)
+{
+    rslf_ctx* ctx = vol->ctx;
+    const size_t rows = (size_t)Vn * vol->S;
+    int rc = ensure_partial(ctx, rows);
+    if (rc)
+        return rc;
+    if (image_major)
+        hipLaunchKernelGGL((k0_pack<SrcT, true>), dim3((unsigned)rows), dim3(256), 0, ctx->stream, d_src, vol->base, V0, Vn, Vn,
+                           vol->S, vol->U, vol->C, vol->pitch, scale, ctx->partial);
+    else
+        hipLaunchKernelGGL((k0_pack<SrcT, false>), dim3((unsigned)rows), dim3(256), 0, ctx->stream, d_src, vol->base, V0, Vn, Vn,
+                           vol->S, vol->U, vol->C, vol->pitch, scale, ctx->partial);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(k0_minmax_final, dim3(1), dim3(256), 0, ctx->stream, ctx->partial, (int)rows, ctx->minmax);
+    HIP_TRY(hipGetLastError());
+    return RSLF_OK;
+}
+
+// Host upload in scanline chunks through a bounded device staging buffer.
+template <typename SrcT>
+static int upload_host(rslf_volume* vol, const SrcT* const* h_ptrs, size_t row_stride_bytes, bool image_major, float scale)
+{
+    rslf_ctx* ctx = vol->ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t row_bytes = (size_t)vol->U * vol->C * sizeof(SrcT);
+    if (row_stride_bytes == 0)
+        row_stride_bytes = row_bytes;
+    if (row_stride_bytes < row_bytes)
+        return fail(RSLF_ERR_INVALID_ARG, "row_stride_bytes %zu < row size %zu", row_stride_bytes, row_bytes);
+    const size_t epi_bytes = row_bytes * vol->S;
+    const size_t budget = (size_t)256 << 20;
+    int chunk = (int)std::max<size_t>(1, budget / epi_bytes);
+    chunk = std::min(chunk, vol->V);
+    int rc = ensure_staging(ctx, (size_t)chunk * epi_bytes);
+    if (rc)
+        return rc;
+    rc = minmax_begin(ctx);
+    if (rc)
+        return rc;
+    for (int v0 = 0; v0 < vol->V; v0 += chunk) {
+        const int vn = std::min(chunk, vol->V - v0);
+        if (!image_major) {
+            // h_ptrs[v] -> S rows; staging [vn][S][U*C]
+            for (int i = 0; i < vn; i++) {
+                if (!h_ptrs[v0 + i])
+                    return fail(RSLF_ERR_INVALID_ARG, "h_epis[%d] is NULL", v0 + i);
+                HIP_TRY(hipMemcpy2DAsync((char*)ctx->staging + (size_t)i * epi_bytes, row_bytes, h_ptrs[v0 + i], row_stride_bytes,
+                                         row_bytes, vol->S, hipMemcpyHostToDevice, ctx->stream));
+            }
+        } else {
+            // h_ptrs[s] -> V rows; staging [S][vn][U*C]
+            for (int s = 0; s < vol->S; s++) {
+                if (!h_ptrs[s])
+                    return fail(RSLF_ERR_INVALID_ARG, "h_imgs[%d] is NULL", s);
+                HIP_TRY(hipMemcpy2DAsync((char*)ctx->staging + (size_t)s * vn * row_bytes, row_bytes,
+                                         (const char*)h_ptrs[s] + (size_t)v0 * row_stride_bytes, row_stride_bytes, row_bytes, vn,
+                                         hipMemcpyHostToDevice, ctx->stream));
+            }
+        }
+        rc = pack_chunk<SrcT>(vol, (const SrcT*)ctx->staging, v0, vn, image_major, scale);
+        if (rc)
+            return rc;
+        // the staging buffer is reused by the next chunk
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    return minmax_end(vol);
+}
+
+// dc.hpp:442-460: epi_scale_factor = max over every value of every EPI
+static float host_max_f32(const float* const* h_ptrs, int n_ptrs, int rows, size_t row_stride_bytes, size_t row_elems, float start)
+{
+    float m = start;
+    for (int i = 0; i < n_ptrs; i++) {
+        for (int r = 0; r < rows; r++) {
+            const float* p = (const float*)((const char*)h_ptrs[i] + (size_t)r * row_stride_bytes);
+            for (size_t k = 0; k < row_elems; k++)
+                if (p[k] > m)
+                    m = p[k];
+        }
+    }
+    return m;
+}
+
+static float scale_of(float epi_scale_factor)
+{
+    return (float)(1.0 / (double)epi_scale_factor);   // dc.hpp:474 through cvtScale's float scale
+}
+
+extern "C" int rslf_volume_upload_epis_f32(rslf_volume* vol, const float* const* h_epis, size_t row_stride_bytes,
+                                           float epi_scale_factor, float* scale_used)
+{
+    if (!vol || !h_epis)
+        return fail(RSLF_ERR_INVALID_ARG, "vol/h_epis is NULL");
+    const size_t row_elems = (size_t)vol->U * vol->C;
+    const size_t stride = row_stride_bytes ? row_stride_bytes : row_elems * sizeof(float);
+    if (epi_scale_factor < 0)
+        epi_scale_factor = host_max_f32(h_epis, vol->V, vol->S, stride, row_elems, epi_scale_factor);
+    if (scale_used)
+        *scale_used = epi_scale_factor;
+    return upload_host<float>(vol, h_epis, stride, false, scale_of(epi_scale_factor));
+}
+
+extern "C" int rslf_volume_upload_epis_u8(rslf_volume* vol, const uint8_t* const* h_epis, size_t row_stride_bytes)
+{
+    if (!vol || !h_epis)
+        return fail(RSLF_ERR_INVALID_ARG, "vol/h_epis is NULL");
+    return upload_host<uint8_t>(vol, h_epis, row_stride_bytes, false, (float)(1.0 / 255.0));   // dc.hpp:470
+}
+
+extern "C" int rslf_volume_upload_images_f32(rslf_volume* vol, const float* const* h_imgs, size_t row_stride_bytes,
+                                             float epi_scale_factor, float* scale_used)
+{
+    if (!vol || !h_imgs)
+        return fail(RSLF_ERR_INVALID_ARG, "vol/h_imgs is NULL");
+    const size_t row_elems = (size_t)vol->U * vol->C;
+    const size_t stride = row_stride_bytes ? row_stride_bytes : row_elems * sizeof(float);
+    if (epi_scale_factor < 0)
+        epi_scale_factor = host_max_f32(h_imgs, vol->S, vol->V, stride, row_elems, epi_scale_factor);
+    if (scale_used)
+        *scale_used = epi_scale_factor;
+    return upload_host<float>(vol, h_imgs, stride, true, scale_of(epi_scale_factor));
+}
+
+extern "C" int rslf_volume_upload_images_u8(rslf_volume* vol, const uint8_t* const* h_imgs, size_t row_stride_bytes)
+{
+    if (!vol || !h_imgs)
+        return fail(RSLF_ERR_INVALID_ARG, "vol/h_imgs is NULL");
+    return upload_host<uint8_t>(vol, h_imgs, row_stride_bytes, true, (float)(1.0 / 255.0));
+}
+
+extern "C" int rslf_volume_pack_device_f32(rslf_volume* vol, const float* d_vsuc, float epi_scale_factor, float* scale_used)
+{
+    if (!vol || !d_vsuc)
+        return fail(RSLF_ERR_INVALID_ARG, "vol/d_vsuc is NULL");
+    if (epi_scale_factor < 0)
+        return fail(RSLF_ERR_INVALID_ARG, "pack_device needs an explicit epi_scale_factor (> 0); 1.0 keeps the values");
+    rslf_ctx* ctx = vol->ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (scale_used)
+        *scale_used = epi_scale_factor;
+    int rc = minmax_begin(ctx);
+    if (rc)
+        return rc;
+    rc = pack_chunk<float>(vol, d_vsuc, 0, vol->V, false, scale_of(epi_scale_factor));
+    if (rc)
+        return rc;
+    return minmax_end(vol);
+}
+
+// ---- hot path -------------------------------------------------------------
+
+extern "C" int rslf_edge_confidence_pile(rslf_ctx* ctx, const rslf_volume* vol, int s, const rslf_params* p,
+                                         float* d_Ce_vu, uint8_t* d_Ce_mask_vu)
+{
+    if (!ctx || !vol || !d_Ce_vu || !d_Ce_mask_vu)
+        return fail(RSLF_ERR_INVALID_ARG, "NULL argument");
+    int rc = check_params(p);
+    if (rc)
+        return rc;
+    if (s < 0 || s >= vol->S)
+        return fail(RSLF_ERR_INVALID_ARG, "s=%d outside [0,%d)", s, vol->S);
+    if (!vol->filled)
+        return fail(RSLF_ERR_INVALID_ARG, "volume has not been filled");
+    HIP_TRY(hipSetDevice(ctx->device));
+    EdgeConsts ec;
+    ec.filter_size = p->edge_confidence_filter_size;
+    ec.cut_shadows = p->cut_shadows;
+    ec.shadow_level = p->shadow_level;
+    ec.edge_thr = p->edge_score_threshold;
+    const dim3 grid((vol->U + 255) / 256, vol->V);
+    if (vol->C == 1)
+        hipLaunchKernelGGL(k1_edge_confidence<1>, grid, dim3(256), 0, ctx->stream, view_of(vol), s, ec, d_Ce_vu, d_Ce_mask_vu);
+    else
+        hipLaunchKernelGGL(k1_edge_confidence<3>, grid, dim3(256), 0, ctx->stream, view_of(vol), s, ec, d_Ce_vu, d_Ce_mask_vu);
+    HIP_TRY(hipGetLastError());
+    return RSLF_OK;
+}
+
+extern "C" int rslf_selective_median(rslf_ctx* ctx, const rslf_volume* vol, const float* d_src_vu, float* d_dst_vu,
+                                     int s_hat, int size, const uint8_t* d_mask_vu, float epsilon)
+{
+    if (!ctx || !vol || !d_src_vu || !d_dst_vu || !d_mask_vu)
+        return fail(RSLF_ERR_INVALID_ARG, "NULL argument");
+    if (d_src_vu == d_dst_vu)
+        return fail(RSLF_ERR_INVALID_ARG, "selective median cannot run in place");
+    if (size < 1 || (size & 1) == 0 || size > kMedianMaxSize)
+        return fail(RSLF_ERR_UNSUPPORTED, "median size must be odd and <= %d", kMedianMaxSize);
+    if (s_hat < 0 || s_hat >= vol->S)
+        return fail(RSLF_ERR_INVALID_ARG, "s_hat=%d outside [0,%d)", s_hat, vol->S);
+    HIP_TRY(hipSetDevice(ctx->device));
+    const dim3 grid((vol->U + 255) / 256, vol->V);
+    if (vol->C == 1)
+        hipLaunchKernelGGL(k3_selective_median<1>, grid, dim3(256), 0, ctx->stream, view_of(vol), d_src_vu, d_dst_vu, d_mask_vu,
+                           s_hat, size, epsilon);
+    else
+        hipLaunchKernelGGL(k3_selective_median<3>, grid, dim3(256), 0, ctx->stream, view_of(vol), d_src_vu, d_dst_vu, d_mask_vu,
+                           s_hat, size, epsilon);
+    HIP_TRY(hipGetLastError());
+    return RSLF_OK;
+}
+
+// Register-variant slot counts compiled into this library (multiples of 8).
+#ifndef RSLF_SPAD_LIST
+#define RSLF_SPAD_LIST(X) X(8) X(16) X(24) X(32) X(40) X(48) X(56) X(64) X(72) X(80) X(88) X(96) X(104) X(112) X(120) X(128)
+#endif
+
+static int launch_scan_reg(int spad, const ScanArgs& a, dim3 grid, hipStream_t stream)
+{
+    switch (spad) {
+#define RSLF_CASE(N)                                                                   \
+    case N:                                                                            \
+        hipLaunchKernelGGL(k2_scan_reg<N>, grid, dim3(256), 0, stream, a);             \
+        return RSLF_OK;
+        RSLF_SPAD_LIST(RSLF_CASE)
+#undef RSLF_CASE
+    default:
+        return fail(RSLF_ERR_UNSUPPORTED, "no register scan kernel with %d slots", spad);
+    }
+}
+
+static int pick_spad(int S)
+{
+    int best = 0;
+#define RSLF_PICK(N) \
+    if (N >= S && N - 8 < S && best == 0) best = N;
+    RSLF_SPAD_LIST(RSLF_PICK)
+#undef RSLF_PICK
+    return best;
+}
+
+extern "C" int rslf_depth_epi_pile(rslf_ctx* ctx, const rslf_volume* vol, const float* d_dmin_vu, const float* d_dmax_vu,
+                                   float dmin, float dmax, int dim_d, int s_hat, float* d_Ce_vu, uint8_t* d_Ce_mask_vu,
+                                   float* d_Cd_vu, float* d_depth_vu, float* d_rbar_vu, const rslf_params* p,
+                                   uint8_t* d_mask_vu, int32_t* d_idx_vu, float* d_score_vu, float* d_depth_raw_vu,
+                                   rslf_stats* stats)
+{
+    if (!ctx || !vol || !d_Ce_vu || !d_Ce_mask_vu || !d_Cd_vu || !d_depth_vu || !d_rbar_vu)
+        return fail(RSLF_ERR_INVALID_ARG, "NULL argument");
+    int rc = check_params(p);
+    if (rc)
+        return rc;
+    if ((d_dmin_vu == nullptr) != (d_dmax_vu == nullptr))
+        return fail(RSLF_ERR_INVALID_ARG, "d_dmin_vu and d_dmax_vu must both be given or both be NULL");
+    if (dim_d < 2)
+        return fail(RSLF_ERR_INVALID_ARG, "dim_d=%d: the hypothesis grid divides by dim_d-1 (core.hpp:548)", dim_d);
+    if (s_hat < 0 || s_hat >= vol->S)
+        return fail(RSLF_ERR_INVALID_ARG, "s_hat=%d outside [0,%d)", s_hat, vol->S);
+    if (!vol->filled)
+        return fail(RSLF_ERR_INVALID_ARG, "volume has not been filled");
+    HIP_TRY(hipSetDevice(ctx->device));
+    rc = ensure_plane_scratch(ctx, vol->V, vol->U);
+    if (rc)
+        return rc;
+
+    const size_t n = (size_t)vol->V * vol->U;
+    hipStream_t st = ctx->stream;
+    if (d_idx_vu)
+        HIP_TRY(hipMemsetAsync(d_idx_vu, 0xFF, n * sizeof(int32_t), st));   // -1
+    if (d_score_vu)
+        HIP_TRY(hipMemsetAsync(d_score_vu, 0, n * sizeof(float), st));
+    HIP_TRY(hipMemsetAsync(ctx->total, 0, sizeof(unsigned long long), st));
+
+    hipLaunchKernelGGL(k_compact_mask, dim3(vol->V), dim3(256), 0, st, d_Ce_mask_vu, d_mask_vu, vol->U, ctx->list, ctx->count,
+                       ctx->total);
+    HIP_TRY(hipGetLastError());
+
+    ScanArgs a;
+    a.vol = view_of(vol);
+    a.list = ctx->list;
+    a.count = ctx->count;
+    a.dmin_vu = d_dmin_vu;
+    a.dmax_vu = d_dmax_vu;
+    a.dmin = dmin;
+    a.dmax = dmax;
+    a.dim_d = dim_d;
+    a.s_hat = s_hat;
+    a.k = make_scan_consts(p);
+    a.Ce = d_Ce_vu;
+    a.Ce_mask = d_Ce_mask_vu;
+    a.scan_mask = d_mask_vu;
+    a.Cd = d_Cd_vu;
+    a.depth = d_depth_vu;
+    a.rbar = d_rbar_vu;
+    a.idx = d_idx_vu;
+    a.score = d_score_vu;
+    a.tiles_per_row = (vol->U + 63) / 64;
+    const long long tiles = (long long)vol->V * a.tiles_per_row;
+    a.logical_blocks = (int)((tiles + 3) / 4);
+    a.per_xcd = (a.logical_blocks + 7) / 8;
+    const dim3 grid((unsigned)(a.per_xcd * 8));
+
+    // Register variant: one channel, S within the compiled slot counts, and
+    // radiances in [0, 1e6] so that max(R,0) == R and the 1e30 sentinel dwarfs them.
+    int spad = 0;
+    if (vol->C == 1 && vol->min_value >= 0.0f && vol->max_value <= 1.0e6f)
+        spad = pick_spad(vol->S);
+    const char* force = getenv("RSLF_FORCE_SCAN");   // "generic": parity tests exercise the fallback on small cases
+    if (force && strcmp(force, "generic") == 0)
+        spad = 0;
+
+    HIP_TRY(hipEventRecord(ctx->ev0, st));
+    if (spad) {
+        rc = launch_scan_reg(spad, a, grid, st);
+        if (rc)
+            return rc;
+    } else if (vol->C == 1) {
+        hipLaunchKernelGGL(k2_scan_generic<1>, grid, dim3(256), 0, st, a);
+    } else {
+        hipLaunchKernelGGL(k2_scan_generic<3>, grid, dim3(256), 0, st, a);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(ctx->ev1, st));
+    ctx->ev_valid = true;
+
+    if (d_depth_raw_vu)
+        HIP_TRY(hipMemcpyAsync(d_depth_raw_vu, d_depth_vu, n * sizeof(float), hipMemcpyDeviceToDevice, st));
+
+    // core.hpp:881-892: median over the EDGE mask, result replaces best_depth
+    rc = rslf_selective_median(ctx, vol, d_depth_vu, ctx->depth_tmp, s_hat, p->median_filter_size, d_Ce_mask_vu,
+                               p->median_filter_epsilon);
+    if (rc)
+        return rc;
+    HIP_TRY(hipMemcpyAsync(d_depth_vu, ctx->depth_tmp, n * sizeof(float), hipMemcpyDeviceToDevice, st));
+
+    if (stats) {
+        unsigned long long tot = 0;
+        HIP_TRY(hipMemcpyAsync(&tot, ctx->total, sizeof(tot), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        stats->pixels_scanned = (int64_t)tot;
+        stats->units = (int64_t)tot * dim_d;
+        stats->scan_kernel = spad ? RSLF_SCAN_REG_1CH : RSLF_SCAN_GENERIC;
+        stats->s_pad = spad;
+    }
+    return RSLF_OK;
+}
+
+static int resolve_s_hat(int s_hat, int S)
+{
+    if (s_hat < 0 || s_hat > S - 1)
+        return (int)std::floor((0.0 + S) / 2);   // dc.hpp:490-494
+    return s_hat;
+}
+
+extern "C" int rslf_depth1d_pile_run(rslf_ctx* ctx, const rslf_volume* vol, float dmin, float dmax, int dim_d, int s_hat,
+                                     const rslf_params* p, float* d_Ce_vu, uint8_t* d_Ce_mask_vu, float* d_Cd_vu,
+                                     float* d_depth_vu, float* d_rbar_vu, int32_t* d_idx_vu, float* d_score_vu,
+                                     float* d_depth_raw_vu, rslf_stats* stats)
+{
+    if (!ctx || !vol || !d_Ce_vu || !d_Ce_mask_vu || !d_Cd_vu || !d_depth_vu || !d_rbar_vu)
+        return fail(RSLF_ERR_INVALID_ARG, "NULL argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    s_hat = resolve_s_hat(s_hat, vol->S);
+    const size_t n = (size_t)vol->V * vol->U;
+    hipStream_t st = ctx->stream;
+    // dc.hpp:501-510 (C_e and C_d are uninitialised there; zero is the intended start)
+    HIP_TRY(hipMemsetAsync(d_Ce_vu, 0, n * sizeof(float), st));
+    HIP_TRY(hipMemsetAsync(d_Cd_vu, 0, n * sizeof(float), st));
+    HIP_TRY(hipMemsetAsync(d_depth_vu, 0, n * sizeof(float), st));
+    HIP_TRY(hipMemsetAsync(d_rbar_vu, 0, n * vol->C * sizeof(float), st));
+    int rc = rslf_edge_confidence_pile(ctx, vol, s_hat, p, d_Ce_vu, d_Ce_mask_vu);   // dc.hpp:538
+    if (rc)
+        return rc;
+    return rslf_depth_epi_pile(ctx, vol, nullptr, nullptr, dmin, dmax, dim_d, s_hat, d_Ce_vu, d_Ce_mask_vu, d_Cd_vu,   // dc.hpp:547
+                               d_depth_vu, d_rbar_vu, p, nullptr, d_idx_vu, d_score_vu, d_depth_raw_vu, stats);
+}
+
+extern "C" int rslf_depth1d_pile_run_host(rslf_ctx* ctx, const rslf_volume* vol, float dmin, float dmax, int dim_d, int s_hat,
+                                          const rslf_params* p, float* h_Ce_vu, uint8_t* h_Ce_mask_vu, float* h_Cd_vu,
+                                          float* h_depth_vu, float* h_rbar_vu, int32_t* h_idx_vu, float* h_score_vu,
+                                          float* h_depth_raw_vu, rslf_stats* stats)
+{
+    if (!ctx || !vol)
+        return fail(RSLF_ERR_INVALID_ARG, "NULL argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t n = (size_t)vol->V * vol->U;
+    // one device block: Ce, Cd, depth, raw, score | rbar (n*C) | idx | mask
+    const size_t f_planes = 5 + (size_t)vol->C;
+    const size_t bytes = n * (f_planes * sizeof(float) + sizeof(int32_t) + 1);
+    char* blk = nullptr;
+    hipError_t e = hipMalloc(&blk, bytes);
+    if (e != hipSuccess)
+        return fail(RSLF_ERR_ALLOC, "hipMalloc(%zu) for result planes failed: %s", bytes, hipGetErrorString(e));
+    float* d_Ce = (float*)blk;
+    float* d_Cd = d_Ce + n;
+    float* d_depth = d_Cd + n;
+    float* d_raw = d_depth + n;
+    float* d_score = d_raw + n;
+    float* d_rbar = d_score + n;
+    int32_t* d_idx = (int32_t*)(d_rbar + n * vol->C);
+    uint8_t* d_mask = (uint8_t*)(d_idx + n);
+    int rc = rslf_depth1d_pile_run(ctx, vol, dmin, dmax, dim_d, s_hat, p, d_Ce, d_mask, d_Cd, d_depth, d_rbar, d_idx, d_score,
+                                   d_raw, nullptr);
+    hipStream_t st = ctx->stream;
+    auto pull = [&](void* h, const void* d, size_t b) -> hipError_t {
+        return h ? hipMemcpyAsync(h, d, b, hipMemcpyDeviceToHost, st) : hipSuccess;
+    };
+    if (rc == RSLF_OK) {
+        hipError_t ce = pull(h_Ce_vu, d_Ce, n * 4);
+        if (ce == hipSuccess) ce = pull(h_Ce_mask_vu, d_mask, n);
+        if (ce == hipSuccess) ce = pull(h_Cd_vu, d_Cd, n * 4);
+        if (ce == hipSuccess) ce = pull(h_depth_vu, d_depth, n * 4);
+        if (ce == hipSuccess) ce = pull(h_rbar_vu, d_rbar, n * 4 * vol->C);
+        if (ce == hipSuccess) ce = pull(h_idx_vu, d_idx, n * 4);
+        if (ce == hipSuccess) ce = pull(h_score_vu, d_score, n * 4);
+        if (ce == hipSuccess) ce = pull(h_depth_raw_vu, d_raw, n * 4);
+        if (ce == hipSuccess) ce = hipStreamSynchronize(st);
+        if (ce != hipSuccess)
+            rc = fail(RSLF_ERR_HIP, "result download failed: %s", hipGetErrorString(ce));
+    } else {
+        (void)hipStreamSynchronize(st);
+    }
+    if (rc == RSLF_OK && stats) {
+        unsigned long long tot = 0;
+        if (hipMemcpy(&tot, ctx->total, sizeof(tot), hipMemcpyDeviceToHost) == hipSuccess) {
+            stats->pixels_scanned = (int64_t)tot;
+            stats->units = (int64_t)tot * dim_d;
+            const int spad = (vol->C == 1 && vol->min_value >= 0.0f && vol->max_value <= 1.0e6f) ? pick_spad(vol->S) : 0;
+            stats->scan_kernel = spad ? RSLF_SCAN_REG_1CH : RSLF_SCAN_GENERIC;
+            stats->s_pad = spad;
+        }
+    }
+    (void)hipFree(blk);
+    return rc;
+}
+
+extern "C" int rslf_last_scan_kernel_ms(rslf_ctx* ctx, float* ms)
+{
+    if (!ctx || !ms)
+        return fail(RSLF_ERR_INVALID_ARG, "NULL argument");
+    if (!ctx->ev_valid)
+        return fail(RSLF_ERR_INVALID_ARG, "no scan kernel has been launched on this context");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipEventSynchronize(ctx->ev1));
+    HIP_TRY(hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+    return RSLF_OK;
+}

@@ -1,0 +1,338 @@
+"""Host-side mirror of the reference's interface for the 1-D pile path.
+
+Names, argument meaning and defaults follow RSLightFields
+(/root/reference/RSLightFields/include/):
+  Depth1DParameters                 rslf_depth_computation_core.hpp:66-142
+  compute_1D_edge_confidence_pile   rslf_depth_computation_core.hpp:279-287
+  compute_1D_depth_epi_pile         rslf_depth_computation_core.hpp:293-310
+  selective_median_filter           rslf_depth_computation_core.hpp:366-375
+  Depth1DComputer_pile              rslf_depth_computation.hpp:93-143, :425-565
+The reference's `Mat`s become torch CUDA tensors (device memory + streams are
+all torch is used for); the arithmetic runs in librslf_hip.so through the C-ABI
+of include/rslf_hip.h.  No CPU path exists here.
+"""
+from __future__ import annotations
+
+import atexit
+import ctypes as C
+import sys
+from dataclasses import dataclass
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import RslfParams, RslfStats, RslfVolumeDesc, check
+
+
+@dataclass
+class Depth1DParameters:
+    """rslf::Depth1DParameters<T> with the reference's member names and defaults."""
+
+    par_edge_score_threshold: float = 0.02
+    par_line_score_threshold: float = 0.02
+    par_disp_score_threshold: float = 0.01
+    par_raw_score_threshold: float = 0.0
+    par_mean_shift_max_iter: float = 10.0
+    par_edge_confidence_filter_size: int = 9
+    par_edge_confidence_opening_type: int = 2
+    par_edge_confidence_opening_size: int = 1
+    par_median_filter_size: int = 5
+    par_median_filter_epsilon: float = 0.1
+    par_propagation_epsilon: float = 0.1
+    par_slope_factor: float = 1.0
+    par_cut_shadows: bool = True
+    par_shadow_level: float = 0.05 * 1.73205080757
+    par_kernel_bandwidth: float = 0.2   # BandwidthKernel(_BANDWIDTH_KERNEL_PARAMETER), core.hpp:78
+
+    @staticmethod
+    def get_default() -> "Depth1DParameters":
+        return Depth1DParameters()
+
+    def to_c(self) -> RslfParams:
+        p = RslfParams()
+        for f, _ in RslfParams._fields_:
+            v = getattr(self, "par_" + f)
+            setattr(p, f, int(v) if isinstance(getattr(p, f), int) else float(v))
+        return p
+
+
+class Context:
+    """rslf_ctx bound to one GPU; launches go to torch's current stream on it."""
+
+    def __init__(self, device: int | torch.device | None = None):
+        if device is None:
+            device = torch.cuda.current_device()
+        self.device = torch.device("cuda", device) if isinstance(device, int) else torch.device(device)
+        h = C.c_void_p()
+        check(_lib.lib().rslf_ctx_create(self.device.index or 0, C.byref(h)), "rslf_ctx_create")
+        self._h = h
+        self.use_current_stream()
+
+    def use_current_stream(self) -> None:
+        s = torch.cuda.current_stream(self.device).cuda_stream
+        check(_lib.lib().rslf_ctx_set_stream(self._h, C.c_void_p(s)), "rslf_ctx_set_stream")
+
+    def synchronize(self) -> None:
+        check(_lib.lib().rslf_ctx_synchronize(self._h), "rslf_ctx_synchronize")
+
+    def last_scan_kernel_ms(self) -> float:
+        ms = C.c_float()
+        check(_lib.lib().rslf_last_scan_kernel_ms(self._h, C.byref(ms)), "rslf_last_scan_kernel_ms")
+        return float(ms.value)
+
+    def close(self) -> None:
+        # at interpreter shutdown the HIP runtime may already be gone: leave the handle to the OS
+        if getattr(self, "_h", None) and not sys.is_finalizing():
+            _lib.lib().rslf_ctx_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+
+_DEFAULT_CTX: dict[int, Context] = {}
+
+
+@atexit.register
+def _drop_default_contexts() -> None:
+    # release while the HIP runtime is still alive (module globals die too late for that)
+    for c in list(_DEFAULT_CTX.values()):
+        c._h = None
+    _DEFAULT_CTX.clear()
+
+
+def default_context(device=None) -> Context:
+    idx = torch.cuda.current_device() if device is None else torch.device(device).index or 0
+    if idx not in _DEFAULT_CTX:
+        _DEFAULT_CTX[idx] = Context(idx)
+    return _DEFAULT_CTX[idx]
+
+
+def _ptr(t: Optional[torch.Tensor]) -> C.c_void_p:
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+class Volume:
+    """The light-field slab in HBM, [V][S][C][pitch] float32 (rslf_volume)."""
+
+    def __init__(self, ctx: Context, V: int, S: int, U: int, C_: int):
+        self.ctx = ctx
+        h = C.c_void_p()
+        check(_lib.lib().rslf_volume_create(ctx._h, V, S, U, C_, C.byref(h)), "rslf_volume_create")
+        self._h = h
+        self.V, self.S, self.U, self.C = V, S, U, C_
+        self.scale_used: float | None = None
+
+    # -- constructors -----------------------------------------------------
+    @staticmethod
+    def from_epis(epis: Sequence[np.ndarray], epi_scale_factor: float = -1.0, ctx: Context | None = None) -> "Volume":
+        """The reference's constructor input: a Vec<Mat> of V EPIs, each [S,U] or
+        [S,U,3], uint8 or float32 (dc.hpp:425-477)."""
+        ctx = ctx or default_context()
+        e0 = np.asarray(epis[0])
+        S, U = e0.shape[:2]
+        C_ = 1 if e0.ndim == 2 else e0.shape[2]
+        vol = Volume(ctx, len(epis), S, U, C_)
+        is_u8 = e0.dtype == np.uint8
+        arrs = [np.ascontiguousarray(e, dtype=np.uint8 if is_u8 else np.float32) for e in epis]
+        for a in arrs:
+            if a.shape != arrs[0].shape:
+                raise ValueError("all EPIs must have the same shape")
+        ptrs = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+        L = _lib.lib()
+        if is_u8:
+            check(L.rslf_volume_upload_epis_u8(vol._h, ptrs, 0), "rslf_volume_upload_epis_u8")
+            vol.scale_used = 255.0
+        else:
+            su = C.c_float()
+            check(L.rslf_volume_upload_epis_f32(vol._h, ptrs, 0, float(epi_scale_factor), C.byref(su)),
+                  "rslf_volume_upload_epis_f32")
+            vol.scale_used = float(su.value)
+        return vol
+
+    @staticmethod
+    def from_images(imgs: Sequence[np.ndarray], epi_scale_factor: float = -1.0, ctx: Context | None = None) -> "Volume":
+        """Image-major input, S images each [V,U] or [V,U,3] -- what
+        rslf::build_epis_from_imgs (rslf_io.cpp:194-227) consumes."""
+        ctx = ctx or default_context()
+        i0 = np.asarray(imgs[0])
+        V, U = i0.shape[:2]
+        C_ = 1 if i0.ndim == 2 else i0.shape[2]
+        vol = Volume(ctx, V, len(imgs), U, C_)
+        is_u8 = i0.dtype == np.uint8
+        arrs = [np.ascontiguousarray(e, dtype=np.uint8 if is_u8 else np.float32) for e in imgs]
+        ptrs = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+        L = _lib.lib()
+        if is_u8:
+            check(L.rslf_volume_upload_images_u8(vol._h, ptrs, 0), "rslf_volume_upload_images_u8")
+            vol.scale_used = 255.0
+        else:
+            su = C.c_float()
+            check(L.rslf_volume_upload_images_f32(vol._h, ptrs, 0, float(epi_scale_factor), C.byref(su)),
+                  "rslf_volume_upload_images_f32")
+            vol.scale_used = float(su.value)
+        return vol
+
+    @staticmethod
+    def from_dense(vsuc, epi_scale_factor: float = 1.0, ctx: Context | None = None) -> "Volume":
+        """Dense [V,S,U] / [V,S,U,C] float32, numpy (uploaded) or a CUDA tensor
+        (packed on the device)."""
+        ctx = ctx or default_context()
+        if isinstance(vsuc, np.ndarray):
+            a = np.ascontiguousarray(vsuc, np.float32)
+            if a.ndim == 4 and a.shape[3] == 1:
+                a = a[..., 0]
+            return Volume.from_epis(list(a), epi_scale_factor, ctx)
+        t = vsuc
+        if t.dim() == 3:
+            t = t.unsqueeze(-1)
+        if not t.is_cuda or t.dtype != torch.float32:
+            raise ValueError("from_dense needs a float32 CUDA tensor or a numpy array")
+        t = t.contiguous()
+        V, S, U, C_ = t.shape
+        vol = Volume(ctx, V, S, U, C_)
+        ctx.use_current_stream()
+        su = C.c_float()
+        check(_lib.lib().rslf_volume_pack_device_f32(vol._h, _ptr(t), float(epi_scale_factor), C.byref(su)),
+              "rslf_volume_pack_device_f32")
+        vol.scale_used = float(su.value)
+        return vol
+
+    def describe(self) -> RslfVolumeDesc:
+        d = RslfVolumeDesc()
+        check(_lib.lib().rslf_volume_describe(self._h, C.byref(d)), "rslf_volume_describe")
+        return d
+
+    def close(self) -> None:
+        if getattr(self, "_h", None) and not sys.is_finalizing():
+            _lib.lib().rslf_volume_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+
+# ---- the reference's free functions -------------------------------------
+
+def compute_1D_edge_confidence_pile(vol: Volume, a_s: int, a_edge_confidence_v_u: torch.Tensor,
+                                    a_parameters: Depth1DParameters | None = None) -> torch.Tensor:
+    """core.hpp:279-287.  Accumulates INTO a_edge_confidence_v_u ([V,U] f32
+    CUDA, pass zeros) and returns the new mask ([V,U] u8) -- the reference
+    allocates the mask itself (core.hpp:740)."""
+    p = (a_parameters or Depth1DParameters()).to_c()
+    mask = torch.empty((vol.V, vol.U), dtype=torch.uint8, device=a_edge_confidence_v_u.device)
+    vol.ctx.use_current_stream()
+    check(_lib.lib().rslf_edge_confidence_pile(vol.ctx._h, vol._h, a_s, C.byref(p), _ptr(a_edge_confidence_v_u), _ptr(mask)),
+          "rslf_edge_confidence_pile")
+    return mask
+
+
+def compute_1D_depth_epi_pile(vol: Volume, a_dmin_v_u, a_dmax_v_u, a_dim_d: int, a_s_hat: int,
+                              a_edge_confidence_v_u: torch.Tensor, a_edge_confidence_mask_v_u: torch.Tensor,
+                              a_disp_confidence_v_u: torch.Tensor, a_best_depth_v_u: torch.Tensor,
+                              a_rbar_v_u: torch.Tensor, a_parameters: Depth1DParameters | None = None,
+                              a_mask_v_u: torch.Tensor | None = None, *, idx_v_u: torch.Tensor | None = None,
+                              score_v_u: torch.Tensor | None = None, depth_raw_v_u: torch.Tensor | None = None,
+                              want_stats: bool = False) -> RslfStats | None:
+    """core.hpp:293-310.  a_dmin_v_u / a_dmax_v_u are [V,U] f32 CUDA tensors or
+    Python floats (the constant planes of dc.hpp:486-487).  All planes are
+    updated in place; a_best_depth_v_u ends as the selective median (core.hpp:892)."""
+    p = (a_parameters or Depth1DParameters()).to_c()
+    planes = isinstance(a_dmin_v_u, torch.Tensor)
+    st = RslfStats() if want_stats else None
+    vol.ctx.use_current_stream()
+    check(_lib.lib().rslf_depth_epi_pile(
+        vol.ctx._h, vol._h, _ptr(a_dmin_v_u if planes else None), _ptr(a_dmax_v_u if planes else None),
+        0.0 if planes else float(a_dmin_v_u), 0.0 if planes else float(a_dmax_v_u), a_dim_d, a_s_hat,
+        _ptr(a_edge_confidence_v_u), _ptr(a_edge_confidence_mask_v_u), _ptr(a_disp_confidence_v_u),
+        _ptr(a_best_depth_v_u), _ptr(a_rbar_v_u), C.byref(p), _ptr(a_mask_v_u), _ptr(idx_v_u), _ptr(score_v_u),
+        _ptr(depth_raw_v_u), C.byref(st) if st is not None else None), "rslf_depth_epi_pile")
+    return st
+
+
+def selective_median_filter(a_src: torch.Tensor, vol: Volume, a_s_hat: int, a_size: int, a_mask_v_u: torch.Tensor,
+                            a_epsilon: float) -> torch.Tensor:
+    """core.hpp:366-375; returns a_dst."""
+    dst = torch.empty_like(a_src)
+    vol.ctx.use_current_stream()
+    check(_lib.lib().rslf_selective_median(vol.ctx._h, vol._h, _ptr(a_src), _ptr(dst), a_s_hat, a_size,
+                                           _ptr(a_mask_v_u), float(a_epsilon)), "rslf_selective_median")
+    return dst
+
+
+# ---- the reference's class -------------------------------------------------
+
+class Depth1DComputer_pile:
+    """rslf::Depth1DComputer_pile<T> (dc.hpp:93-143).
+
+    `epis` is the reference's Vec<Mat> (a list of V arrays [S,U] or [S,U,3],
+    uint8 or float32), a dense numpy / CUDA array [V,S,U(,C)], or a Volume that
+    is already resident.  After run(), the result members hold CUDA tensors."""
+
+    def __init__(self, epis, dmin: float, dmax: float, dim_d: int, s_hat: int = -1, epi_scale_factor: float = -1.0,
+                 parameters: Depth1DParameters | None = None, ctx: Context | None = None):
+        self.m_parameters = parameters or Depth1DParameters.get_default()
+        if isinstance(epis, Volume):
+            self.m_epis = epis
+        elif isinstance(epis, (list, tuple)):
+            self.m_epis = Volume.from_epis(epis, epi_scale_factor, ctx)
+        elif isinstance(epis, np.ndarray):
+            a = epis[..., 0] if (epis.ndim == 4 and epis.shape[3] == 1) else epis
+            self.m_epis = Volume.from_epis(list(a), epi_scale_factor, ctx)
+        else:
+            self.m_epis = Volume.from_dense(epis, epi_scale_factor if epi_scale_factor > 0 else 1.0, ctx)
+        vol = self.m_epis
+        self.m_dim_d = int(dim_d)
+        self.m_dmin, self.m_dmax = float(dmin), float(dmax)
+        # dc.hpp:490-498
+        self.m_s_hat = int(np.floor((0.0 + vol.S) / 2)) if (s_hat < 0 or s_hat > vol.S - 1) else int(s_hat)
+        dev = vol.ctx.device
+        V, U, C_ = vol.V, vol.U, vol.C
+        self.m_edge_confidence_v_u = torch.empty((V, U), dtype=torch.float32, device=dev)
+        self.m_edge_confidence_mask_v_u = torch.empty((V, U), dtype=torch.uint8, device=dev)
+        self.m_disp_confidence_v_u = torch.empty((V, U), dtype=torch.float32, device=dev)
+        self.m_best_depth_v_u = torch.empty((V, U), dtype=torch.float32, device=dev)
+        self.m_rbar_v_u = torch.empty((V, U, C_), dtype=torch.float32, device=dev)
+        # parity witnesses, not in the reference
+        self.m_depth_idx_v_u = torch.empty((V, U), dtype=torch.int32, device=dev)
+        self.m_score_v_u = torch.empty((V, U), dtype=torch.float32, device=dev)
+        self.m_depth_raw_v_u = torch.empty((V, U), dtype=torch.float32, device=dev)
+        self.stats: RslfStats | None = None
+
+    def run(self, want_stats: bool = True) -> None:
+        """dc.hpp:513-565."""
+        vol = self.m_epis
+        p = self.m_parameters.to_c()
+        st = RslfStats() if want_stats else None
+        vol.ctx.use_current_stream()
+        check(_lib.lib().rslf_depth1d_pile_run(
+            vol.ctx._h, vol._h, self.m_dmin, self.m_dmax, self.m_dim_d, self.m_s_hat, C.byref(p),
+            _ptr(self.m_edge_confidence_v_u), _ptr(self.m_edge_confidence_mask_v_u), _ptr(self.m_disp_confidence_v_u),
+            _ptr(self.m_best_depth_v_u), _ptr(self.m_rbar_v_u), _ptr(self.m_depth_idx_v_u), _ptr(self.m_score_v_u),
+            _ptr(self.m_depth_raw_v_u), C.byref(st) if st is not None else None), "rslf_depth1d_pile_run")
+        self.stats = st
+
+    def get_s_hat(self) -> int:
+        return self.m_s_hat
+
+    def results(self) -> dict:
+        """Host copies of every output plane."""
+        torch.cuda.synchronize(self.m_epis.ctx.device)
+        return dict(
+            edge_confidence=self.m_edge_confidence_v_u.cpu().numpy(),
+            edge_mask=self.m_edge_confidence_mask_v_u.cpu().numpy(),
+            disp_confidence=self.m_disp_confidence_v_u.cpu().numpy(),
+            depth=self.m_best_depth_v_u.cpu().numpy(),
+            rbar=self.m_rbar_v_u.cpu().numpy(),
+            depth_idx=self.m_depth_idx_v_u.cpu().numpy(),
+            score=self.m_score_v_u.cpu().numpy(),
+            depth_raw=self.m_depth_raw_v_u.cpu().numpy(),
+        )

@@ -1,0 +1,265 @@
+"""HIP path vs the CPU oracle, through the C-ABI, on a real MI355X.
+
+Bit-exact for masks and argmax indices; float planes asserted within 1e-5 (the
+tolerance north_star states) AND bit-identical, since both sides perform the
+same IEEE binary32 operations in the same order.  C_d goes through double
+arithmetic whose summation order is free, so it is held to 1e-5 only.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from tests.util import assert_pile_parity
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def rs():
+    import torch
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    from remotesensingproject_amd import depth
+    return depth
+
+
+def _run(rs, vol, dmin, dmax, D, s_hat=-1, params=None, scale=1.0):
+    comp = rs.Depth1DComputer_pile(vol, dmin, dmax, D, s_hat, scale, params)
+    comp.run()
+    return comp, comp.results()
+
+
+def _structured(U, V, S, C, seed, deltas=None, dmin=-2.0, dmax=5.0):
+    from remotesensingproject_amd.synth import make_lightfield
+    return make_lightfield(U, V, S, C, seed=seed, deltas=deltas, dmin=dmin, dmax=dmax, band=2)[0]
+
+
+CASES_1CH = [
+    # name, U, V, S, D, dmin, dmax, kind
+    ("tiny_s9", 40, 6, 9, 25, -1.0, 2.0, "struct"),
+    ("s16_exact_pad", 70, 5, 16, 17, -1.5, 1.5, "noise"),
+    ("s17_pad7", 70, 5, 17, 17, -1.5, 1.5, "noise"),
+    ("s33_interior", 300, 6, 33, 32, -1.0, 2.875, "struct"),
+    ("s33_noise", 130, 5, 33, 24, -2.0, 2.0, "noise"),
+    ("s64", 200, 3, 64, 16, -1.0, 1.0, "noise"),
+    ("s101_c3like", 700, 3, 101, 16, -2.0, 5.5, "struct"),
+    ("s128_max_reg", 150, 2, 128, 8, -0.5, 0.5, "noise"),
+    ("s129_generic", 150, 2, 129, 8, -0.5, 0.5, "noise"),
+    ("u_not_mult64", 67, 4, 9, 12, -3.0, 3.0, "noise"),
+    ("u_lt_filter", 6, 3, 5, 9, -1.0, 1.0, "noise"),
+]
+
+
+def _vol(kind, U, V, S, C, seed, dmin, dmax):
+    if kind == "struct":
+        return _structured(U, V, S, C, seed, dmin=dmin, dmax=dmax)
+    rng = np.random.default_rng(seed)
+    return rng.uniform(0.0, 1.0, size=(V, S, U, C)).astype(np.float32)
+
+
+@pytest.mark.parametrize("case", CASES_1CH, ids=[c[0] for c in CASES_1CH])
+def test_pile_1ch(rs, oracle_mod, case):
+    name, U, V, S, D, dmin, dmax, kind = case
+    vol = _vol(kind, U, V, S, 1, 1234 + len(name), dmin, dmax)
+    ref = oracle_mod.depth1d_pile_run(vol, dmin, dmax, D)
+    comp, got = _run(rs, vol, dmin, dmax, D)
+    assert_pile_parity(got, ref, label=name)
+    assert comp.stats.pixels_scanned == int((oracle_mod.edge_confidence_pile(vol, comp.get_s_hat())[1] > 0).sum())
+    assert comp.stats.units == comp.stats.pixels_scanned * D
+    want_reg = S <= 128
+    assert (comp.stats.scan_kernel == 1) == want_reg, "unexpected scan kernel %d" % comp.stats.scan_kernel
+
+
+@pytest.mark.parametrize("kind", ["struct", "noise"])
+def test_pile_3ch(rs, oracle_mod, kind):
+    U, V, S, D = 90, 5, 17, 20
+    vol = _vol(kind, U, V, S, 3, 77, -1.0, 2.0)
+    ref = oracle_mod.depth1d_pile_run(vol, -1.0, 2.0, D)
+    comp, got = _run(rs, vol, -1.0, 2.0, D)
+    assert_pile_parity(got, ref, label="3ch_" + kind)
+    assert comp.stats.scan_kernel == 0
+
+
+def test_generic_kernel_matches_on_1ch(rs, oracle_mod, monkeypatch):
+    """The fallback scan (any S, any sign) must agree with the register scan's oracle too."""
+    monkeypatch.setenv("RSLF_FORCE_SCAN", "generic")
+    U, V, S, D = 130, 4, 33, 24
+    vol = _vol("noise", U, V, S, 1, 5, -2.0, 2.0)
+    ref = oracle_mod.depth1d_pile_run(vol, -2.0, 2.0, D)
+    comp, got = _run(rs, vol, -2.0, 2.0, D)
+    assert comp.stats.scan_kernel == 0
+    assert_pile_parity(got, ref, label="forced_generic")
+
+
+def test_negative_radiances_take_generic_path(rs, oracle_mod):
+    """max(R,0) != R when the input goes negative (core.hpp:580): register scan must not run."""
+    rng = np.random.default_rng(11)
+    vol = rng.uniform(-0.5, 1.0, size=(4, 9, 80, 1)).astype(np.float32)
+    ref = oracle_mod.depth1d_pile_run(vol, -1.0, 1.0, 16)
+    comp, got = _run(rs, vol, -1.0, 1.0, 16)
+    assert comp.stats.scan_kernel == 0
+    assert_pile_parity(got, ref, label="negative")
+
+
+def test_s_hat_and_params(rs, oracle_mod):
+    """Non-default s_hat, slope factor, thresholds, iteration count, bandwidth."""
+    vol = _vol("noise", 120, 4, 21, 1, 3, 0, 0)
+    P = rs.Depth1DParameters(par_slope_factor=0.5, par_edge_score_threshold=0.3, par_raw_score_threshold=0.2,
+                             par_mean_shift_max_iter=4.0, par_kernel_bandwidth=0.35, par_median_filter_size=3,
+                             par_median_filter_epsilon=0.25, par_cut_shadows=False, par_edge_confidence_filter_size=5)
+    op = oracle_mod.default_params()
+    op.slope_factor, op.edge_score_threshold, op.raw_score_threshold = 0.5, 0.3, 0.2
+    op.mean_shift_max_iter, op.kernel_bandwidth, op.median_filter_size = 4.0, 0.35, 3
+    op.median_filter_epsilon, op.cut_shadows, op.edge_confidence_filter_size = 0.25, 0, 5
+    ref = oracle_mod.depth1d_pile_run(vol, -2.0, 3.0, 21, 4, op)
+    comp, got = _run(rs, vol, -2.0, 3.0, 21, 4, P)
+    assert_pile_parity(got, ref, label="params")
+    assert (ref.depth_idx == -1).any() and (ref.depth_idx >= 0).any()   # the raw threshold rejects some pixels
+
+
+def test_shadow_flat_and_dark_rows(rs, oracle_mod):
+    """All-dark row (shadow cut), flat row (C_e = 0 => nothing scanned), dmin == dmax (all hypotheses tie => index 0)."""
+    rng = np.random.default_rng(9)
+    vol = rng.uniform(0.2, 1.0, size=(5, 9, 64, 1)).astype(np.float32)
+    vol[1] = 0.01          # dark
+    vol[2] = 0.5           # flat
+    vol[3, :, 10:20] = 0.0
+    ref = oracle_mod.depth1d_pile_run(vol, 1.0, 1.0, 8)
+    comp, got = _run(rs, vol, 1.0, 1.0, 8)
+    assert_pile_parity(got, ref, label="degenerate")
+    assert (got["edge_mask"][1] == 0).all() and (got["edge_mask"][2] == 0).all()
+    assert (got["depth_idx"][got["edge_mask"] > 0] == 0).all()
+
+
+def test_u8_epis_and_images(rs, oracle_mod):
+    """uint8 Vec<Mat> input (x * float(1/255), dc.hpp:470), and the image-major upload."""
+    rng = np.random.default_rng(21)
+    raw = rng.integers(0, 256, size=(5, 9, 70, 3), dtype=np.uint8)
+    vol = oracle_mod.normalize_u8(raw)
+    ref = oracle_mod.depth1d_pile_run(vol, -1.0, 1.0, 12)
+    comp = rs.Depth1DComputer_pile(list(raw), -1.0, 1.0, 12)
+    comp.run()
+    assert_pile_parity(comp.results(), ref, label="u8_epis")
+    imgs = [np.ascontiguousarray(raw[:, s]) for s in range(raw.shape[1])]   # [s][v][u][c]
+    v2 = rs.Volume.from_images(imgs)
+    comp2 = rs.Depth1DComputer_pile(v2, -1.0, 1.0, 12)
+    comp2.run()
+    assert_pile_parity(comp2.results(), ref, label="u8_images")
+
+
+def test_f32_max_normalisation(rs, oracle_mod):
+    """float input with epi_scale_factor < 0: scale by the max over all EPIs (dc.hpp:442-460, :474)."""
+    rng = np.random.default_rng(22)
+    raw = rng.uniform(8.0, 262.0, size=(4, 9, 70)).astype(np.float32)
+    vol, scale = oracle_mod.normalize_f32(raw[..., None])
+    ref = oracle_mod.depth1d_pile_run(vol, -1.0, 1.0, 12)
+    comp = rs.Depth1DComputer_pile(list(raw), -1.0, 1.0, 12)
+    comp.run()
+    assert abs(comp.m_epis.scale_used - scale) == 0
+    assert_pile_parity(comp.results(), ref, label="f32_max")
+
+
+def test_per_pixel_range_and_scan_mask(rs, oracle_mod):
+    """compute_1D_depth_epi_pile with per-pixel [dmin,dmax] planes and a caller mask
+    (the fine-to-coarse / 2-D callers' form, core.hpp:293-310, :510-511)."""
+    import torch
+    rng = np.random.default_rng(31)
+    V, S, U, D = 5, 17, 150, 14
+    vol = rng.uniform(0.0, 1.0, size=(V, S, U, 1)).astype(np.float32)
+    dmin = rng.uniform(-2.0, 0.0, size=(V, U)).astype(np.float32)
+    dmax = (dmin + rng.uniform(0.0, 3.0, size=(V, U))).astype(np.float32)
+    mask = (rng.uniform(size=(V, U)) > 0.4).astype(np.uint8) * 255
+    s_hat = 8
+    Ce, cm = oracle_mod.edge_confidence_pile(vol, s_hat)
+    pre_depth = rng.uniform(-1, 1, size=(V, U)).astype(np.float32)   # values the median must keep seeing
+    ref = oracle_mod.depth_epi_pile(vol, dmin, dmax, D, s_hat, Ce, cm, mask_vu=mask)
+    # oracle.depth_epi_pile starts depth at 0; redo with the pre-filled plane by hand
+    import ctypes as C
+    L = oracle_mod.lib()
+    p = oracle_mod.default_params()
+    Ce2, cm2, m2 = Ce.copy(), cm.copy(), mask.copy()
+    Cd2 = np.zeros((V, U), np.float32); depth2 = pre_depth.copy(); rbar2 = np.zeros((V, U, 1), np.float32)
+    idx2 = np.full((V, U), -1, np.int32); sc2 = np.zeros((V, U), np.float32); raw2 = np.zeros((V, U), np.float32)
+    L.oracle_depth_epi_pile(vol.reshape(-1), V, S, U, 1, dmin.reshape(-1), dmax.reshape(-1), D, s_hat,
+                            Ce2.reshape(-1), cm2.reshape(-1), Cd2.reshape(-1), depth2.reshape(-1), rbar2.reshape(-1),
+                            C.byref(p), m2.ctypes.data_as(C.c_void_p), idx2.ctypes.data_as(C.c_void_p),
+                            sc2.ctypes.data_as(C.c_void_p), raw2.ctypes.data_as(C.c_void_p))
+
+    dev = "cuda"
+    v = rs.Volume.from_dense(vol)
+    t = lambda a: torch.from_numpy(a.copy()).to(dev)
+    tCe = torch.zeros((V, U), dtype=torch.float32, device=dev)
+    tcm = rs.compute_1D_edge_confidence_pile(v, s_hat, tCe)
+    assert np.array_equal(tCe.cpu().numpy(), Ce) and np.array_equal(tcm.cpu().numpy(), cm)
+    tCd = torch.zeros((V, U), dtype=torch.float32, device=dev)
+    tdepth = t(pre_depth); trbar = torch.zeros((V, U, 1), dtype=torch.float32, device=dev)
+    tmask = t(mask); tidx = torch.empty((V, U), dtype=torch.int32, device=dev)
+    tsc = torch.empty((V, U), dtype=torch.float32, device=dev); traw = torch.empty((V, U), dtype=torch.float32, device=dev)
+    st = rs.compute_1D_depth_epi_pile(v, t(dmin), t(dmax), D, s_hat, tCe, tcm, tCd, tdepth, trbar, None, tmask,
+                                      idx_v_u=tidx, score_v_u=tsc, depth_raw_v_u=traw, want_stats=True)
+    torch.cuda.synchronize()
+    assert st.pixels_scanned == int(((cm & mask) > 0).sum())
+    assert np.array_equal(tmask.cpu().numpy(), m2), "scan mask must be AND-ed in place (core.hpp:511)"
+    assert np.array_equal(tidx.cpu().numpy(), idx2)
+    assert np.array_equal(tcm.cpu().numpy(), cm2)
+    assert np.array_equal(tsc.cpu().numpy(), sc2)
+    assert np.array_equal(traw.cpu().numpy(), raw2)
+    assert np.array_equal(tdepth.cpu().numpy(), depth2)
+    assert np.array_equal(trbar.cpu().numpy(), rbar2)
+    assert np.array_equal(tCe.cpu().numpy(), Ce2)
+    assert np.abs(tCd.cpu().numpy() - Cd2).max() <= 1e-5
+    assert (idx2 == ref.depth_idx).all()
+
+
+def test_selective_median_standalone(rs, oracle_mod):
+    import torch
+    rng = np.random.default_rng(41)
+    for C_ in (1, 3):
+        V, S, U = 9, 5, 77
+        vol = rng.uniform(0.0, 1.0, size=(V, S, U, C_)).astype(np.float32)
+        vol[:, 2] = np.round(vol[:, 2] * 3) / 3   # clusters of similar radiance
+        src = rng.uniform(-2, 5, size=(V, U)).astype(np.float32)
+        src[rng.uniform(size=(V, U)) < 0.3] = 1.0   # ties
+        mask = (rng.uniform(size=(V, U)) > 0.3).astype(np.uint8) * 255
+        for size in (3, 5, 7):
+            want = oracle_mod.selective_median(src, vol, 2, mask, size, np.float32(0.1))
+            v = rs.Volume.from_dense(vol)
+            got = rs.selective_median_filter(torch.from_numpy(src).cuda(), v, 2, size, torch.from_numpy(mask).cuda(), 0.1)
+            assert np.array_equal(got.cpu().numpy(), want), (C_, size)
+
+
+def test_analytic_known_answer(rs):
+    """Oracle-free KAT: integer true disparity on the hypothesis grid => every sample of the
+    true line equals the centre radiance, K == 1, score == 1.0 exactly, argmax known."""
+    from remotesensingproject_amd.synth import make_lightfield
+    U, V, S, D = 256, 8, 33, 33
+    dmin, dmax = -2.0, 2.0   # step 1/8, integers on the grid
+    deltas = np.array([-2, -1, 0, 1, 2, 1, 0, -1], np.float32)
+    vol, _ = make_lightfield(U, V, S, 1, seed=5, deltas=deltas)
+    comp, got = _run(rs, vol, dmin, dmax, D)
+    want_idx = ((deltas - dmin) / ((dmax - dmin) / (D - 1))).astype(np.int32)
+    m = got["edge_mask"] > 0
+    assert m.mean() > 0.99
+    for v in range(V):
+        assert (got["depth_idx"][v][m[v]] == want_idx[v]).all(), v
+        assert (got["score"][v][m[v]] == 1.0).all(), v
+        assert (got["depth"][v][m[v]] == deltas[v]).all(), v
+    # rbar = (r + r + ... + r) / n in float: the centre radiance up to the rounding of that sum
+    assert np.abs(got["rbar"][..., 0][m] - vol[:, S // 2, :, 0][m]).max() < 1e-6
+
+
+def test_errors_do_not_throw_across_abi(rs):
+    import torch
+    from remotesensingproject_amd import _lib
+    vol = rs.Volume.from_dense(torch.rand((2, 5, 70, 1), device="cuda"))
+    Ce = torch.zeros((2, 70), device="cuda")
+    with pytest.raises(_lib.RslfError) as e:
+        rs.compute_1D_edge_confidence_pile(vol, 7, Ce)
+    assert e.value.status == -1
+    with pytest.raises(_lib.RslfError):
+        rs.Depth1DComputer_pile(vol, -1.0, 1.0, 1).run()           # dim_d < 2
+    with pytest.raises(_lib.RslfError) as e:
+        rs.Depth1DComputer_pile(vol, -1.0, 1.0, 8, parameters=rs.Depth1DParameters(par_edge_confidence_opening_size=3)).run()
+    assert e.value.status == -2
+    with pytest.raises(_lib.RslfError):
+        rs.Volume(rs.default_context(), 2, 5, 70, 2)               # C = 2 unsupported
