@@ -1,0 +1,231 @@
+#!/usr/bin/env python3
+"""Throughput of the EPI depth scan on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c3]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = one pass of the hot path (K1 edge confidence, compaction, K2 scan, K3
+selective median; for N > 1 also the RCCL gather that reassembles the depth map
+on rank 0) over one synthetic light field that is already resident in HBM.
+N = 1 runs BASELINE.json configs[2] (1920x1080, 101 views, 256 hypotheses); for
+N > 1 the SAME sweep is sharded by scanline (configs[3]): strong scaling.
+Prints one JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_VECTOR_TFLOPS = 157.3   # MI355X_MICROARCH.md "Peak FP32 (vector)"
+PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md "HBM3E peak BW"
+
+
+def algorithmic_flops_per_unit(S: int, C: int) -> int:
+    """each add/sub/mul/div/max/floor/ceil of the reference's
+    arithmetic counted once per (pixel, hypothesis)."""
+    return 95 * S + 21 if C == 1 else 230 * S + 40
+
+
+def algorithmic_bytes_per_pixel(S: int, C: int) -> int:
+    """every input voxel read once, every output written once."""
+    return 4 * S * C + 8 + 13 + 4 * C
+
+
+def cpu_baseline(cfg: dict, budget_s: float = 12.0) -> dict:
+    """The CPU oracle (a port of the reference's arithmetic, OpenMP over scanlines like
+    core.hpp:799) timed on this host on a bounded sample: whole scanlines of the same workload."""
+    import oracle
+    from remotesensingproject_amd.synth import make_lightfield
+    threads = oracle.num_threads()
+    rows = max(threads, 8)
+    vol, _ = make_lightfield(cfg["U"], rows, cfg["S"], cfg["C"], seed=cfg["seed"], dmin=cfg["dmin"], dmax=cfg["dmax"])
+    # units = pixels whose mask is set on entry to the scan (core.hpp:515-527) x hypotheses
+    pixels = int((oracle.edge_confidence_pile(vol, cfg["S"] // 2)[1] > 0).sum())
+    units, elapsed, reps = 0, 0.0, 0
+    while elapsed < budget_s and reps < 64:
+        t0 = time.perf_counter()
+        oracle.depth1d_pile_run(vol, cfg["dmin"], cfg["dmax"], cfg["D"])
+        elapsed += time.perf_counter() - t0
+        units += pixels * cfg["D"]
+        reps += 1
+    return {
+        "value": units / elapsed / 1e6,
+        "unit": "Mpixel*hyp/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": "%d scanlines x %d px x %d views x %d hypotheses of the same synthetic field, %d passes, %.1f s" % (
+            rows, cfg["U"], cfg["S"], cfg["D"], reps, elapsed),
+    }
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="c3", help="synthetic config of BASELINE.md section 4 (c2, c3, c5)")
+    ap.add_argument("--rows", type=int, default=0, help="override the number of scanlines (developer runs)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from remotesensingproject_amd import depth as rs
+    from remotesensingproject_amd import sharding
+    from remotesensingproject_amd.synth import CONFIGS, make_lightfield
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs the torch.distributed.run launcher (WORLD_SIZE=%d)" % (args.gpus, world))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
+
+    cfg = dict(CONFIGS[args.config])
+    if args.rows:
+        cfg["V"] = args.rows
+    U, V, S, C, D = cfg["U"], cfg["V"], cfg["S"], cfg["C"], cfg["D"]
+    params = rs.Depth1DParameters()
+    shard = sharding.make_shard(V, rank, world, params.par_median_filter_size)
+
+    # synthetic light field: every rank draws the same textures and keeps its scanlines (+halo)
+    host, _ = make_lightfield(U, V, S, C, seed=cfg["seed"], dmin=cfg["dmin"], dmax=cfg["dmax"], rows=shard.rows)
+    ctx = rs.default_context(dev)
+    vol = rs.Volume.from_dense(torch.from_numpy(host).to(dev), 1.0, ctx)
+    del host
+    comp = rs.Depth1DComputer_pile(vol, cfg["dmin"], cfg["dmax"], D, parameters=params)
+
+    def planes():
+        return dict(edge_confidence=comp.m_edge_confidence_v_u, disp_confidence=comp.m_disp_confidence_v_u,
+                    depth=comp.m_best_depth_v_u, depth_raw=comp.m_depth_raw_v_u, score=comp.m_score_v_u,
+                    depth_idx=comp.m_depth_idx_v_u, rbar=comp.m_rbar_v_u, edge_mask=comp.m_edge_confidence_mask_v_u)
+
+    k2_ms = []
+
+    def step(record: bool):
+        comp.run(want_stats=False)
+        out = planes()
+        if world > 1:
+            out = sharding.gather_planes(out, shard, U, C)
+        if record:
+            k2_ms.append(ctx.last_scan_kernel_ms())   # HIP events on the launching stream
+        return out
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step(False)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step(True)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # units = mask-selected pixels actually scanned x hypotheses, owned rows only:
+    # the scan mask on entry is the edge mask K1 produces (core.hpp:513)
+    ce0 = torch.zeros((vol.V, U), dtype=torch.float32, device=dev)
+    m0 = rs.compute_1D_edge_confidence_pile(vol, comp.get_s_hat(), ce0, params)
+    scanned_local = int((m0[shard.interior] > 0).sum().item())
+    comp.run(want_stats=True)
+    torch.cuda.synchronize(dev)
+    n = torch.tensor([scanned_local], dtype=torch.int64, device=dev)
+    if world > 1:
+        dist.all_reduce(n)
+    pixels = int(n.item())
+    units_per_step = pixels * D
+    ms_per_step = elapsed / args.steps * 1e3
+    value = units_per_step / (elapsed / args.steps) / 1e6
+
+    if rank == 0:
+        k2_avg_ms = float(np.mean(k2_ms))
+        units_launch = int(comp.stats.units)          # what rank 0's K2 launch processed (incl. halo rows)
+        flops = algorithmic_flops_per_unit(S, C)
+        achieved_tflops = units_launch * flops / (k2_avg_ms * 1e-3) / 1e12
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "k2_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                key = "%s_n%d" % (args.config, world)
+                if key in tj and not args.rows:
+                    traffic = tj[key]["hbm_bytes_per_launch"]
+            except Exception:  # noqa: BLE001
+                traffic = None
+        px_launch = units_launch // D
+        hbm_bytes = px_launch * algorithmic_bytes_per_pixel(S, C)
+        line = {
+            "metric": "Mpixel*disparity-hypotheses/s",
+            "value": value,
+            "unit": "Mpixel*hyp/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "%s: %dx%d px x %d views x %d ch, %d hypotheses in [%g, %g], seed %d, all pixels confident" % (
+                    args.config, U, V, S, C, D, cfg["dmin"], cfg["dmax"], cfg["seed"]),
+                "sharding": "none" if world == 1 else "scanline blocks + %d-row recomputed halo, 1 RCCL gather/step" % ((params.par_median_filter_size - 1) // 2),
+                "scan_kernel": "k2_scan_reg<%d>" % comp.stats.s_pad if comp.stats.scan_kernel == 1 else "k2_scan_generic<%d>" % C,
+                "pixels_scanned": pixels,
+            },
+            "roofline": {
+                "bound": "valu_fp32",
+                "kernel": "k2_scan",
+                "achieved": achieved_tflops,
+                "peak": PEAK_FP32_VECTOR_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": achieved_tflops / PEAK_FP32_VECTOR_TFLOPS,
+                "traffic": traffic,
+                "flops_per_unit": flops,
+                "units_per_launch": units_launch,
+                "kernel_ms": k2_avg_ms,
+                "note": "algorithmic flops (SURVEY 8d) / K2 HIP-event time; the reference's arithmetic forbids FMA, "
+                        "so the reachable ceiling is the non-FMA issue rate (DESIGN.md)",
+            },
+            "roofline_hbm": {
+                "bound": "hbm",
+                "achieved": hbm_bytes / (k2_avg_ms * 1e-3) / 1e9,
+                "peak": PEAK_HBM_GBS,
+                "unit": "GB/s",
+                "frac": hbm_bytes / (k2_avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                "bytes_per_unit": algorithmic_bytes_per_pixel(S, C) / D,
+                "note": "compulsory-byte model; this path is VALU-bound, not HBM-bound (SURVEY 8d)",
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(cfg)
+        print(json.dumps(line), flush=True)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -28,6 +28,9 @@ HIPCC_FLAGS = [
     "-shared",
     "-ffp-contract=off",
     "-fno-fast-math",
+    # packed fp32 (v_pk_*) issues at half the rate of the scalar forms on gfx950
+    # (tools/ubench_valu.hip), so SLP packing only adds v_mov shuffles
+    "-fno-slp-vectorize",
 ]
 
 

@@ -169,8 +169,7 @@ __global__ __launch_bounds__(256) void k2_scan_generic(ScanArgs a)
                     R0[0] = (R > 0.0f) ? R : 0.0f;          // cv::max(R, 0), NaN -> 0
                     const float delta = R - rbar[0];
                     const float q = (a.k.k1 * delta) * delta;
-                    const float one_m = 1.0f - q;
-                    K = (one_m > 0.0f) ? one_m : 0.0f;      // NaN -> 0
+                    K = kernel_weight(q);                   // max(1 - q, 0), NaN -> 0
                 } else {
                     float q[C];
 #pragma unroll
@@ -185,8 +184,7 @@ __global__ __launch_bounds__(256) void k2_scan_generic(ScanArgs a)
                     }
                     float qs = q[0] + q[C > 2 ? 2 : 0];     // OpenCV 3.x reduceC_: (q0 + q2) + q1
                     qs = qs + q[C > 1 ? 1 : 0];
-                    const float one_m = 1.0f - qs;
-                    K = (one_m > 0.0f) ? one_m : 0.0f;
+                    K = kernel_weight(qs);
                 }
 #pragma unroll
                 for (int c = 0; c < C; c++) {
@@ -222,7 +220,7 @@ __global__ __launch_bounds__(256) void k2_scan_generic(ScanArgs a)
 //
 // The S samples of one (pixel, hypothesis) are gathered once into SPAD VGPRs
 // and the mean-shift passes run out of registers:
-//     delta = R - rbar ; t = k1*delta ; q = t*delta ; K = max(1 - q, 0)
+//     delta = R - rbar ; t = k1*delta ; q = t*delta ; K = clamp(1 - q)
 //     P = R*K ; A += P ; B += K                      (7 VALU, no memory)
 // Out-of-range samples (the reference's NaN, interp.hpp:189) and the padding
 // slots s >= S hold kSentinel = 1e30: then q = +inf, K = max(-inf, 0) = 0 and
@@ -341,8 +339,7 @@ __device__ __forceinline__ void scan_reg_body(const ScanArgs& a, int v, int u, b
                 const float delta = R[s] - rbar;
                 const float tq = k1 * delta;
                 const float q = tq * delta;
-                const float one_m = 1.0f - q;
-                const float K = fmaxf(one_m, 0.0f);
+                const float K = kernel_weight(q);
                 const float pr = R[s] * K;
                 A = A + pr;
                 B = B + K;

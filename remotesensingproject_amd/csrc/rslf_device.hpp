@@ -56,6 +56,19 @@ __device__ __forceinline__ float norm3(float x, float y, float z)
     return (float)sqrt(s);
 }
 
+// K = max(1 - q, 0), NaN -> 0  (src/rslf_kernels.cpp:23-25 / :51-53) as ONE instruction:
+// v_sub_f32 with the clamp output modifier clamps to [0, 1] and (DX10_CLAMP, the hipcc kernel
+// default) sends NaN to 0.  q = (k*delta)*delta is >= 0 or NaN, so 1 - q <= 1 and the upper
+// clamp never acts: the result equals cv::max(1 - q, 0) bit for bit.  v_max_f32 issues at
+// about half the rate of v_sub_f32 on gfx950 (tools/ubench_valu.hip), so this is worth ~20 %
+// of the mean-shift loop.
+__device__ __forceinline__ float kernel_weight(float q)
+{
+    float k;
+    asm("v_sub_f32_e64 %0, 1.0, %1 clamp" : "=v"(k) : "v"(q));
+    return k;
+}
+
 // cv::BORDER_REFLECT_101
 __device__ __forceinline__ int reflect101(int p, int len)
 {

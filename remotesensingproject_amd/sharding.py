@@ -1,0 +1,141 @@
+"""Scanline sharding of the pile path over the GPUs of one node.
+
+K1 (edge confidence) and K2 (the scan) are independent per scanline v
+(rslf_depth_computation_core.hpp:743-757, :799-854); K3 (selective median,
+:663-718) reads rows v +- (size-1)/2 of the depth plane, the mask and the
+s_hat row of the volume.  So each rank takes a contiguous block of scanlines
+plus a halo of (size-1)/2 rows on each side that it RECOMPUTES (no exchange),
+and the only data-path collective is the reassembly of the output planes on
+rank 0: one gather per run, all planes packed in a single byte buffer (xGMI is
+point-to-point, so one ~MB message per peer beats eight small ones).
+
+One process per GPU; `torch.distributed` backend "nccl" is RCCL on ROCm.  The
+partition/stitch logic is backend-agnostic and is exercised on CPU with gloo
+(tests/test_sharding_gloo.py), where the per-rank compute is injected.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Callable, Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+# plane name -> (torch dtype, trailing channels multiplier: 1 or "C")
+PLANES: List[Tuple[str, torch.dtype, bool]] = [
+    ("edge_confidence", torch.float32, False),
+    ("disp_confidence", torch.float32, False),
+    ("depth", torch.float32, False),
+    ("depth_raw", torch.float32, False),
+    ("score", torch.float32, False),
+    ("depth_idx", torch.int32, False),
+    ("rbar", torch.float32, True),
+    ("edge_mask", torch.uint8, False),
+]
+
+
+def row_partition(V: int, world: int) -> List[Tuple[int, int]]:
+    """Contiguous scanline blocks [v0, v1), sizes differing by at most one."""
+    base, rem = divmod(V, world)
+    out, v = [], 0
+    for r in range(world):
+        n = base + (1 if r < rem else 0)
+        out.append((v, v + n))
+        v += n
+    return out
+
+
+@dataclass
+class Shard:
+    rank: int
+    world: int
+    V: int            # scanlines of the whole light field
+    v0: int           # owned block [v0, v1)
+    v1: int
+    lo: int           # computed block [lo, hi) = owned + halo, clipped to [0, V)
+    hi: int
+
+    @property
+    def rows(self) -> slice:
+        """Rows of the whole volume this rank must hold."""
+        return slice(self.lo, self.hi)
+
+    @property
+    def interior(self) -> slice:
+        """Owned rows, in the local (computed-block) frame."""
+        return slice(self.v0 - self.lo, self.v1 - self.lo)
+
+
+def make_shard(V: int, rank: int, world: int, median_filter_size: int = 5) -> Shard:
+    halo = (median_filter_size - 1) // 2          # core.hpp:686
+    v0, v1 = row_partition(V, world)[rank]
+    return Shard(rank, world, V, v0, v1, max(0, v0 - halo), min(V, v1 + halo))
+
+
+def _row_bytes(U: int, C: int) -> int:
+    n = 0
+    for _, dt, per_c in PLANES:
+        n += U * (C if per_c else 1) * torch.empty((), dtype=dt).element_size()
+    return n
+
+
+def pack_planes(planes: Dict[str, torch.Tensor], rows: slice, max_rows: int, U: int, C: int) -> torch.Tensor:
+    """Owned rows of every output plane, back to back, as one uint8 buffer of
+    max_rows * row_bytes (short blocks are zero padded so every rank sends the same size)."""
+    dev = planes["depth"].device
+    buf = torch.zeros(max_rows * _row_bytes(U, C), dtype=torch.uint8, device=dev)
+    off = 0
+    for name, dt, per_c in PLANES:
+        t = planes[name][rows].contiguous()
+        assert t.dtype == dt, (name, t.dtype, dt)
+        b = t.view(torch.uint8).reshape(-1)
+        buf[off:off + b.numel()] = b
+        off += max_rows * U * (C if per_c else 1) * t.element_size()
+    return buf
+
+
+def unpack_planes(bufs: List[torch.Tensor], parts: List[Tuple[int, int]], max_rows: int, U: int, C: int) -> Dict[str, torch.Tensor]:
+    """Inverse of pack_planes over all ranks: the stitched [V, U(, C)] planes."""
+    V = parts[-1][1]
+    dev = bufs[0].device
+    out: Dict[str, torch.Tensor] = {}
+    off = 0
+    for name, dt, per_c in PLANES:
+        cc = C if per_c else 1
+        es = torch.empty((), dtype=dt).element_size()
+        full = torch.empty((V, U, cc) if per_c else (V, U), dtype=dt, device=dev)
+        for (v0, v1), buf in zip(parts, bufs):
+            n = (v1 - v0) * U * cc * es
+            seg = buf[off:off + n].view(dt).reshape((v1 - v0, U, cc) if per_c else (v1 - v0, U))
+            full[v0:v1] = seg
+        out[name] = full
+        off += max_rows * U * cc * es
+    return out
+
+
+def gather_planes(planes: Dict[str, torch.Tensor], shard: Shard, U: int, C: int, group=None,
+                  dst: int = 0) -> Optional[Dict[str, torch.Tensor]]:
+    """Reassemble the depth map on rank `dst`: ONE gather of the packed owned rows."""
+    parts = row_partition(shard.V, shard.world)
+    max_rows = max(b - a for a, b in parts)
+    buf = pack_planes(planes, shard.interior, max_rows, U, C)
+    if shard.world == 1:
+        return unpack_planes([buf], parts, max_rows, U, C)
+    if shard.rank == dst:
+        recv = [torch.empty_like(buf) for _ in range(shard.world)]
+        dist.gather(buf, recv, dst=dst, group=group)
+        return unpack_planes(recv, parts, max_rows, U, C)
+    dist.gather(buf, None, dst=dst, group=group)
+    return None
+
+
+def run_sharded(local_compute: Callable[[Shard], Dict[str, torch.Tensor]], V: int, U: int, C: int,
+                median_filter_size: int = 5, group=None) -> Optional[Dict[str, torch.Tensor]]:
+    """local_compute(shard) -> output planes for rows [shard.lo, shard.hi) (it must run the
+    full K1+K2+K3 path on exactly those rows); returns the stitched planes on rank 0."""
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    shard = make_shard(V, rank, world, median_filter_size)
+    planes = local_compute(shard)
+    return gather_planes(planes, shard, U, C, group)
