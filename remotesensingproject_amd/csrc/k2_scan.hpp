@@ -6,15 +6,19 @@
 // (src/rslf_kernels.cpp:16-54) inlined.
 //
 // Work mapping (both variants)
-//   wavefront = 64 consecutive entries of one scanline's confident-pixel list
-//   lane      = one pixel u; the lane walks all dim_d hypotheses itself
-// so a wave's 64 gathers per (s, d) are 64 neighbouring floats of one EPI row
-// (coalesced along u), the argmax / mean over d never leaves the lane, and the
-// sum over s is the reference's sequential float sum.  Four such waves make a
-// 256-thread workgroup with no LDS and no barrier; logical workgroups are
+//   workgroup = one tile: 64 consecutive entries of one scanline's confident-pixel list
+//   wavefront = one quarter of the hypothesis range for that tile
+//   lane      = one pixel u; it walks its wave's hypotheses itself
+// A wave's 64 gathers per (s, d) are 64 neighbouring floats of one EPI row
+// (coalesced along u), and the sum over s is the reference's sequential float
+// sum.  The argmax / mean over d stays in the lane within a wave; the four
+// waves' partial results meet once in LDS (first maximum wins in hypothesis
+// order, as cv::minMaxLoc does).  Putting the four waves on ONE tile rather
+// than on four tiles quarters the number of EPIs a CU has in flight, so an
+// XCD's working set (~3 EPIs) stays inside its 4 MiB L2; logical workgroups are
 // dealt to XCDs in contiguous scanline ranges (rslf_device.hpp).
 //
-// This kernel is FP32-VALU bound: per (pixel, hypothesis, view,
+// The kernel is FP32-VALU bound: per (pixel, hypothesis, view,
 // mean-shift pass) the register variant issues 7 vector instructions and no
 // memory instruction.
 #pragma once
@@ -22,6 +26,8 @@
 #include "rslf_device.hpp"
 
 namespace rslf {
+
+constexpr int kScanWaves = 4;   // waves per workgroup = hypothesis chunks per tile
 
 struct ScanArgs {
     VolView vol;
@@ -34,39 +40,76 @@ struct ScanArgs {
     ScanConsts k;
     float* Ce;              // [V][U] in/out
     uint8_t* Ce_mask;       // [V][U] in/out
-    uint8_t* scan_mask;     // nullable: the caller's mask plane (cleared like Ce_mask? no: core.hpp:655-656 clears the edge mask only)
     float* Cd;              // [V][U]
     float* depth;           // [V][U]
     float* rbar;            // [V][U][C]
     int32_t* idx;           // nullable
     float* score;           // nullable
     int tiles_per_row;      // ceil(U / 64)
-    int logical_blocks;     // ceil(V * tiles_per_row / 4)
+    int logical_blocks;     // V * tiles_per_row
     int per_xcd;            // ceil(logical_blocks / 8)
 };
 
-// Which pixel does this lane own?  Returns false when the whole wave has none.
+// One lane's running result over the hypotheses it has scored (core.hpp:630-644).
+template <int C>
+struct Best {
+    float score;   // -1 before any hypothesis: scores are >= 0, so the first one always takes the lead
+    int d;
+    float D;
+    float rbar[C];
+    double sum;    // of all scores, for cv::mean (core.hpp:641)
+    __device__ __forceinline__ void init()
+    {
+        score = -1.0f;
+        d = 0;
+        D = 0.0f;
+#pragma unroll
+        for (int c = 0; c < C; c++)
+            rbar[c] = 0.0f;
+        sum = 0.0;
+    }
+    __device__ __forceinline__ void offer(float sc, int dd, float Dd, const float (&rb)[C])
+    {
+        sum += (double)sc;
+        if (sc > score) {   // strict: first maximum wins (cv::minMaxLoc, core.hpp:634)
+            score = sc;
+            d = dd;
+            D = Dd;
+#pragma unroll
+            for (int c = 0; c < C; c++)
+                rbar[c] = rb[c];
+        }
+    }
+};
+
+// Which tile does this workgroup own, which pixel this lane?  Block-uniform result
+// (every wave of the block takes the same branch, so the later barrier is safe).
 __device__ __forceinline__ bool scan_tile(const ScanArgs& a, int& v, int& u, bool& active)
 {
     const int lane = threadIdx.x & 63;
-    // wave-uniform by construction; readfirstlane lets the compiler keep v and row bases in SGPRs
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lb = xcd_logical_block(blockIdx.x, a.per_xcd);
     if (lb >= a.logical_blocks)
         return false;
-    const int T = lb * 4 + wave;
-    v = T / a.tiles_per_row;
-    if (v >= a.vol.V)
-        return false;
-    const int j = T - v * a.tiles_per_row;
+    v = lb / a.tiles_per_row;
+    const int j = lb - v * a.tiles_per_row;
     const int n = a.count[v];
     if (j * 64 >= n)
         return false;
     const int e = j * 64 + lane;
     active = e < n;
-    // idle lanes of the last tile shadow its last pixel so their addresses stay valid
+    // idle lanes of a scanline's last tile shadow its last pixel so their addresses stay valid
     u = a.list[(long long)v * a.vol.U + (active ? e : n - 1)];
     return true;
+}
+
+// This wave's hypotheses [d0, d1): contiguous quarters, so "first maximum" = lowest wave first.
+__device__ __forceinline__ void scan_chunk(const ScanArgs& a, int& d0, int& d1)
+{
+    // wave-uniform by construction; readfirstlane lets the compiler keep it in an SGPR
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int chunk = (a.dim_d + kScanWaves - 1) / kScanWaves;
+    d0 = min(wave * chunk, a.dim_d);
+    d1 = min(d0 + chunk, a.dim_d);
 }
 
 // core.hpp:545-548: D[d] = dmin + d * (dmax - dmin) / (dim_d - 1)
@@ -77,18 +120,53 @@ __device__ __forceinline__ float hypothesis(float dmin, float range, float denom
     return dmin + quo;
 }
 
-// core.hpp:630-657 for one lane once all hypotheses are scored.
+// Merge the waves' partial results in hypothesis order and write the pixel (core.hpp:630-657).
 template <int C>
-__device__ __forceinline__ void scan_epilogue(const ScanArgs& a, int v, int u, bool active, float best, int best_d,
-                                              float best_D, const float (&best_rbar)[C], double sum)
+__device__ __forceinline__ void scan_epilogue(const ScanArgs& a, int v, int u, bool active, const Best<C>& mine)
 {
-    if (!active)
+    __shared__ float s_score[kScanWaves][64];
+    __shared__ float s_D[kScanWaves][64];
+    __shared__ float s_rbar[kScanWaves][C][64];
+    __shared__ int s_d[kScanWaves][64];
+    __shared__ double s_sum[kScanWaves][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    s_score[wave][lane] = mine.score;
+    s_D[wave][lane] = mine.D;
+    s_d[wave][lane] = mine.d;
+    s_sum[wave][lane] = mine.sum;
+#pragma unroll
+    for (int c = 0; c < C; c++)
+        s_rbar[wave][c][lane] = mine.rbar[c];
+    __syncthreads();
+    if (wave != 0 || !active)
         return;
+
+    float best = mine.score, best_D = mine.D;
+    int best_d = mine.d;
+    float best_rbar[C];
+#pragma unroll
+    for (int c = 0; c < C; c++)
+        best_rbar[c] = mine.rbar[c];
+    double sum = mine.sum;
+#pragma unroll
+    for (int w = 1; w < kScanWaves; w++) {
+        const float sc = s_score[w][lane];
+        sum += s_sum[w][lane];
+        if (sc > best) {   // a wave that scored nothing holds -1 and never wins
+            best = sc;
+            best_d = s_d[w][lane];
+            best_D = s_D[w][lane];
+#pragma unroll
+            for (int c = 0; c < C; c++)
+                best_rbar[c] = s_rbar[w][c][lane];
+        }
+    }
+
     const long long o = (long long)v * a.vol.U + u;
-    if ((double)best > (double)a.k.raw_thr) {
+    if ((double)best > (double)a.k.raw_thr) {   // core.hpp:636
         a.depth[o] = best_D;
         const double mean = sum / (double)a.dim_d;
-        a.Cd[o] = (float)((double)a.Ce[o] * fabs((double)best - mean));
+        a.Cd[o] = (float)((double)a.Ce[o] * fabs((double)best - mean));   // core.hpp:641
 #pragma unroll
         for (int c = 0; c < C; c++)
             a.rbar[o * C + c] = best_rbar[c];
@@ -96,7 +174,7 @@ __device__ __forceinline__ void scan_epilogue(const ScanArgs& a, int v, int u, b
             a.idx[o] = best_d;
         if (a.score)
             a.score[o] = best;
-    } else {
+    } else {   // core.hpp:653-657
         a.Ce[o] = 0.0f;
         a.Ce_mask[o] = 0;
     }
@@ -108,12 +186,14 @@ __device__ __forceinline__ void scan_epilogue(const ScanArgs& a, int v, int u, b
 // slab (L1/L2 hits).  ~3x the instructions of the register variant.
 // ---------------------------------------------------------------------------
 template <int C>
-__global__ __launch_bounds__(256) void k2_scan_generic(ScanArgs a)
+__global__ __launch_bounds__(64 * kScanWaves) void k2_scan_generic(ScanArgs a)
 {
     int v, u;
     bool active;
     if (!scan_tile(a, v, u, active))
         return;
+    int d0, d1;
+    scan_chunk(a, d0, d1);
 
     const VolView& vol = a.vol;
     const float* epi = vol.row(v, 0, 0);
@@ -125,15 +205,10 @@ __global__ __launch_bounds__(256) void k2_scan_generic(ScanArgs a)
     const float range = dmax - dmin;
     const float denom = (float)(a.dim_d - 1);
 
-    float best = -1.0f, best_D = 0.0f;   // scores are >= 0, so d = 0 always takes the lead
-    int best_d = 0;
-    float best_rbar[C];
-#pragma unroll
-    for (int c = 0; c < C; c++)
-        best_rbar[c] = 0.0f;
-    double sum = 0.0;
+    Best<C> best;
+    best.init();
 
-    for (int d = 0; d < a.dim_d; d++) {
+    for (int d = d0; d < d1; d++) {
         const float Dd = hypothesis(dmin, range, denom, d);
         float rbar[C];
 #pragma unroll
@@ -148,14 +223,14 @@ __global__ __launch_bounds__(256) void k2_scan_generic(ScanArgs a)
             B = 0.0f;
             card = 0.0f;
             for (int s = 0; s < vol.S; s++) {
-                float x = (float)(a.s_hat - s) * Dd;   // I = S * D
-                x = x * a.k.slope;                     // I *= slope_factor
-                x = x + uf;                            // I += u
+                float x = (float)(a.s_hat - s) * Dd;   // I = S * D          core.hpp:550
+                x = x * a.k.slope;                     // I *= slope_factor  core.hpp:551
+                x = x + uf;                            // I += u             core.hpp:552
                 const float fl = floorf(x);
-                const int i0 = (int)fl;
+                const int i0 = (int)fl;                // interp.hpp:179-181
                 const int i1 = (int)ceilf(x);
                 const float t = x - fl;
-                const bool valid = !(i0 < 0 || i1 > Um1);
+                const bool valid = !(i0 < 0 || i1 > Um1);   // interp.hpp:182
                 const int j0 = min(max(i0, 0), Um1), j1 = min(max(i1, 0), Um1);
                 const float* row = epi + (long long)s * vol.stride_s;
                 const float omt = 1.0f - t;
@@ -164,9 +239,9 @@ __global__ __launch_bounds__(256) void k2_scan_generic(ScanArgs a)
                 if (C == 1) {
                     const float m0 = omt * row[j0];
                     const float m1 = t * row[j1];
-                    float R = m0 + m1;
-                    R = valid ? R : NAN;
-                    R0[0] = (R > 0.0f) ? R : 0.0f;          // cv::max(R, 0), NaN -> 0
+                    float R = m0 + m1;                      // interp.hpp:184
+                    R = valid ? R : NAN;                    // interp.hpp:189
+                    R0[0] = (R > 0.0f) ? R : 0.0f;          // cv::max(R, 0), NaN -> 0   core.hpp:580
                     const float delta = R - rbar[0];
                     const float q = (a.k.k1 * delta) * delta;
                     K = kernel_weight(q);                   // max(1 - q, 0), NaN -> 0
@@ -200,19 +275,11 @@ __global__ __launch_bounds__(256) void k2_scan_generic(ScanArgs a)
                 rbar[c] = (q > 0.0f) ? q : 0.0f;
             }
         }
-        float sc = (card != 0.0f) ? (B / card) : 0.0f;
+        float sc = (card != 0.0f) ? (B / card) : 0.0f;   // core.hpp:620
         sc = (sc > 0.0f) ? sc : 0.0f;
-        sum += (double)sc;
-        if (sc > best) {   // strict: first maximum wins (cv::minMaxLoc)
-            best = sc;
-            best_d = d;
-            best_D = Dd;
-#pragma unroll
-            for (int c = 0; c < C; c++)
-                best_rbar[c] = rbar[c];
-        }
+        best.offer(sc, d, Dd, rbar);
     }
-    scan_epilogue<C>(a, v, u, active, best, best_d, best_D, best_rbar, sum);
+    scan_epilogue<C>(a, v, u, active, best);
 }
 
 // ---------------------------------------------------------------------------
@@ -227,12 +294,12 @@ __global__ __launch_bounds__(256) void k2_scan_generic(ScanArgs a)
 // P = 1e30 * 0 = 0 exactly, so they add +0 to both sums -- bit-identical to the
 // reference's "NaN -> K = 0, R0 = 0" without a second register per sample.
 // Needs R == max(R, 0), hence the non-negative-volume precondition checked by
-// the host (rslf_abi.hip: pick_scan_kernel).
+// the host (rslf_abi.hip: rslf_depth_epi_pile).
 // ---------------------------------------------------------------------------
 constexpr int kGatherBatch = 8;   // samples whose loads are in flight together
 
 template <int SPAD, bool BORDER>
-__device__ __forceinline__ void scan_reg_body(const ScanArgs& a, int v, int u, bool active)
+__device__ __forceinline__ void scan_reg_body(const ScanArgs& a, int v, int u, int d0, int d1, Best<1>& best)
 {
     const VolView& vol = a.vol;
     const float* epi = vol.row(v, 0, 0);
@@ -248,14 +315,11 @@ __device__ __forceinline__ void scan_reg_body(const ScanArgs& a, int v, int u, b
     const float k1 = a.k.k1;
     const float slope = a.k.slope;
     const int stride_s = (int)vol.stride_s;
-
-    float best = -1.0f, best_D = 0.0f;
-    int best_d = 0;
-    float best_rbar[1] = {0.0f};
-    double sum = 0.0;
+    // core.hpp:577: rbar starts from R[s_hat] = E[s_hat][u] for every hypothesis
+    const float centre = epi[(long long)a.s_hat * vol.stride_s + u];
 
 #pragma unroll 1
-    for (int d = 0; d < a.dim_d; d++) {
+    for (int d = d0; d < d1; d++) {
         const float Dd = hypothesis(dmin, range, denom, d);
         float R[SPAD];
         int card = BORDER ? 0 : S;
@@ -327,38 +391,30 @@ __device__ __forceinline__ void scan_reg_body(const ScanArgs& a, int v, int u, b
             }
         }
 
-        // core.hpp:577: rbar <- R[s_hat] = E[s_hat][u]
-        float rbar = epi[(long long)a.s_hat * vol.stride_s + u];
+        float rbar[1] = {centre};
         float B = 0.0f;
 #pragma unroll 1
-        for (int it = 0; it < a.k.n_iter; it++) {
+        for (int it = 0; it < a.k.n_iter; it++) {   // core.hpp:584-610
             float A = 0.0f;
             B = 0.0f;
 #pragma unroll
             for (int s = 0; s < SPAD; s++) {
-                const float delta = R[s] - rbar;
-                const float tq = k1 * delta;
+                const float delta = R[s] - rbar[0];   // core.hpp:591
+                const float tq = k1 * delta;          // kernels.cpp:21
                 const float q = tq * delta;
-                const float K = kernel_weight(q);
-                const float pr = R[s] * K;
-                A = A + pr;
-                B = B + K;
+                const float K = kernel_weight(q);     // kernels.cpp:23-25
+                const float pr = R[s] * K;            // core.cpp:28
+                A = A + pr;                           // core.hpp:602
+                B = B + K;                            // core.hpp:603
             }
-            const float qd = (B != 0.0f) ? (A / B) : 0.0f;
-            rbar = (qd > 0.0f) ? qd : 0.0f;
+            const float qd = (B != 0.0f) ? (A / B) : 0.0f;   // core.cpp:42, OpenCV 3.x: /0 -> 0
+            rbar[0] = (qd > 0.0f) ? qd : 0.0f;               // core.hpp:609
         }
         const float cardf = (float)card;
-        float sc = (card != 0) ? (B / cardf) : 0.0f;
-        sc = (sc > 0.0f) ? sc : 0.0f;
-        sum += (double)sc;
-        if (sc > best) {
-            best = sc;
-            best_d = d;
-            best_D = Dd;
-            best_rbar[0] = rbar;
-        }
+        float sc = (card != 0) ? (B / cardf) : 0.0f;   // core.hpp:616-620: the last pass's sum of K
+        sc = (sc > 0.0f) ? sc : 0.0f;                  // core.hpp:622
+        best.offer(sc, d, Dd, rbar);
     }
-    scan_epilogue<1>(a, v, u, active, best, best_d, best_D, best_rbar, sum);
 }
 
 // Waves per SIMD the register budget allows: SPAD sample slots + ~64 working registers
@@ -372,13 +428,15 @@ constexpr int scan_reg_waves(int spad)
 }
 
 template <int SPAD>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(scan_reg_waves(SPAD), scan_reg_waves(SPAD))))
+__global__ __launch_bounds__(64 * kScanWaves) __attribute__((amdgpu_waves_per_eu(scan_reg_waves(SPAD), scan_reg_waves(SPAD))))
 void k2_scan_reg(ScanArgs a)
 {
     int v, u;
     bool active;
     if (!scan_tile(a, v, u, active))
         return;
+    int d0, d1;
+    scan_chunk(a, d0, d1);
     // A wave whose every sample line stays inside [0, U-1] for every hypothesis
     // needs no validity test: |x - u| <= max|s_hat - s| * max|d| * slope.
     bool interior = false;
@@ -389,10 +447,13 @@ void k2_scan_reg(ScanArgs a)
         const float uf = (float)u;
         interior = __all((uf - reach >= 0.0f) && (uf + reach <= (float)(a.vol.U - 1)));
     }
+    Best<1> best;
+    best.init();
     if (interior)
-        scan_reg_body<SPAD, false>(a, v, u, active);
+        scan_reg_body<SPAD, false>(a, v, u, d0, d1, best);
     else
-        scan_reg_body<SPAD, true>(a, v, u, active);
+        scan_reg_body<SPAD, true>(a, v, u, d0, d1, best);
+    scan_epilogue<1>(a, v, u, active, best);
 }
 
 }  // namespace rslf

@@ -58,6 +58,7 @@ struct rslf_ctx {
     size_t staging_cap = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool ev_valid = false;
+    int last_spad = 0;   // register-scan slot count of the last K2 launch, 0 = generic
 };
 
 struct rslf_volume {
@@ -584,7 +585,7 @@ static int launch_scan_reg(int spad, const ScanArgs& a, dim3 grid, hipStream_t s
     switch (spad) {
 #define RSLF_CASE(N)                                                                   \
     case N:                                                                            \
-        hipLaunchKernelGGL(k2_scan_reg<N>, grid, dim3(256), 0, stream, a);             \
+        hipLaunchKernelGGL(k2_scan_reg<N>, grid, dim3(64 * kScanWaves), 0, stream, a);             \
         return RSLF_OK;
         RSLF_SPAD_LIST(RSLF_CASE)
 #undef RSLF_CASE
@@ -652,7 +653,6 @@ extern "C" int rslf_depth_epi_pile(rslf_ctx* ctx, const rslf_volume* vol, const 
     a.k = make_scan_consts(p);
     a.Ce = d_Ce_vu;
     a.Ce_mask = d_Ce_mask_vu;
-    a.scan_mask = d_mask_vu;
     a.Cd = d_Cd_vu;
     a.depth = d_depth_vu;
     a.rbar = d_rbar_vu;
@@ -660,7 +660,9 @@ extern "C" int rslf_depth_epi_pile(rslf_ctx* ctx, const rslf_volume* vol, const 
     a.score = d_score_vu;
     a.tiles_per_row = (vol->U + 63) / 64;
     const long long tiles = (long long)vol->V * a.tiles_per_row;
-    a.logical_blocks = (int)((tiles + 3) / 4);
+    if (tiles > (long long)1 << 30)
+        return fail(RSLF_ERR_UNSUPPORTED, "V * ceil(U/64) = %lld tiles exceeds the grid limit", tiles);
+    a.logical_blocks = (int)tiles;   // one workgroup per tile, its waves split the hypotheses
     a.per_xcd = (a.logical_blocks + 7) / 8;
     const dim3 grid((unsigned)(a.per_xcd * 8));
 
@@ -673,15 +675,16 @@ extern "C" int rslf_depth_epi_pile(rslf_ctx* ctx, const rslf_volume* vol, const 
     if (force && strcmp(force, "generic") == 0)
         spad = 0;
 
+    ctx->last_spad = spad;
     HIP_TRY(hipEventRecord(ctx->ev0, st));
     if (spad) {
         rc = launch_scan_reg(spad, a, grid, st);
         if (rc)
             return rc;
     } else if (vol->C == 1) {
-        hipLaunchKernelGGL(k2_scan_generic<1>, grid, dim3(256), 0, st, a);
+        hipLaunchKernelGGL(k2_scan_generic<1>, grid, dim3(64 * kScanWaves), 0, st, a);
     } else {
-        hipLaunchKernelGGL(k2_scan_generic<3>, grid, dim3(256), 0, st, a);
+        hipLaunchKernelGGL(k2_scan_generic<3>, grid, dim3(64 * kScanWaves), 0, st, a);
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ctx->ev1, st));
@@ -789,9 +792,8 @@ extern "C" int rslf_depth1d_pile_run_host(rslf_ctx* ctx, const rslf_volume* vol,
         if (hipMemcpy(&tot, ctx->total, sizeof(tot), hipMemcpyDeviceToHost) == hipSuccess) {
             stats->pixels_scanned = (int64_t)tot;
             stats->units = (int64_t)tot * dim_d;
-            const int spad = (vol->C == 1 && vol->min_value >= 0.0f && vol->max_value <= 1.0e6f) ? pick_spad(vol->S) : 0;
-            stats->scan_kernel = spad ? RSLF_SCAN_REG_1CH : RSLF_SCAN_GENERIC;
-            stats->s_pad = spad;
+            stats->scan_kernel = ctx->last_spad ? RSLF_SCAN_REG_1CH : RSLF_SCAN_GENERIC;
+            stats->s_pad = ctx->last_spad;
         }
     }
     (void)hipFree(blk);
