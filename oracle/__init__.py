@@ -75,6 +75,7 @@ def lib():
             _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int,
             C.POINTER(OracleParams), _f32p, _u8p, _f32p, _f32p, _f32p, _i32p, _f32p, _f32p]
         L.oracle_num_threads.restype = C.c_int
+        L.oracle_set_num_threads.argtypes = [C.c_int]
         _lib = L
     return _lib
 
@@ -203,3 +204,28 @@ def depth1d_pile_run(vol, dmin, dmax, dim_d, s_hat=-1, params=None) -> PileResul
 
 def num_threads() -> int:
     return int(lib().oracle_num_threads())
+
+
+def usable_cpus() -> int:
+    """CPUs this process may actually use: the affinity mask capped by the cgroup quota
+    (a GPU box gives a container a share of a much larger host)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, q // per))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n)
+
+
+def set_num_threads(n: int) -> None:
+    lib().oracle_set_num_threads(int(n))

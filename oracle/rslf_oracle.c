@@ -37,6 +37,16 @@ void oracle_default_params(oracle_params* p)
     p->kernel_bandwidth = (float)0.2;
 }
 
+void oracle_set_num_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0)
+        omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 int oracle_num_threads(void)
 {
 #ifdef _OPENMP
@@ -155,8 +165,8 @@ void oracle_edge_confidence_pile(const float* vol, int V, int S, int U, int C,
 /* ---- core.hpp:480-661 ------------------------------------------------- */
 
 typedef struct scan_scratch {
-    float* R;    /* [C][S][D] radiances, NaN where out of range */
-    float* R0;   /* [C][S][D] NaN -> 0 (core.hpp:580) */
+    float* R;    /* [C][S][DBLOCK] radiances of the current hypothesis block, NaN where out of range */
+    float* R0;   /* [C][S][DBLOCK] NaN -> 0 (core.hpp:580) */
     float* Kmat; /* [S][D] last kernel values */
     float* Dv;   /* [D] hypothesis values */
     float* card; /* [D] */
@@ -170,8 +180,9 @@ typedef struct scan_scratch {
 static int scratch_alloc(scan_scratch* w, int S, int D, int C)
 {
     size_t sd = (size_t)S * D;
-    w->R = (float*)malloc(sizeof(float) * sd * C);
-    w->R0 = (float*)malloc(sizeof(float) * sd * C);
+    size_t sb = (size_t)S * 32; /* ORACLE_DBLOCK */
+    w->R = (float*)malloc(sizeof(float) * sb * C);
+    w->R0 = (float*)malloc(sizeof(float) * sb * C);
     w->Kmat = (float*)malloc(sizeof(float) * sd);
     w->Dv = (float*)malloc(sizeof(float) * D);
     w->card = (float*)malloc(sizeof(float) * D);
@@ -225,13 +236,16 @@ static inline void kernel_row(const float* const* Rrow, const float* const* rbar
     }
 }
 
+/* Hypotheses are independent of each other, so they are scored in blocks of
+ * ORACLE_DBLOCK to keep the S x block temporaries cache resident (the reference
+ * streams full S x D matrices, core.hpp:584-610; the values are the same). */
+#define ORACLE_DBLOCK 32
+
 static void scan_pixel(const float* epi, int S, int U, int C, int u,
                        float dmin, float dmax, int D, int s_hat,
                        const oracle_params* p, scan_scratch* w,
                        float inv_h2, float k1, int n_iter)
 {
-    const size_t SD = (size_t)S * D;
-
     /* core.hpp:545-548: D[d] = dmin + d * (dmax - dmin) / (dim_d - 1) */
     const float range = dmax - dmin;
     const float denom = (float)(D - 1);
@@ -240,100 +254,146 @@ static void scan_pixel(const float* epi, int S, int U, int C, int u,
         const float quo = num / denom;
         w->Dv[d] = dmin + quo;
     }
-
-    memset(w->card, 0, sizeof(float) * D);
-
-    /* core.hpp:550-552 + interp.hpp:155-193 */
     const float uf = (float)u;
-    const float Um1 = (float)(U - 1);
-    (void)Um1;
-    for (int s = 0; s < S; s++) {
-        const float Ss = (float)(s_hat - s); /* core.hpp:542 */
-        const float* erow = epi + (size_t)s * U * C;
-        for (int d = 0; d < D; d++) {
-            float xi = Ss * w->Dv[d];       /* I = S * D (gemm, K=1)    */
-            xi = xi * p->slope_factor;      /* I *= par_slope_factor    */
-            xi = xi + uf;                   /* I += u                   */
-            const int i0 = (int)floorf(xi); /* interp.hpp:179           */
-            const int i1 = (int)ceilf(xi);  /* interp.hpp:180           */
-            const float t = xi - (float)i0; /* interp.hpp:181           */
-            if (!(i0 < 0 || i1 > U - 1)) {  /* interp.hpp:182           */
-                const float omt = 1.0f - t;
-                for (int c = 0; c < C; c++) {
-                    const float a = omt * erow[(size_t)i0 * C + c];
-                    const float b = t * erow[(size_t)i1 * C + c];
-                    const float r = a + b;  /* interp.hpp:184           */
-                    w->R[c * SD + (size_t)s * D + d] = r;
-                    /* cv::max(R, 0) (core.hpp:580) */
-                    w->R0[c * SD + (size_t)s * D + d] = (r > 0.0f) ? r : 0.0f;
-                }
-                w->card[d] = w->card[d] + 1.0f;
-            } else {
-                for (int c = 0; c < C; c++) {
-                    w->R[c * SD + (size_t)s * D + d] = NAN; /* interp.hpp:189 */
-                    w->R0[c * SD + (size_t)s * D + d] = 0.0f;
-                }
-            }
-        }
-    }
 
-    /* core.hpp:577: r_bar <- R[s_hat,:] */
-    for (int c = 0; c < C; c++)
-        memcpy(w->rbar + (size_t)c * D, w->R + c * SD + (size_t)s_hat * D, sizeof(float) * D);
+    for (int c0 = 0; c0 < D; c0 += ORACLE_DBLOCK) {
+        const int nb = (D - c0 < ORACLE_DBLOCK) ? (D - c0) : ORACLE_DBLOCK;
+        const size_t SD = (size_t)S * ORACLE_DBLOCK;   /* channel stride inside the block */
+        const float* Dv = w->Dv + c0;
+        float* card = w->card + c0;
+        memset(card, 0, sizeof(float) * nb);
 
-    const float* rbarp[3];
-    for (int c = 0; c < C; c++)
-        rbarp[c] = w->rbar + (size_t)c * D;
-
-    /* core.hpp:584-610 */
-    for (int it = 0; it < n_iter; it++) {
+        /* core.hpp:550-552 + interp.hpp:155-193 */
         for (int s = 0; s < S; s++) {
-            const float* Rrow[3];
-            for (int c = 0; c < C; c++)
-                Rrow[c] = w->R + c * SD + (size_t)s * D;
-            float* K = w->Kmat + (size_t)s * D;
-            kernel_row(Rrow, rbarp, D, C, inv_h2, k1, K);
-            /* r*K (core.cpp:25-37) and the column sums (core.hpp:602-603):
-             * cv::reduce starts from row 0 and adds rows in order */
-            if (s == 0) {
-                for (int c = 0; c < C; c++) {
-                    const float* r0 = w->R0 + c * SD;
-                    float* A = w->A + (size_t)c * D;
-                    for (int d = 0; d < D; d++)
-                        A[d] = r0[d] * K[d];
+            const float Ss = (float)(s_hat - s); /* core.hpp:542 */
+            const float* erow = epi + (size_t)s * U * C;
+            if (C == 1) {
+                /* branch-free so the compiler can vectorise it (gathers); same values */
+                float* restrict Rr = w->R + (size_t)s * ORACLE_DBLOCK;
+                float* restrict R0r = w->R0 + (size_t)s * ORACLE_DBLOCK;
+                const int Um1 = U - 1;
+                const float slope = p->slope_factor;
+                for (int d = 0; d < nb; d++) {
+                    float xi = Ss * Dv[d];          /* I = S * D (gemm, K=1)    */
+                    xi = xi * slope;                /* I *= par_slope_factor    */
+                    xi = xi + uf;                   /* I += u                   */
+                    const float fl = floorf(xi);
+                    const float ce = ceilf(xi);
+                    const int i0 = (int)fl;         /* interp.hpp:179           */
+                    const int i1 = (int)ce;         /* interp.hpp:180           */
+                    const float t = xi - (float)i0; /* interp.hpp:181           */
+                    const int valid = (i0 >= 0) & (i1 <= Um1); /* interp.hpp:182 */
+                    const int j0 = i0 < 0 ? 0 : (i0 > Um1 ? Um1 : i0);
+                    const int j1 = i1 < 0 ? 0 : (i1 > Um1 ? Um1 : i1);
+                    const float omt = 1.0f - t;
+                    const float a = omt * erow[j0];
+                    const float b = t * erow[j1];
+                    const float r = a + b;          /* interp.hpp:184           */
+                    Rr[d] = valid ? r : NAN;        /* interp.hpp:189           */
+                    R0r[d] = (valid && r > 0.0f) ? r : 0.0f; /* core.hpp:580    */
+                    card[d] = card[d] + (valid ? 1.0f : 0.0f);
                 }
-                for (int d = 0; d < D; d++)
-                    w->B[d] = K[d];
-            } else {
-                for (int c = 0; c < C; c++) {
-                    const float* r0 = w->R0 + c * SD + (size_t)s * D;
-                    float* A = w->A + (size_t)c * D;
-                    for (int d = 0; d < D; d++) {
-                        const float pr = r0[d] * K[d];
-                        A[d] = A[d] + pr;
+                continue;
+            }
+            for (int d = 0; d < nb; d++) {
+                float xi = Ss * Dv[d];          /* I = S * D (gemm, K=1)    */
+                xi = xi * p->slope_factor;      /* I *= par_slope_factor    */
+                xi = xi + uf;                   /* I += u                   */
+                const int i0 = (int)floorf(xi); /* interp.hpp:179           */
+                const int i1 = (int)ceilf(xi);  /* interp.hpp:180           */
+                const float t = xi - (float)i0; /* interp.hpp:181           */
+                if (!(i0 < 0 || i1 > U - 1)) {  /* interp.hpp:182           */
+                    const float omt = 1.0f - t;
+                    for (int c = 0; c < C; c++) {
+                        const float a = omt * erow[(size_t)i0 * C + c];
+                        const float b = t * erow[(size_t)i1 * C + c];
+                        const float r = a + b;  /* interp.hpp:184           */
+                        w->R[c * SD + (size_t)s * ORACLE_DBLOCK + d] = r;
+                        /* cv::max(R, 0) (core.hpp:580) */
+                        w->R0[c * SD + (size_t)s * ORACLE_DBLOCK + d] = (r > 0.0f) ? r : 0.0f;
+                    }
+                    card[d] = card[d] + 1.0f;
+                } else {
+                    for (int c = 0; c < C; c++) {
+                        w->R[c * SD + (size_t)s * ORACLE_DBLOCK + d] = NAN; /* interp.hpp:189 */
+                        w->R0[c * SD + (size_t)s * ORACLE_DBLOCK + d] = 0.0f;
                     }
                 }
-                for (int d = 0; d < D; d++)
-                    w->B[d] = w->B[d] + K[d];
             }
         }
-        /* _divide_multi_channel (core.cpp:39-51): OpenCV 3.x, divisor 0 -> 0;
-         * then cv::max(r_bar, 0) (core.hpp:609) */
-        for (int c = 0; c < C; c++) {
-            float* rb = w->rbar + (size_t)c * D;
-            const float* A = w->A + (size_t)c * D;
-            for (int d = 0; d < D; d++) {
-                float q = (w->B[d] != 0.0f) ? (A[d] / w->B[d]) : 0.0f;
-                rb[d] = (q > 0.0f) ? q : 0.0f;
-            }
-        }
-    }
 
-    /* core.hpp:616-622: K is re-evaluated on the last r - r_bar, i.e. it
-     * equals the last iteration's K, and its column sum the last B. */
-    for (int d = 0; d < D; d++) {
-        float sc = (w->card[d] != 0.0f) ? (w->B[d] / w->card[d]) : 0.0f;
-        w->score[d] = (sc > 0.0f) ? sc : 0.0f;
+        /* core.hpp:577: r_bar <- R[s_hat,:] */
+        float* rbarp_w[3];
+        const float* rbarp[3];
+        float* Ap[3];
+        for (int c = 0; c < C; c++) {
+            rbarp_w[c] = w->rbar + (size_t)c * D + c0;
+            rbarp[c] = rbarp_w[c];
+            Ap[c] = w->A + (size_t)c * D + c0;
+            memcpy(rbarp_w[c], w->R + c * SD + (size_t)s_hat * ORACLE_DBLOCK, sizeof(float) * nb);
+        }
+        float* B = w->B + c0;
+
+        /* core.hpp:584-610 */
+        for (int it = 0; it < n_iter; it++) {
+            /* r*K (core.cpp:25-37) and the column sums (core.hpp:602-603): cv::reduce
+             * starts from row 0 and adds the rows in order.  Starting from +0 instead is
+             * the same value: every term is >= +0, and 0 + x == x. */
+            for (int c = 0; c < C; c++)
+                memset(Ap[c], 0, sizeof(float) * nb);
+            memset(B, 0, sizeof(float) * nb);
+            for (int s = 0; s < S; s++) {
+                float* restrict K = w->Kmat + (size_t)s * D + c0;
+                if (C == 1) {
+                    /* fused single pass (the hot loop of the CPU baseline) */
+                    const float* restrict r = w->R + (size_t)s * ORACLE_DBLOCK;
+                    const float* restrict r0 = w->R0 + (size_t)s * ORACLE_DBLOCK;
+                    const float* restrict rb = rbarp[0];
+                    float* restrict A0 = Ap[0];
+                    float* restrict Bb = B;
+                    for (int d = 0; d < nb; d++) {
+                        const float delta = r[d] - rb[d];          /* core.hpp:591 */
+                        const float t = k1 * delta;                /* kernels.cpp:21 */
+                        const float q = t * delta;
+                        const float o = 1.0f - q;                  /* kernels.cpp:23 */
+                        const float k = (o > 0.0f) ? o : 0.0f;     /* kernels.cpp:25, NaN -> 0 */
+                        K[d] = k;
+                        const float pr = r0[d] * k;                /* core.cpp:28 */
+                        A0[d] = A0[d] + pr;                        /* core.hpp:602 */
+                        Bb[d] = Bb[d] + k;                         /* core.hpp:603 */
+                    }
+                } else {
+                    const float* Rrow[3];
+                    for (int c = 0; c < C; c++)
+                        Rrow[c] = w->R + c * SD + (size_t)s * ORACLE_DBLOCK;
+                    kernel_row(Rrow, rbarp, nb, C, inv_h2, k1, K);
+                    for (int c = 0; c < C; c++) {
+                        const float* r0 = w->R0 + c * SD + (size_t)s * ORACLE_DBLOCK;
+                        for (int d = 0; d < nb; d++) {
+                            const float pr = r0[d] * K[d];
+                            Ap[c][d] = Ap[c][d] + pr;
+                        }
+                    }
+                    for (int d = 0; d < nb; d++)
+                        B[d] = B[d] + K[d];
+                }
+            }
+            /* _divide_multi_channel (core.cpp:39-51): OpenCV 3.x, divisor 0 -> 0;
+             * then cv::max(r_bar, 0) (core.hpp:609) */
+            for (int c = 0; c < C; c++) {
+                for (int d = 0; d < nb; d++) {
+                    float q = (B[d] != 0.0f) ? (Ap[c][d] / B[d]) : 0.0f;
+                    rbarp_w[c][d] = (q > 0.0f) ? q : 0.0f;
+                }
+            }
+        }
+
+        /* core.hpp:616-622: K is re-evaluated on the last r - r_bar, i.e. it
+         * equals the last iteration's K, and its column sum the last B. */
+        for (int d = 0; d < nb; d++) {
+            float sc = (card[d] != 0.0f) ? (B[d] / card[d]) : 0.0f;
+            w->score[c0 + d] = (sc > 0.0f) ? sc : 0.0f;
+        }
     }
 }
 

@@ -120,6 +120,7 @@ void oracle_depth1d_pile_run(const float* vol, int V, int S, int U, int C,
                              float* depth_raw_vu);
 
 int oracle_num_threads(void);
+void oracle_set_num_threads(int n);
 
 #ifdef __cplusplus
 }

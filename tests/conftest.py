@@ -16,4 +16,5 @@ def pytest_configure(config):
 def oracle_mod():
     import oracle
     oracle.build()
+    oracle.set_num_threads(min(oracle.usable_cpus(), 16))   # the GPU box shares a 256-CPU host
     return oracle

@@ -1,0 +1,95 @@
+#!/usr/bin/env python3
+"""Turn gpurun_out/prof/ (tools/collect_profiles.sh) into the committed summaries under profiles/.
+
+    python tools/summarize_profiles.py r01 c3_n1
+
+Writes profiles/<round>_<tag>_kernel_stats.csv (rocprofv3 --stats, ours kernels only),
+profiles/<round>_<tag>_pmc.json (per-launch counter means for the rslf kernels) and updates
+profiles/k2_traffic.json, which bench.py reads for roofline.traffic.
+
+HBM bytes follow MI355X_MICROARCH.md "HBM": FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950
+FETCH_SIZE reports half the bytes of a coalesced streaming read, so the read side is
+calibrated on k0_pack of the same run, whose read byte count is known exactly
+(V*S*U*C*4 of dense input): factor = known / reported, applied to the scan kernel's FETCH_SIZE.
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PROF = os.path.join(ROOT, "gpurun_out", "prof")
+
+
+def pmc_means(sub):
+    files = sorted(glob.glob(os.path.join(PROF, sub, "*", "*counter_collection.csv")))
+    if not files:
+        return {}
+    rows = list(csv.DictReader(open(files[-1])))
+    agg = collections.defaultdict(lambda: collections.defaultdict(float))
+    disp = collections.defaultdict(set)
+    for r in rows:
+        k = r["Kernel_Name"]
+        if "rslf::" not in k:
+            continue
+        k = k.split("(")[0].replace("void ", "")
+        agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        disp[k].add(r["Dispatch_Id"])
+    return {k: dict(launches=len(disp[k]), **{c: v / len(disp[k]) for c, v in cs.items()}) for k, cs in agg.items()}
+
+
+def main():
+    rnd, tag = sys.argv[1], sys.argv[2]
+    out = os.path.join(ROOT, "profiles")
+    os.makedirs(out, exist_ok=True)
+    # kernel stats
+    st = sorted(glob.glob(os.path.join(PROF, "stats", "*", "*kernel_stats.csv")))
+    if st:
+        rows = list(csv.reader(open(st[-1])))
+        keep = [rows[0]] + [r for r in rows[1:] if "rslf::" in r[0]]
+        with open(os.path.join(out, "%s_%s_kernel_stats.csv" % (rnd, tag)), "w", newline="") as f:
+            csv.writer(f, quoting=csv.QUOTE_ALL).writerows(keep)
+    summary = {}
+    for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_l2"):
+        for k, v in pmc_means(sub).items():
+            summary.setdefault(k, {}).update(v)
+    bench = {}
+    bj = os.path.join(PROF, "bench_stats.json")
+    if os.path.exists(bj):
+        try:
+            bench = json.loads(open(bj).read().strip().splitlines()[-1])
+        except Exception:  # noqa: BLE001
+            bench = {}
+    # HBM traffic of the scan kernel, read side calibrated on k0_pack
+    k2 = next((k for k in summary if "k2_scan" in k), None)
+    k0 = next((k for k in summary if "k0_pack" in k), None)
+    traffic = None
+    if k2 and "FETCH_SIZE" in summary[k2]:
+        factor, known = 2.0, None
+        wl = bench.get("config", {}).get("workload", "")
+        if k0 and "FETCH_SIZE" in summary[k0] and bench:
+            import re
+            m = re.search(r"(\d+)x(\d+) px x (\d+) views x (\d+) ch", wl)
+            if m:
+                U, V, S, C = map(int, m.groups())
+                known = V * S * U * C * 4
+                factor = known / (summary[k0]["FETCH_SIZE"] * 1024.0)
+        rd = summary[k2]["FETCH_SIZE"] * 1024.0 * factor
+        wr = summary[k2].get("WRITE_SIZE", 0.0) * 1024.0
+        traffic = dict(hbm_bytes_per_launch=rd + wr, read_bytes=rd, write_bytes=wr,
+                       fetch_size_kib=summary[k2]["FETCH_SIZE"], write_size_kib=summary[k2].get("WRITE_SIZE"),
+                       read_calibration_factor=factor, calibrated_on="k0_pack known read bytes %s" % known,
+                       kernel=k2, workload=wl)
+        tpath = os.path.join(out, "k2_traffic.json")
+        tj = json.load(open(tpath)) if os.path.exists(tpath) else {}
+        tj[tag] = traffic
+        json.dump(tj, open(tpath, "w"), indent=1)
+    json.dump(dict(bench_line_under_rocprof=bench, per_launch_counter_means=summary, k2_traffic=traffic),
+              open(os.path.join(out, "%s_%s_pmc.json" % (rnd, tag)), "w"), indent=1)
+    print(json.dumps(dict(k2=summary.get(k2), traffic=traffic), indent=1))
+
+
+if __name__ == "__main__":
+    main()
