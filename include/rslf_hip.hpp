@@ -1,0 +1,257 @@
+// rslf_hip.hpp -- C++11 host side of the MI355X EPI depth scan.
+//
+// Keeps the constructor / run() shape of rslf::Depth1DComputer_pile<DataType>
+// (RSLightFields/include/rslf_depth_computation.hpp:93-143, :425-565) and of
+// rslf::Depth1DParameters<DataType> (rslf_depth_computation_core.hpp:66-142) so
+// the class drops into the reference's demos (tests/test_depth_computation_pile.cpp:49-51)
+// in place of the OpenMP path.  Everything below the class goes through the
+// C-ABI of rslf_hip.h; nothing here computes.
+//
+// OpenCV is optional: when <opencv2/core/core.hpp> is on the include path
+// (the reference's own build, CMakeLists.txt:29) the cv::Mat constructor and
+// getters are compiled in; otherwise the same class works on plain pointers.
+// Header-only, C++11, exceptions carry the C-ABI's error text.
+#ifndef RSLF_HIP_HPP
+#define RSLF_HIP_HPP
+
+#include <cmath>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "rslf_hip.h"
+
+#if defined(__has_include)
+#if __has_include(<opencv2/core/core.hpp>)
+#include <opencv2/core/core.hpp>
+#define RSLFX_HAVE_OPENCV 1
+#endif
+#endif
+
+namespace rslfx {
+
+struct Error : std::runtime_error {
+    int status;
+    Error(int st, const std::string& where)
+        : std::runtime_error(where + ": " + rslf_status_string(st) + ": " + rslf_last_error()), status(st) {}
+};
+
+inline void check(int st, const char* where)
+{
+    if (st != RSLF_OK)
+        throw Error(st, where);
+}
+
+// rslf::Depth1DParameters<T>: same member names (par_*), same defaults.
+struct Depth1DParameters {
+    float par_edge_score_threshold;
+    float par_line_score_threshold;
+    float par_disp_score_threshold;
+    float par_raw_score_threshold;
+    float par_mean_shift_max_iter;
+    int par_edge_confidence_filter_size;
+    int par_edge_confidence_opening_type;
+    int par_edge_confidence_opening_size;
+    int par_median_filter_size;
+    float par_median_filter_epsilon;
+    float par_propagation_epsilon;
+    float par_slope_factor;
+    bool par_cut_shadows;
+    float par_shadow_level;
+    float par_kernel_bandwidth;   // BandwidthKernel(_BANDWIDTH_KERNEL_PARAMETER), core.hpp:78
+
+    Depth1DParameters()
+    {
+        rslf_params p;
+        rslf_default_params(&p);
+        par_edge_score_threshold = p.edge_score_threshold;
+        par_line_score_threshold = p.line_score_threshold;
+        par_disp_score_threshold = p.disp_score_threshold;
+        par_raw_score_threshold = p.raw_score_threshold;
+        par_mean_shift_max_iter = p.mean_shift_max_iter;
+        par_edge_confidence_filter_size = p.edge_confidence_filter_size;
+        par_edge_confidence_opening_type = p.edge_confidence_opening_type;
+        par_edge_confidence_opening_size = p.edge_confidence_opening_size;
+        par_median_filter_size = p.median_filter_size;
+        par_median_filter_epsilon = p.median_filter_epsilon;
+        par_propagation_epsilon = p.propagation_epsilon;
+        par_slope_factor = p.slope_factor;
+        par_cut_shadows = p.cut_shadows != 0;
+        par_shadow_level = p.shadow_level;
+        par_kernel_bandwidth = p.kernel_bandwidth;
+    }
+
+    static Depth1DParameters& get_default()
+    {
+        static Depth1DParameters s_default;   // core.hpp:138-142
+        return s_default;
+    }
+
+    rslf_params to_c() const
+    {
+        rslf_params p;
+        p.edge_score_threshold = par_edge_score_threshold;
+        p.line_score_threshold = par_line_score_threshold;
+        p.disp_score_threshold = par_disp_score_threshold;
+        p.raw_score_threshold = par_raw_score_threshold;
+        p.mean_shift_max_iter = par_mean_shift_max_iter;
+        p.edge_confidence_filter_size = par_edge_confidence_filter_size;
+        p.edge_confidence_opening_type = par_edge_confidence_opening_type;
+        p.edge_confidence_opening_size = par_edge_confidence_opening_size;
+        p.median_filter_size = par_median_filter_size;
+        p.median_filter_epsilon = par_median_filter_epsilon;
+        p.propagation_epsilon = par_propagation_epsilon;
+        p.slope_factor = par_slope_factor;
+        p.cut_shadows = par_cut_shadows ? 1 : 0;
+        p.shadow_level = par_shadow_level;
+        p.kernel_bandwidth = par_kernel_bandwidth;
+        return p;
+    }
+};
+
+// RAII handles
+class Context {
+public:
+    explicit Context(int device = 0) : h_(nullptr) { check(rslf_ctx_create(device, &h_), "rslf_ctx_create"); }
+    ~Context() { rslf_ctx_destroy(h_); }
+    Context(const Context&) = delete;
+    Context& operator=(const Context&) = delete;
+    rslf_ctx* get() const { return h_; }
+    void set_stream(void* hip_stream) { check(rslf_ctx_set_stream(h_, hip_stream), "rslf_ctx_set_stream"); }
+    void synchronize() { check(rslf_ctx_synchronize(h_), "rslf_ctx_synchronize"); }
+    float last_scan_kernel_ms()
+    {
+        float ms = 0;
+        check(rslf_last_scan_kernel_ms(h_, &ms), "rslf_last_scan_kernel_ms");
+        return ms;
+    }
+
+private:
+    rslf_ctx* h_;
+};
+
+// rslf::Depth1DComputer_pile<DataType>.  DataType is float (1 channel) or a
+// 3-float pixel (cv::Vec3f in the reference, dc.hpp:149-154): only its channel
+// count matters here.
+template <int CHANNELS>
+class Depth1DComputer_pile {
+public:
+    // The reference's constructor (dc.hpp:97-106) on raw pointers: epis[v] points
+    // at an S x U image of CHANNELS interleaved values, rows row_stride_bytes
+    // apart (cv::Mat::data / cv::Mat::step; 0 = dense).  is_u8 selects the
+    // uchar branch of dc.hpp:468-475.
+    Depth1DComputer_pile(Context& ctx, const void* const* epis, bool is_u8, int dim_v, int dim_s, int dim_u,
+                         size_t row_stride_bytes, float dmin, float dmax, int dim_d, int s_hat = -1,
+                         float epi_scale_factor = -1, const Depth1DParameters& parameters = Depth1DParameters::get_default())
+        : ctx_(ctx), vol_(nullptr), m_parameters(parameters)
+    {
+        init(epis, is_u8, dim_v, dim_s, dim_u, row_stride_bytes, dmin, dmax, dim_d, s_hat, epi_scale_factor);
+    }
+
+#ifdef RSLFX_HAVE_OPENCV
+    // Exactly the reference's signature: Vec<Mat> in (dc.hpp:97-106).
+    Depth1DComputer_pile(Context& ctx, const std::vector<cv::Mat>& epis, float dmin, float dmax, int dim_d, int s_hat = -1,
+                         float epi_scale_factor = -1, const Depth1DParameters& parameters = Depth1DParameters::get_default())
+        : ctx_(ctx), vol_(nullptr), m_parameters(parameters)
+    {
+        if (epis.empty())
+            throw std::invalid_argument("Depth1DComputer_pile: no EPIs");
+        if (epis[0].channels() != CHANNELS)
+            throw std::invalid_argument("Depth1DComputer_pile: channel count does not match the instantiation");
+        std::vector<const void*> ptrs(epis.size());
+        for (size_t v = 0; v < epis.size(); v++) {
+            if (epis[v].rows != epis[0].rows || epis[v].cols != epis[0].cols || epis[v].type() != epis[0].type())
+                throw std::invalid_argument("Depth1DComputer_pile: EPIs differ in size or type");
+            ptrs[v] = epis[v].data;
+        }
+        const bool is_u8 = epis[0].depth() == CV_8U;
+        if (!is_u8 && epis[0].depth() != CV_32F)
+            throw std::invalid_argument("Depth1DComputer_pile: EPIs must be CV_8U or CV_32F");
+        init(ptrs.data(), is_u8, (int)epis.size(), epis[0].rows, epis[0].cols, epis[0].step[0], dmin, dmax, dim_d, s_hat,
+             epi_scale_factor);
+    }
+    cv::Mat get_edge_confidence() const { return cv::Mat(dim_v_, dim_u_, CV_32FC1, (void*)m_edge_confidence_v_u.data()).clone(); }
+    cv::Mat get_edge_confidence_mask() const { return cv::Mat(dim_v_, dim_u_, CV_8UC1, (void*)m_edge_confidence_mask_v_u.data()).clone(); }
+    cv::Mat get_disp_confidence() const { return cv::Mat(dim_v_, dim_u_, CV_32FC1, (void*)m_disp_confidence_v_u.data()).clone(); }
+    cv::Mat get_best_depth() const { return cv::Mat(dim_v_, dim_u_, CV_32FC1, (void*)m_best_depth_v_u.data()).clone(); }
+    cv::Mat get_rbar() const { return cv::Mat(dim_v_, dim_u_, CV_32FC(CHANNELS), (void*)m_rbar_v_u.data()).clone(); }
+#endif
+
+    ~Depth1DComputer_pile() { rslf_volume_destroy(vol_); }
+    Depth1DComputer_pile(const Depth1DComputer_pile&) = delete;
+    Depth1DComputer_pile& operator=(const Depth1DComputer_pile&) = delete;
+
+    // dc.hpp:513-565: edge confidence, scan, selective median -- on the GPU -- then the
+    // result planes are copied into the host members below.
+    void run()
+    {
+        const size_t n = (size_t)dim_v_ * dim_u_;
+        m_edge_confidence_v_u.assign(n, 0.f);
+        m_edge_confidence_mask_v_u.assign(n, 0);
+        m_disp_confidence_v_u.assign(n, 0.f);
+        m_best_depth_v_u.assign(n, 0.f);
+        m_rbar_v_u.assign(n * CHANNELS, 0.f);
+        m_depth_idx_v_u.assign(n, -1);
+        m_score_v_u.assign(n, 0.f);
+        const rslf_params p = m_parameters.to_c();
+        check(rslf_depth1d_pile_run_host(ctx_.get(), vol_, m_dmin, m_dmax, m_dim_d, m_s_hat, &p, m_edge_confidence_v_u.data(),
+                                         m_edge_confidence_mask_v_u.data(), m_disp_confidence_v_u.data(),
+                                         m_best_depth_v_u.data(), m_rbar_v_u.data(), m_depth_idx_v_u.data(),
+                                         m_score_v_u.data(), nullptr, &stats),
+              "rslf_depth1d_pile_run_host");
+    }
+
+    int get_s_hat() const { return m_s_hat; }
+    int rows() const { return dim_v_; }
+    int cols() const { return dim_u_; }
+    float epi_scale_factor() const { return scale_used_; }
+
+    // Results, dense row-major [V][U] (what the reference keeps as private Mats, dc.hpp:131-135)
+    std::vector<float> m_edge_confidence_v_u;
+    std::vector<uint8_t> m_edge_confidence_mask_v_u;
+    std::vector<float> m_disp_confidence_v_u;
+    std::vector<float> m_best_depth_v_u;
+    std::vector<float> m_rbar_v_u;          // [V][U][CHANNELS]
+    std::vector<int32_t> m_depth_idx_v_u;   // argmax index, -1 where no disparity was assigned
+    std::vector<float> m_score_v_u;
+    rslf_stats stats;
+
+private:
+    void init(const void* const* epis, bool is_u8, int dim_v, int dim_s, int dim_u, size_t row_stride_bytes, float dmin,
+              float dmax, int dim_d, int s_hat, float epi_scale_factor)
+    {
+        dim_v_ = dim_v;
+        dim_s_ = dim_s;
+        dim_u_ = dim_u;
+        m_dmin = dmin;
+        m_dmax = dmax;
+        m_dim_d = dim_d;
+        // dc.hpp:490-498
+        m_s_hat = (s_hat < 0 || s_hat > dim_s - 1) ? (int)std::floor((0.0 + dim_s) / 2) : s_hat;
+        stats = rslf_stats();
+        check(rslf_volume_create(ctx_.get(), dim_v, dim_s, dim_u, CHANNELS, &vol_), "rslf_volume_create");
+        scale_used_ = 255.f;
+        if (is_u8)
+            check(rslf_volume_upload_epis_u8(vol_, (const uint8_t* const*)epis, row_stride_bytes), "rslf_volume_upload_epis_u8");
+        else
+            check(rslf_volume_upload_epis_f32(vol_, (const float* const*)epis, row_stride_bytes, epi_scale_factor, &scale_used_),
+                  "rslf_volume_upload_epis_f32");
+    }
+
+    Context& ctx_;
+    rslf_volume* vol_;
+    int dim_v_, dim_s_, dim_u_;
+    int m_dim_d;
+    float m_dmin, m_dmax;
+    int m_s_hat;
+    float scale_used_;
+    const Depth1DParameters m_parameters;
+};
+
+typedef Depth1DComputer_pile<1> Depth1DComputer_pile_1ch;   // dc.hpp:149
+typedef Depth1DComputer_pile<3> Depth1DComputer_pile_3ch;   // dc.hpp:154
+
+}  // namespace rslfx
+
+#endif  // RSLF_HIP_HPP

@@ -1,0 +1,96 @@
+// Exercises include/rslf_hip.hpp the way the reference's demo uses its class
+// (RSLightFields/tests/test_depth_computation_pile.cpp:49-51):
+//     rslf::Depth1DComputer_pile<float> depth_computer_1d(epis, d_min, d_max, dim_d);
+//     depth_computer_1d.run();
+// Built with g++ -std=c++11 (the reference's toolchain) against librslf_hip.so; no OpenCV here,
+// so the EPIs are plain buffers.  Writes input and results to <out_dir>/ for the pytest side
+// (tests/test_gpu_cpp_host.py) to compare against the oracle.
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+#include "rslf_hip.hpp"
+
+template <typename T>
+static void dump(const std::string& path, const std::vector<T>& v)
+{
+    FILE* f = std::fopen(path.c_str(), "wb");
+    if (!f || std::fwrite(v.data(), sizeof(T), v.size(), f) != v.size()) {
+        std::perror(path.c_str());
+        std::exit(2);
+    }
+    std::fclose(f);
+}
+
+template <int C>
+static int run_case(rslfx::Context& ctx, const std::string& dir, const std::string& tag, bool u8)
+{
+    const int V = 7, S = 13, U = 150, D = 20;
+    const float dmin = -1.5f, dmax = 2.0f;
+    // deterministic pseudo-random EPIs, one separately allocated buffer per scanline (a Vec<Mat>)
+    std::vector<std::vector<float> > epis_f(V);
+    std::vector<std::vector<unsigned char> > epis_u8(V);
+    std::vector<const void*> ptrs(V);
+    unsigned state = 12345u + (unsigned)C + (u8 ? 77u : 0u);
+    std::vector<float> flat;
+    for (int v = 0; v < V; v++) {
+        epis_f[v].resize((size_t)S * U * C);
+        epis_u8[v].resize((size_t)S * U * C);
+        for (size_t i = 0; i < epis_f[v].size(); i++) {
+            state = state * 1664525u + 1013904223u;
+            const unsigned r = (state >> 8) & 0xffffu;
+            epis_u8[v][i] = (unsigned char)(r & 0xffu);
+            epis_f[v][i] = 3.0f + 250.0f * (float)r / 65535.0f;   // raw sensor-like range: the ctor rescales by the max
+            flat.push_back(u8 ? (float)epis_u8[v][i] : epis_f[v][i]);
+        }
+        ptrs[v] = u8 ? (const void*)epis_u8[v].data() : (const void*)epis_f[v].data();
+    }
+    rslfx::Depth1DParameters params;   // defaults = the reference's
+    rslfx::Depth1DComputer_pile<C> depth_computer_1d(ctx, ptrs.data(), u8, V, S, U, 0, dmin, dmax, D, -1, -1.0f, params);
+    depth_computer_1d.run();
+    if (depth_computer_1d.get_s_hat() != S / 2)
+        return 1;
+    dump(dir + "/" + tag + "_input.f32", flat);
+    dump(dir + "/" + tag + "_Ce.f32", depth_computer_1d.m_edge_confidence_v_u);
+    dump(dir + "/" + tag + "_mask.u8", depth_computer_1d.m_edge_confidence_mask_v_u);
+    dump(dir + "/" + tag + "_Cd.f32", depth_computer_1d.m_disp_confidence_v_u);
+    dump(dir + "/" + tag + "_depth.f32", depth_computer_1d.m_best_depth_v_u);
+    dump(dir + "/" + tag + "_rbar.f32", depth_computer_1d.m_rbar_v_u);
+    dump(dir + "/" + tag + "_idx.i32", depth_computer_1d.m_depth_idx_v_u);
+    dump(dir + "/" + tag + "_score.f32", depth_computer_1d.m_score_v_u);
+    std::printf("%s V=%d S=%d U=%d C=%d D=%d scale=%.9g scanned=%lld kernel=%d spad=%d K2=%.3f ms\n", tag.c_str(), V, S, U, C, D,
+                depth_computer_1d.epi_scale_factor(), (long long)depth_computer_1d.stats.pixels_scanned,
+                depth_computer_1d.stats.scan_kernel, depth_computer_1d.stats.s_pad, ctx.last_scan_kernel_ms());
+    return 0;
+}
+
+int main(int argc, char** argv)
+{
+    const std::string dir = argc > 1 ? argv[1] : ".";
+    try {
+        rslfx::Context ctx(0);
+        int rc = 0;
+        rc |= run_case<1>(ctx, dir, "f32_1ch", false);
+        rc |= run_case<3>(ctx, dir, "f32_3ch", false);
+        rc |= run_case<3>(ctx, dir, "u8_3ch", true);
+        // error convention: the C-ABI never throws; the C++ wrapper turns its status into rslfx::Error
+        bool threw = false;
+        try {
+            std::vector<float> e(4 * 8, 0.5f);
+            const void* p[1] = {e.data()};
+            rslfx::Depth1DComputer_pile<1> bad(ctx, p, false, 1, 4, 8, 0, 0.f, 1.f, 1 /* dim_d < 2 */);
+            bad.run();
+        } catch (const rslfx::Error& err) {
+            threw = err.status == RSLF_ERR_INVALID_ARG;
+        }
+        if (!threw) {
+            std::fprintf(stderr, "expected RSLF_ERR_INVALID_ARG for dim_d = 1\n");
+            rc |= 4;
+        }
+        return rc;
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "FAILED: %s\n", e.what());
+        return 3;
+    }
+}
