@@ -90,7 +90,7 @@ typedef struct rslf_stats {
 } rslf_stats;
 
 #define RSLF_SCAN_GENERIC   0  /* any S, C in {1,3}, any sign: re-gathers every mean-shift pass */
-#define RSLF_SCAN_REG_1CH   1  /* C=1, S<=128, volume >= 0: samples held in VGPRs */
+#define RSLF_SCAN_REG       1  /* volume >= 0 and C=1, S<=256 or C=3, S<=104: samples held in VGPRs/AGPRs */
 
 int         rslf_abi_version(void);
 const char* rslf_status_string(int status);

@@ -283,24 +283,30 @@ __global__ __launch_bounds__(64 * kScanWaves) void k2_scan_generic(ScanArgs a)
 }
 
 // ---------------------------------------------------------------------------
-// Register variant: C = 1, S <= SPAD <= 128, every radiance in [0, 1e6].
+// Register variant: C*SPAD sample registers, every radiance in [0, 1e6].
 //
-// The S samples of one (pixel, hypothesis) are gathered once into SPAD VGPRs
-// and the mean-shift passes run out of registers:
-//     delta = R - rbar ; t = k1*delta ; q = t*delta ; K = clamp(1 - q)
-//     P = R*K ; A += P ; B += K                      (7 VALU, no memory)
+// The S samples (x C channels) of one (pixel, hypothesis) are gathered once into
+// VGPRs and the mean-shift passes run out of registers, no memory instruction:
+//   C = 1:  delta = R - rbar ; t = k1*delta ; q = t*delta ; K = clamp(1 - q)
+//           P = R*K ; A += P ; B += K                                  ( 7 VALU / sample / pass)
+//   C = 3:  per channel delta, t = inv_h2*delta, q = t*delta ; qs = (q0+q2)+q1 ; K = clamp(1 - qs)
+//           per channel P = R*K, A += P ; B += K                       (19 VALU / sample / pass)
 // Out-of-range samples (the reference's NaN, interp.hpp:189) and the padding
-// slots s >= S hold kSentinel = 1e30: then q = +inf, K = max(-inf, 0) = 0 and
-// P = 1e30 * 0 = 0 exactly, so they add +0 to both sums -- bit-identical to the
+// slots s >= S hold kSentinel = 1e30 in every channel: then q = +inf, K = max(-inf, 0) = 0
+// and P = 1e30 * 0 = 0 exactly, so they add +0 to every sum -- bit-identical to the
 // reference's "NaN -> K = 0, R0 = 0" without a second register per sample.
 // Needs R == max(R, 0), hence the non-negative-volume precondition checked by
 // the host (rslf_abi.hip: rslf_depth_epi_pile).
 // ---------------------------------------------------------------------------
-constexpr int kGatherBatch = 8;   // samples whose loads are in flight together
+// samples whose loads are in flight together (2 registers per sample and channel while they are)
+constexpr int gather_batch(int c) { return c == 1 ? 8 : 4; }
+constexpr int kPadSlack = 16;     // compiled slot counts step by at most this: only the last kPadSlack slots can be padding
 
-template <int SPAD, bool BORDER>
-__device__ __forceinline__ void scan_reg_body(const ScanArgs& a, int v, int u, int d0, int d1, Best<1>& best)
+template <int SPAD, int C, bool BORDER>
+__device__ __forceinline__ void scan_reg_body(const ScanArgs& a, int v, int u, int d0, int d1, Best<C>& best)
 {
+    constexpr int kGatherBatch = gather_batch(C);
+    static_assert(SPAD % 8 == 0, "slot counts are multiples of 8");
     const VolView& vol = a.vol;
     const float* epi = vol.row(v, 0, 0);
     const float uf = (float)u;
@@ -312,16 +318,20 @@ __device__ __forceinline__ void scan_reg_body(const ScanArgs& a, int v, int u, i
     const float dmax = a.dmax_vu ? a.dmax_vu[o] : a.dmax;
     const float range = dmax - dmin;
     const float denom = (float)(a.dim_d - 1);
-    const float k1 = a.k.k1;
+    const float kq = (C == 1) ? a.k.k1 : a.k.inv_h2;   // kernels.cpp:21 / :43
     const float slope = a.k.slope;
     const int stride_s = (int)vol.stride_s;
+    const unsigned pitch_b = (unsigned)vol.pitch << 2;
     // core.hpp:577: rbar starts from R[s_hat] = E[s_hat][u] for every hypothesis
-    const float centre = epi[(long long)a.s_hat * vol.stride_s + u];
+    float centre[C];
+#pragma unroll
+    for (int c = 0; c < C; c++)
+        centre[c] = epi[(long long)a.s_hat * vol.stride_s + (long long)c * vol.pitch + u];
 
 #pragma unroll 1
     for (int d = d0; d < d1; d++) {
         const float Dd = hypothesis(dmin, range, denom, d);
-        float R[SPAD];
+        float R[C][SPAD];
         int card = BORDER ? 0 : S;
         // The gather is fully unrolled (R[] must be register-indexed).  Everything in it that
         // does not depend on d would otherwise be hoisted out of the d loop -- SPAD row
@@ -334,17 +344,20 @@ __device__ __forceinline__ void scan_reg_body(const ScanArgs& a, int v, int u, i
         asm volatile("" : "+s"(rowoff));
 #pragma unroll
         for (int g = 0; g < SPAD / kGatherBatch; g++) {
-            float tt[kGatherBatch], e0[kGatherBatch], e1[kGatherBatch];
+            float tt[kGatherBatch], e0[C][kGatherBatch], e1[C][kGatherBatch];
             bool ok[kGatherBatch];
             // issue the batch's loads back to back, then blend
 #pragma unroll
             for (int j = 0; j < kGatherBatch; j++) {
                 const int s = g * kGatherBatch + j;
                 tt[j] = 0.0f;
-                e0[j] = kSentinel;
-                e1[j] = 0.0f;
                 ok[j] = false;
-                if (s < SPAD - 8 || s < S) {
+#pragma unroll
+                for (int c = 0; c < C; c++) {
+                    e0[c][j] = kSentinel;
+                    e1[c][j] = 0.0f;
+                }
+                if (s < SPAD - kPadSlack || s < S) {
                     float x = (Ss0 - (float)s) * Dd;   // float(s_hat - s) * D[d]   core.hpp:542,550
                     x = x * slope;                     // core.hpp:551
                     x = x + uf;                        // core.hpp:552
@@ -357,58 +370,91 @@ __device__ __forceinline__ void scan_reg_body(const ScanArgs& a, int v, int u, i
                         ok[j] = (x >= 0.0f) && (x <= Um1f);
                         i0 = min(max(i0, 0), Um1);
                     }
-                    // 32-bit byte offset off the EPI's scalar base: one global_load_dwordx2 per sample
+                    // 32-bit byte offset off the EPI's scalar base: one global_load_dwordx2 per channel
                     const unsigned byteoff = (unsigned)(i0 + rowoff) << 2;
-                    const float* p = (const float*)((const char*)epi + byteoff);
-                    // second tap = p[1]: for integral x the reference reads p[0] twice with weights
-                    // 1 and 0; 0 * p[1] is the same +0 (rows are zero padded, so p[1] is finite)
-                    e0[j] = p[0];
-                    e1[j] = p[1];
+#pragma unroll
+                    for (int c = 0; c < C; c++) {
+                        const float* p = (const float*)((const char*)epi + (byteoff + (unsigned)c * pitch_b));
+                        // second tap = p[1]: for integral x the reference reads p[0] twice with weights
+                        // 1 and 0; 0 * p[1] is the same +0 (rows are zero padded, so p[1] is finite)
+                        e0[c][j] = p[0];
+                        e1[c][j] = p[1];
+                    }
                 }
                 rowoff += stride_s;
             }
 #pragma unroll
             for (int j = 0; j < kGatherBatch; j++) {
                 const int s = g * kGatherBatch + j;
-                const float m0 = (1.0f - tt[j]) * e0[j];   // interp.hpp:184
-                const float m1 = tt[j] * e1[j];
-                const float r = m0 + m1;
-                if (BORDER) {
-                    R[s] = ok[j] ? r : kSentinel;
-                    card += ok[j] ? 1 : 0;
-                } else {
-                    R[s] = (s < SPAD - 8 || s < S) ? r : kSentinel;
+                const float omt = 1.0f - tt[j];
+#pragma unroll
+                for (int c = 0; c < C; c++) {
+                    const float m0 = omt * e0[c][j];   // interp.hpp:184
+                    const float m1 = tt[j] * e1[c][j];
+                    const float r = m0 + m1;
+                    if (BORDER)
+                        R[c][s] = ok[j] ? r : kSentinel;
+                    else
+                        R[c][s] = (s < SPAD - kPadSlack || s < S) ? r : kSentinel;
                 }
+                if (BORDER)
+                    card += ok[j] ? 1 : 0;
             }
-            // Pin this batch: its eight results must exist here, and the next batch's address
-            // state is re-made opaque here, so the compiler cannot turn the unrolled gather into
-            // "all loads first, all blends last" (which parks 2*SPAD loaded values in scratch).
+            // Pin this batch: its results must exist here, and the next batch's address state is
+            // re-made opaque here, so the compiler cannot turn the unrolled gather into "all
+            // loads first, all blends last" (which parks 2*C*SPAD loaded values in scratch).
             {
                 const int b = g * kGatherBatch;
-                asm volatile(""
-                             : "+v"(R[b + 0]), "+v"(R[b + 1]), "+v"(R[b + 2]), "+v"(R[b + 3]), "+v"(R[b + 4]),
-                               "+v"(R[b + 5]), "+v"(R[b + 6]), "+v"(R[b + 7]), "+s"(rowoff), "+v"(Ss0));
+#pragma unroll
+                for (int c = 0; c < C; c++) {
+                    asm volatile("" : "+v"(R[c][b + 0]), "+v"(R[c][b + 1]), "+v"(R[c][b + 2]), "+v"(R[c][b + 3]));
+                    if (kGatherBatch == 8)
+                        asm volatile("" : "+v"(R[c][b + kGatherBatch - 4]), "+v"(R[c][b + kGatherBatch - 3]),
+                                          "+v"(R[c][b + kGatherBatch - 2]), "+v"(R[c][b + kGatherBatch - 1]));
+                }
+                asm volatile("" : "+s"(rowoff), "+v"(Ss0));
             }
         }
 
-        float rbar[1] = {centre};
+        float rbar[C];
+#pragma unroll
+        for (int c = 0; c < C; c++)
+            rbar[c] = centre[c];
         float B = 0.0f;
 #pragma unroll 1
         for (int it = 0; it < a.k.n_iter; it++) {   // core.hpp:584-610
-            float A = 0.0f;
+            float A[C];
+#pragma unroll
+            for (int c = 0; c < C; c++)
+                A[c] = 0.0f;
             B = 0.0f;
 #pragma unroll
             for (int s = 0; s < SPAD; s++) {
-                const float delta = R[s] - rbar[0];   // core.hpp:591
-                const float tq = k1 * delta;          // kernels.cpp:21
-                const float q = tq * delta;
-                const float K = kernel_weight(q);     // kernels.cpp:23-25
-                const float pr = R[s] * K;            // core.cpp:28
-                A = A + pr;                           // core.hpp:602
-                B = B + K;                            // core.hpp:603
+                float q[C];
+#pragma unroll
+                for (int c = 0; c < C; c++) {
+                    const float delta = R[c][s] - rbar[c];   // core.hpp:591
+                    const float tq = kq * delta;             // kernels.cpp:21 / :43
+                    q[c] = tq * delta;
+                }
+                float qs = q[0];
+                if (C == 3) {
+                    qs = q[0] + q[C - 1];                    // OpenCV 3.x reduceC_: (q0 + q2) + q1
+                    qs = qs + q[C > 1 ? 1 : 0];
+                }
+                const float K = kernel_weight(qs);           // kernels.cpp:23-25 / :51-53
+#pragma unroll
+                for (int c = 0; c < C; c++) {
+                    const float pr = R[c][s] * K;            // core.cpp:28 / :36
+                    A[c] = A[c] + pr;                        // core.hpp:602
+                }
+                B = B + K;                                   // core.hpp:603
             }
-            const float qd = (B != 0.0f) ? (A / B) : 0.0f;   // core.cpp:42, OpenCV 3.x: /0 -> 0
-            rbar[0] = (qd > 0.0f) ? qd : 0.0f;               // core.hpp:609
+#pragma unroll
+            for (int c = 0; c < C; c++) {
+                const float qd = (B != 0.0f) ? (A[c] / B) : 0.0f;   // core.cpp:42 / :50, OpenCV 3.x: /0 -> 0
+                rbar[c] = (qd > 0.0f) ? qd : 0.0f;                  // core.hpp:609
+            }
         }
         const float cardf = (float)card;
         float sc = (card != 0) ? (B / cardf) : 0.0f;   // core.hpp:616-620: the last pass's sum of K
@@ -417,18 +463,18 @@ __device__ __forceinline__ void scan_reg_body(const ScanArgs& a, int v, int u, i
     }
 }
 
-// Waves per SIMD the register budget allows: SPAD sample slots + ~64 working registers
-// (a batch of 8 in-flight samples, the per-pixel state, SGPR overflow lanes), in the
-// hardware's 8-register granules, 512 registers per SIMD lane.
-constexpr int scan_reg_waves(int spad)
+// Waves per SIMD the register budget allows: C*SPAD sample registers + ~64 working registers
+// (a batch of in-flight samples, the per-pixel state, SGPR overflow lanes), in the hardware's
+// 8-register granules, 512 registers per SIMD lane.
+constexpr int scan_reg_waves(int spad, int c)
 {
-    const int regs = ((spad + 64 + 7) / 8) * 8;
+    const int regs = ((c * spad + (c == 1 ? 64 : 96) + 7) / 8) * 8;
     const int w = 512 / regs;
     return w > 8 ? 8 : (w < 1 ? 1 : w);
 }
 
-template <int SPAD>
-__global__ __launch_bounds__(64 * kScanWaves) __attribute__((amdgpu_waves_per_eu(scan_reg_waves(SPAD), scan_reg_waves(SPAD))))
+template <int SPAD, int C>
+__global__ __launch_bounds__(64 * kScanWaves) __attribute__((amdgpu_waves_per_eu(scan_reg_waves(SPAD, C), scan_reg_waves(SPAD, C))))
 void k2_scan_reg(ScanArgs a)
 {
     int v, u;
@@ -447,13 +493,13 @@ void k2_scan_reg(ScanArgs a)
         const float uf = (float)u;
         interior = __all((uf - reach >= 0.0f) && (uf + reach <= (float)(a.vol.U - 1)));
     }
-    Best<1> best;
+    Best<C> best;
     best.init();
     if (interior)
-        scan_reg_body<SPAD, false>(a, v, u, d0, d1, best);
+        scan_reg_body<SPAD, C, false>(a, v, u, d0, d1, best);
     else
-        scan_reg_body<SPAD, true>(a, v, u, d0, d1, best);
-    scan_epilogue<1>(a, v, u, active, best);
+        scan_reg_body<SPAD, C, true>(a, v, u, d0, d1, best);
+    scan_epilogue<C>(a, v, u, active, best);
 }
 
 }  // namespace rslf

@@ -575,31 +575,57 @@ extern "C" int rslf_selective_median(rslf_ctx* ctx, const rslf_volume* vol, cons
     return RSLF_OK;
 }
 
-// Register-variant slot counts compiled into this library (multiples of 8).
-#ifndef RSLF_SPAD_LIST
-#define RSLF_SPAD_LIST(X) X(8) X(16) X(24) X(32) X(40) X(48) X(56) X(64) X(72) X(80) X(88) X(96) X(104) X(112) X(120) X(128)
+// Register-variant slot counts compiled into this library (multiples of 8), per channel count.
+// C*SPAD + working registers must fit the 512 (256 VGPR + 256 AGPR) a lane can own without scratch:
+// C=1 up to 256 slots (2 waves/SIMD up to 192, then 1), C=3 up to 104 slots (1 wave/SIMD from 56 on;
+// 112 and more spill to scratch and lose to the generic kernel, so they are not built).
+#ifndef RSLF_SPAD_LIST_1CH
+#define RSLF_SPAD_LIST_1CH(X) X(8) X(16) X(24) X(32) X(40) X(48) X(56) X(64) X(72) X(80) X(88) X(96) X(104) X(112) X(120) X(128) \
+    X(144) X(160) X(176) X(192) X(208) X(224) X(240) X(256)
+#endif
+#ifndef RSLF_SPAD_LIST_3CH
+#define RSLF_SPAD_LIST_3CH(X) X(8) X(16) X(24) X(32) X(40) X(48) X(56) X(64) X(72) X(80) X(88) X(96) X(104)
 #endif
 
-static int launch_scan_reg(int spad, const ScanArgs& a, dim3 grid, hipStream_t stream)
+static int launch_scan_reg(int spad, int C, const ScanArgs& a, dim3 grid, hipStream_t stream)
 {
-    switch (spad) {
-#define RSLF_CASE(N)                                                                   \
-    case N:                                                                            \
-        hipLaunchKernelGGL(k2_scan_reg<N>, grid, dim3(64 * kScanWaves), 0, stream, a);             \
+    if (C == 1) {
+        switch (spad) {
+#define RSLF_CASE(N)                                                                            \
+    case N:                                                                                     \
+        hipLaunchKernelGGL((k2_scan_reg<N, 1>), grid, dim3(64 * kScanWaves), 0, stream, a);     \
         return RSLF_OK;
-        RSLF_SPAD_LIST(RSLF_CASE)
+            RSLF_SPAD_LIST_1CH(RSLF_CASE)
 #undef RSLF_CASE
-    default:
-        return fail(RSLF_ERR_UNSUPPORTED, "no register scan kernel with %d slots", spad);
+        default:
+            break;
+        }
+    } else if (C == 3) {
+        switch (spad) {
+#define RSLF_CASE(N)                                                                            \
+    case N:                                                                                     \
+        hipLaunchKernelGGL((k2_scan_reg<N, 3>), grid, dim3(64 * kScanWaves), 0, stream, a);     \
+        return RSLF_OK;
+            RSLF_SPAD_LIST_3CH(RSLF_CASE)
+#undef RSLF_CASE
+        default:
+            break;
+        }
     }
+    return fail(RSLF_ERR_UNSUPPORTED, "no register scan kernel with %d slots x %d channels", spad, C);
 }
 
-static int pick_spad(int S)
+// Smallest compiled slot count >= S (0 = none: the generic kernel runs).
+static int pick_spad(int S, int C)
 {
     int best = 0;
 #define RSLF_PICK(N) \
-    if (N >= S && N - 8 < S && best == 0) best = N;
-    RSLF_SPAD_LIST(RSLF_PICK)
+    if (N >= S && best == 0) best = N;
+    if (C == 1) {
+        RSLF_SPAD_LIST_1CH(RSLF_PICK)
+    } else if (C == 3) {
+        RSLF_SPAD_LIST_3CH(RSLF_PICK)
+    }
 #undef RSLF_PICK
     return best;
 }
@@ -669,8 +695,8 @@ extern "C" int rslf_depth_epi_pile(rslf_ctx* ctx, const rslf_volume* vol, const 
     // Register variant: one channel, S within the compiled slot counts, and
     // radiances in [0, 1e6] so that max(R,0) == R and the 1e30 sentinel dwarfs them.
     int spad = 0;
-    if (vol->C == 1 && vol->min_value >= 0.0f && vol->max_value <= 1.0e6f)
-        spad = pick_spad(vol->S);
+    if (vol->min_value >= 0.0f && vol->max_value <= 1.0e6f)
+        spad = pick_spad(vol->S, vol->C);
     const char* force = getenv("RSLF_FORCE_SCAN");   // "generic": parity tests exercise the fallback on small cases
     if (force && strcmp(force, "generic") == 0)
         spad = 0;
@@ -678,7 +704,7 @@ extern "C" int rslf_depth_epi_pile(rslf_ctx* ctx, const rslf_volume* vol, const 
     ctx->last_spad = spad;
     HIP_TRY(hipEventRecord(ctx->ev0, st));
     if (spad) {
-        rc = launch_scan_reg(spad, a, grid, st);
+        rc = launch_scan_reg(spad, vol->C, a, grid, st);
         if (rc)
             return rc;
     } else if (vol->C == 1) {
@@ -706,7 +732,7 @@ extern "C" int rslf_depth_epi_pile(rslf_ctx* ctx, const rslf_volume* vol, const 
         HIP_TRY(hipStreamSynchronize(st));
         stats->pixels_scanned = (int64_t)tot;
         stats->units = (int64_t)tot * dim_d;
-        stats->scan_kernel = spad ? RSLF_SCAN_REG_1CH : RSLF_SCAN_GENERIC;
+        stats->scan_kernel = spad ? RSLF_SCAN_REG : RSLF_SCAN_GENERIC;
         stats->s_pad = spad;
     }
     return RSLF_OK;
@@ -792,7 +818,7 @@ extern "C" int rslf_depth1d_pile_run_host(rslf_ctx* ctx, const rslf_volume* vol,
         if (hipMemcpy(&tot, ctx->total, sizeof(tot), hipMemcpyDeviceToHost) == hipSuccess) {
             stats->pixels_scanned = (int64_t)tot;
             stats->units = (int64_t)tot * dim_d;
-            stats->scan_kernel = ctx->last_spad ? RSLF_SCAN_REG_1CH : RSLF_SCAN_GENERIC;
+            stats->scan_kernel = ctx->last_spad ? RSLF_SCAN_REG : RSLF_SCAN_GENERIC;
             stats->s_pad = ctx->last_spad;
         }
     }

@@ -43,8 +43,12 @@ CASES_1CH = [
     ("s33_noise", 130, 5, 33, 24, -2.0, 2.0, "noise"),
     ("s64", 200, 3, 64, 16, -1.0, 1.0, "noise"),
     ("s101_c3like", 700, 3, 101, 16, -2.0, 5.5, "struct"),
-    ("s128_max_reg", 150, 2, 128, 8, -0.5, 0.5, "noise"),
-    ("s129_generic", 150, 2, 129, 8, -0.5, 0.5, "noise"),
+    ("s128", 150, 2, 128, 8, -0.5, 0.5, "noise"),
+    ("s129_pad15", 150, 2, 129, 8, -0.5, 0.5, "noise"),
+    ("s145_pad15", 150, 2, 145, 6, -0.5, 0.5, "noise"),
+    ("s201_agpr", 300, 2, 201, 6, -1.0, 1.0, "struct"),
+    ("s256_max_reg", 120, 2, 256, 5, -0.25, 0.25, "noise"),
+    ("s257_generic", 120, 2, 257, 5, -0.25, 0.25, "noise"),
     ("u_not_mult64", 67, 4, 9, 12, -3.0, 3.0, "noise"),
     ("u_lt_filter", 6, 3, 5, 9, -1.0, 1.0, "noise"),
 ]
@@ -66,18 +70,32 @@ def test_pile_1ch(rs, oracle_mod, case):
     assert_pile_parity(got, ref, label=name)
     assert comp.stats.pixels_scanned == int((oracle_mod.edge_confidence_pile(vol, comp.get_s_hat())[1] > 0).sum())
     assert comp.stats.units == comp.stats.pixels_scanned * D
-    want_reg = S <= 128
+    want_reg = S <= 256
     assert (comp.stats.scan_kernel == 1) == want_reg, "unexpected scan kernel %d" % comp.stats.scan_kernel
+    if want_reg:
+        assert S <= comp.stats.s_pad < S + 16
 
 
-@pytest.mark.parametrize("kind", ["struct", "noise"])
-def test_pile_3ch(rs, oracle_mod, kind):
-    U, V, S, D = 90, 5, 17, 20
-    vol = _vol(kind, U, V, S, 3, 77, -1.0, 2.0)
-    ref = oracle_mod.depth1d_pile_run(vol, -1.0, 2.0, D)
-    comp, got = _run(rs, vol, -1.0, 2.0, D)
-    assert_pile_parity(got, ref, label="3ch_" + kind)
+@pytest.mark.parametrize("kind,S", [("struct", 17), ("noise", 17), ("noise", 9), ("struct", 56), ("noise", 64), ("noise", 65),
+                                    ("struct", 101), ("noise", 104), ("noise", 105)])
+def test_pile_3ch(rs, oracle_mod, kind, S):
+    """RGB: register scan up to 104 views (VGPRs, then AGPRs), generic beyond."""
+    U, V, D = (90, 5, 20) if S < 60 else (200, 2, 7)
+    dm = 2.0 if S < 60 else 0.75
+    vol = _vol(kind, U, V, S, 3, 77 + S, -1.0, dm)
+    ref = oracle_mod.depth1d_pile_run(vol, -1.0, dm, D)
+    comp, got = _run(rs, vol, -1.0, dm, D)
+    assert_pile_parity(got, ref, label="3ch_%s_%d" % (kind, S))
+    assert comp.stats.scan_kernel == (1 if S <= 104 else 0)
+
+
+def test_generic_kernel_matches_on_3ch(rs, oracle_mod, monkeypatch):
+    monkeypatch.setenv("RSLF_FORCE_SCAN", "generic")
+    vol = _vol("noise", 90, 4, 17, 3, 78, -1.0, 2.0)
+    ref = oracle_mod.depth1d_pile_run(vol, -1.0, 2.0, 20)
+    comp, got = _run(rs, vol, -1.0, 2.0, 20)
     assert comp.stats.scan_kernel == 0
+    assert_pile_parity(got, ref, label="forced_generic_3ch")
 
 
 def test_generic_kernel_matches_on_1ch(rs, oracle_mod, monkeypatch):
