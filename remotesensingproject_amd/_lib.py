@@ -78,7 +78,8 @@ class RslfError(RuntimeError):
 
 
 def library_path() -> str:
-    return _build.SO
+    # RSLF_LIBRARY: load another build of the same ABI (A/B timing of kernel variants)
+    return os.environ.get("RSLF_LIBRARY") or _build.SO
 
 
 def lib():

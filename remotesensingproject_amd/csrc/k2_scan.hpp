@@ -302,8 +302,15 @@ __global__ __launch_bounds__(64 * kScanWaves) void k2_scan_generic(ScanArgs a)
 constexpr int gather_batch(int c) { return c == 1 ? 8 : 4; }
 constexpr int kPadSlack = 16;     // compiled slot counts step by at most this: only the last kPadSlack slots can be padding
 
-template <int SPAD, int C, bool BORDER>
-__device__ __forceinline__ void scan_reg_body(const ScanArgs& a, int v, int u, int d0, int d1, Best<C>& best)
+// BORDER:    some sample line of this wave may leave [0, U-1]: test validity per sample.
+// UNIFORM_D: every pixel shares the hypothesis grid (no per-pixel dmin/dmax planes), so the
+//            view offset fl(fl(float(s_hat - s) * D[d]) * slope) is the same for all 64 lanes:
+//            the wave computes the S offsets of a hypothesis once (2-4 lane-parallel rounds),
+//            parks them in LDS and every sample starts from one broadcast ds_read -- 3 VALU
+//            instructions fewer per sample than recomputing them per lane.
+template <int SPAD, int C, bool BORDER, bool UNIFORM_D>
+__device__ __forceinline__ void scan_reg_body(const ScanArgs& a, int v, int u, int d0, int d1, Best<C>& best,
+                                              float* __restrict__ otab)
 {
     constexpr int kGatherBatch = gather_batch(C);
     static_assert(SPAD % 8 == 0, "slot counts are multiples of 8");
@@ -311,8 +318,9 @@ __device__ __forceinline__ void scan_reg_body(const ScanArgs& a, int v, int u, i
     const float* epi = vol.row(v, 0, 0);
     const float uf = (float)u;
     const int Um1 = vol.U - 1;
-    const float Um1f = (float)Um1;
+    const unsigned Um1_bits = __float_as_uint((float)Um1);
     const int S = vol.S;
+    const int lane = threadIdx.x & 63;
     const long long o = (long long)v * vol.U + u;
     const float dmin = a.dmin_vu ? a.dmin_vu[o] : a.dmin;
     const float dmax = a.dmax_vu ? a.dmax_vu[o] : a.dmax;
@@ -342,6 +350,18 @@ __device__ __forceinline__ void scan_reg_body(const ScanArgs& a, int v, int u, i
         asm volatile("" : "+v"(Ss0));
         int rowoff = 0;
         asm volatile("" : "+s"(rowoff));
+        if (UNIFORM_D) {
+#pragma unroll
+            for (int s0 = 0; s0 < SPAD; s0 += 64) {
+                const int s = s0 + lane;
+                float off = (float)(a.s_hat - s) * Dd;   // float(s_hat - s) * D[d]   core.hpp:542,550
+                off = off * slope;                       // core.hpp:551
+                if (SPAD % 64 == 0 || s < SPAD)
+                    otab[s] = off;
+            }
+            // same wave, LDS is in order: the broadcast reads below see these writes
+            __builtin_amdgcn_wave_barrier();
+        }
 #pragma unroll
         for (int g = 0; g < SPAD / kGatherBatch; g++) {
             float tt[kGatherBatch], e0[C][kGatherBatch], e1[C][kGatherBatch];
@@ -358,17 +378,24 @@ __device__ __forceinline__ void scan_reg_body(const ScanArgs& a, int v, int u, i
                     e1[c][j] = 0.0f;
                 }
                 if (s < SPAD - kPadSlack || s < S) {
-                    float x = (Ss0 - (float)s) * Dd;   // float(s_hat - s) * D[d]   core.hpp:542,550
-                    x = x * slope;                     // core.hpp:551
+                    float x;
+                    if (UNIFORM_D) {
+                        x = otab[s];                   // one broadcast read for the wave
+                    } else {
+                        x = (Ss0 - (float)s) * Dd;     // float(s_hat - s) * D[d]   core.hpp:542,550
+                        x = x * slope;                 // core.hpp:551
+                    }
                     x = x + uf;                        // core.hpp:552
                     const float fl = floorf(x);        // interp.hpp:179
                     tt[j] = x - fl;                    // interp.hpp:181
                     int i0 = (int)fl;
                     ok[j] = true;
                     if (BORDER) {
-                        // floor(x) >= 0 <=> x >= 0 ; ceil(x) <= U-1 <=> x <= U-1   (interp.hpp:182)
-                        ok[j] = (x >= 0.0f) && (x <= Um1f);
-                        i0 = min(max(i0, 0), Um1);
+                        // interp.hpp:182: floor(x) >= 0 <=> x >= 0 and ceil(x) <= U-1 <=> x <= U-1.
+                        // x is never -0 (u >= +0 is added last), so both tests are ONE unsigned compare
+                        // of the bit patterns: negative floats have the sign bit set and compare high.
+                        ok[j] = __float_as_uint(x) <= Um1_bits;
+                        i0 = ok[j] ? i0 : 0;           // keep the address inside the row
                     }
                     // 32-bit byte offset off the EPI's scalar base: one global_load_dwordx2 per channel
                     const unsigned byteoff = (unsigned)(i0 + rowoff) << 2;
@@ -412,7 +439,10 @@ __device__ __forceinline__ void scan_reg_body(const ScanArgs& a, int v, int u, i
                         asm volatile("" : "+v"(R[c][b + kGatherBatch - 4]), "+v"(R[c][b + kGatherBatch - 3]),
                                           "+v"(R[c][b + kGatherBatch - 2]), "+v"(R[c][b + kGatherBatch - 1]));
                 }
-                asm volatile("" : "+s"(rowoff), "+v"(Ss0));
+                if (BORDER)
+                    asm volatile("" : "+s"(rowoff), "+v"(Ss0), "+v"(card));
+                else
+                    asm volatile("" : "+s"(rowoff), "+v"(Ss0));
             }
         }
 
@@ -428,27 +458,34 @@ __device__ __forceinline__ void scan_reg_body(const ScanArgs& a, int v, int u, i
             for (int c = 0; c < C; c++)
                 A[c] = 0.0f;
             B = 0.0f;
+            if (C == 1) {
+                // hand-scheduled, four samples per block (rslf_device.hpp)
 #pragma unroll
-            for (int s = 0; s < SPAD; s++) {
-                float q[C];
+                for (int s0 = 0; s0 < SPAD; s0 += 4)
+                    mean_shift_group4(R[0][s0], R[0][s0 + 1], R[0][s0 + 2], R[0][s0 + 3], rbar[0], kq, A[0], B);
+            } else {
 #pragma unroll
-                for (int c = 0; c < C; c++) {
-                    const float delta = R[c][s] - rbar[c];   // core.hpp:591
-                    const float tq = kq * delta;             // kernels.cpp:21 / :43
-                    q[c] = tq * delta;
-                }
-                float qs = q[0];
-                if (C == 3) {
-                    qs = q[0] + q[C - 1];                    // OpenCV 3.x reduceC_: (q0 + q2) + q1
-                    qs = qs + q[C > 1 ? 1 : 0];
-                }
-                const float K = kernel_weight(qs);           // kernels.cpp:23-25 / :51-53
+                for (int s = 0; s < SPAD; s++) {
+                    float q[C];
 #pragma unroll
-                for (int c = 0; c < C; c++) {
-                    const float pr = R[c][s] * K;            // core.cpp:28 / :36
-                    A[c] = A[c] + pr;                        // core.hpp:602
+                    for (int c = 0; c < C; c++) {
+                        const float delta = R[c][s] - rbar[c];   // core.hpp:591
+                        const float tq = kq * delta;             // kernels.cpp:21 / :43
+                        q[c] = tq * delta;
+                    }
+                    float qs = q[0];
+                    if (C == 3) {
+                        qs = q[0] + q[C - 1];                    // OpenCV 3.x reduceC_: (q0 + q2) + q1
+                        qs = qs + q[C > 1 ? 1 : 0];
+                    }
+                    const float K = kernel_weight(qs);           // kernels.cpp:23-25 / :51-53
+#pragma unroll
+                    for (int c = 0; c < C; c++) {
+                        const float pr = R[c][s] * K;            // core.cpp:28 / :36
+                        A[c] = A[c] + pr;                        // core.hpp:602
+                    }
+                    B = B + K;                                   // core.hpp:603
                 }
-                B = B + K;                                   // core.hpp:603
             }
 #pragma unroll
             for (int c = 0; c < C; c++) {
@@ -493,12 +530,16 @@ void k2_scan_reg(ScanArgs a)
         const float uf = (float)u;
         interior = __all((uf - reach >= 0.0f) && (uf + reach <= (float)(a.vol.U - 1)));
     }
+    __shared__ float s_otab[kScanWaves][SPAD];
+    float* otab = s_otab[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)];
     Best<C> best;
     best.init();
     if (interior)
-        scan_reg_body<SPAD, C, false>(a, v, u, d0, d1, best);
+        scan_reg_body<SPAD, C, false, true>(a, v, u, d0, d1, best, otab);
+    else if (!a.dmin_vu)
+        scan_reg_body<SPAD, C, true, true>(a, v, u, d0, d1, best, otab);
     else
-        scan_reg_body<SPAD, C, true>(a, v, u, d0, d1, best);
+        scan_reg_body<SPAD, C, true, false>(a, v, u, d0, d1, best, otab);
     scan_epilogue<C>(a, v, u, active, best);
 }
 

@@ -61,12 +61,56 @@ __device__ __forceinline__ float norm3(float x, float y, float z)
 // default) sends NaN to 0.  q = (k*delta)*delta is >= 0 or NaN, so 1 - q <= 1 and the upper
 // clamp never acts: the result equals cv::max(1 - q, 0) bit for bit.  v_max_f32 issues at
 // about half the rate of v_sub_f32 on gfx950 (tools/ubench_valu.hip), so this is worth ~20 %
-// of the mean-shift loop.
+// of the mean-shift loop.  Written as asm on purpose: hipcc does fold
+// __builtin_amdgcn_fmed3f(1 - q, 0, 1) into the same instruction, but then schedules each
+// sample's 7-instruction chain back to back through two registers (+10 % cycles, profiles/).
 __device__ __forceinline__ float kernel_weight(float q)
 {
     float k;
     asm("v_sub_f32_e64 %0, 1.0, %1 clamp" : "=v"(k) : "v"(q));
     return k;
+}
+
+// Four samples of one mean-shift pass (1 channel), hand-scheduled: 28 VALU instructions issued
+// stage by stage so that no instruction reads the result of the one before it (hipcc, left to
+// itself, allocates two temporaries and emits the 7-instruction chain of each sample back to
+// back, which stalls the issue: +10 % cycles measured).  The two running sums take
+// the samples in ascending order, one IEEE add each -- the reference's sequential cv::reduce.
+//   delta = R - rbar ; t = k1*delta ; q = t*delta ; K = clamp(1 - q) ; P = R*K ; A += P ; B += K
+__device__ __forceinline__ void mean_shift_group4(float r0, float r1, float r2, float r3, float rbar, float k1,
+                                                  float& A, float& B)
+{
+    float t0, t1, t2, t3, u0, u1, u2, u3;
+    asm("v_sub_f32 %2, %10, %14\n\t"
+        "v_sub_f32 %3, %11, %14\n\t"
+        "v_sub_f32 %4, %12, %14\n\t"
+        "v_sub_f32 %5, %13, %14\n\t"
+        "v_mul_f32 %6, %15, %2\n\t"
+        "v_mul_f32 %7, %15, %3\n\t"
+        "v_mul_f32 %8, %15, %4\n\t"
+        "v_mul_f32 %9, %15, %5\n\t"
+        "v_mul_f32 %2, %2, %6\n\t"
+        "v_mul_f32 %3, %3, %7\n\t"
+        "v_mul_f32 %4, %4, %8\n\t"
+        "v_mul_f32 %5, %5, %9\n\t"
+        "v_sub_f32_e64 %2, 1.0, %2 clamp\n\t"
+        "v_sub_f32_e64 %3, 1.0, %3 clamp\n\t"
+        "v_sub_f32_e64 %4, 1.0, %4 clamp\n\t"
+        "v_sub_f32_e64 %5, 1.0, %5 clamp\n\t"
+        "v_mul_f32 %6, %10, %2\n\t"
+        "v_mul_f32 %7, %11, %3\n\t"
+        "v_mul_f32 %8, %12, %4\n\t"
+        "v_mul_f32 %9, %13, %5\n\t"
+        "v_add_f32 %0, %0, %6\n\t"
+        "v_add_f32 %1, %1, %2\n\t"
+        "v_add_f32 %0, %0, %7\n\t"
+        "v_add_f32 %1, %1, %3\n\t"
+        "v_add_f32 %0, %0, %8\n\t"
+        "v_add_f32 %1, %1, %4\n\t"
+        "v_add_f32 %0, %0, %9\n\t"
+        "v_add_f32 %1, %1, %5"
+        : "+v"(A), "+v"(B), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(u0), "=&v"(u1), "=&v"(u2), "=&v"(u3)
+        : "v"(r0), "v"(r1), "v"(r2), "v"(r3), "v"(rbar), "s"(k1));
 }
 
 // cv::BORDER_REFLECT_101

@@ -24,7 +24,7 @@ PROF = os.path.join(ROOT, "gpurun_out", "prof")
 
 
 def pmc_means(sub):
-    files = sorted(glob.glob(os.path.join(PROF, sub, "*", "*counter_collection.csv")))
+    files = sorted(glob.glob(os.path.join(PROF, sub, "*", "*counter_collection.csv")), key=os.path.getmtime)
     if not files:
         return {}
     rows = list(csv.DictReader(open(files[-1])))
@@ -45,7 +45,7 @@ def main():
     out = os.path.join(ROOT, "profiles")
     os.makedirs(out, exist_ok=True)
     # kernel stats
-    st = sorted(glob.glob(os.path.join(PROF, "stats", "*", "*kernel_stats.csv")))
+    st = sorted(glob.glob(os.path.join(PROF, "stats", "*", "*kernel_stats.csv")), key=os.path.getmtime)
     if st:
         rows = list(csv.reader(open(st[-1])))
         keep = [rows[0]] + [r for r in rows[1:] if "rslf::" in r[0]]
