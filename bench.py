@@ -92,10 +92,17 @@ def main() -> None:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus %d needs the torch.distributed.run launcher (WORLD_SIZE=%d)" % (args.gpus, world))
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    # RSLF_DIST_BACKEND=gloo + RSLF_ONE_DEVICE=1 rehearse the N > 1 path on a one-GPU box (never a result)
+    backend = os.environ.get("RSLF_DIST_BACKEND", "nccl")
+    if os.environ.get("RSLF_ONE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
+        else:
+            dist.init_process_group(backend)
 
     cfg = dict(CONFIGS[args.config])
     if args.rows:
@@ -117,12 +124,11 @@ def main() -> None:
                     depth_idx=comp.m_depth_idx_v_u, rbar=comp.m_rbar_v_u, edge_mask=comp.m_edge_confidence_mask_v_u)
 
     k2_ms = []
+    gatherer = sharding.PlaneGatherer(shard, U, C, dev)
 
     def step(record: bool):
         comp.run(want_stats=False)
-        out = planes()
-        if world > 1:
-            out = sharding.gather_planes(out, shard, U, C)
+        out = gatherer(planes())   # N > 1: RCCL gather of the owned rows onto rank 0
         if record:
             k2_ms.append(ctx.last_scan_kernel_ms())   # HIP events on the launching stream
         return out
@@ -141,7 +147,7 @@ def main() -> None:
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -152,7 +158,7 @@ def main() -> None:
     scanned_local = int((m0[shard.interior] > 0).sum().item())
     comp.run(want_stats=True)
     torch.cuda.synchronize(dev)
-    n = torch.tensor([scanned_local], dtype=torch.int64, device=dev)
+    n = torch.tensor([scanned_local], dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(n)
     pixels = int(n.item())
@@ -189,11 +195,11 @@ def main() -> None:
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic",
+            "data": "synthetic" if backend == "nccl" else "synthetic (REHEARSAL: %s backend, not a result)" % backend,
             "config": {
                 "workload": "%s: %dx%d px x %d views x %d ch, %d hypotheses in [%g, %g], seed %d, all pixels confident" % (
                     args.config, U, V, S, C, D, cfg["dmin"], cfg["dmax"], cfg["seed"]),
-                "sharding": "none" if world == 1 else "scanline blocks + %d-row recomputed halo, 1 RCCL gather/step" % ((params.par_median_filter_size - 1) // 2),
+                "sharding": "none" if world == 1 else "scanline blocks + %d-row recomputed halo, RCCL gather of the output planes per step" % ((params.par_median_filter_size - 1) // 2),
                 "scan_kernel": "k2_scan_reg<%d>" % comp.stats.s_pad if comp.stats.scan_kernel == 1 else "k2_scan_generic<%d>" % C,
                 "pixels_scanned": pixels,
             },

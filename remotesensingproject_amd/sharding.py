@@ -6,8 +6,8 @@ K1 (edge confidence) and K2 (the scan) are independent per scanline v
 s_hat row of the volume.  So each rank takes a contiguous block of scanlines
 plus a halo of (size-1)/2 rows on each side that it RECOMPUTES (no exchange),
 and the only data-path collective is the reassembly of the output planes on
-rank 0: one gather per run, all planes packed in a single byte buffer (xGMI is
-point-to-point, so one ~MB message per peer beats eight small ones).
+rank 0 (PlaneGatherer): per-plane gathers straight into the final planes when
+the blocks are equal, else one gather of a packed, padded byte buffer.
 
 One process per GPU; `torch.distributed` backend "nccl" is RCCL on ROCm.  The
 partition/stitch logic is backend-agnostic and is exercised on CPU with gloo
@@ -112,6 +112,65 @@ def unpack_planes(bufs: List[torch.Tensor], parts: List[Tuple[int, int]], max_ro
         out[name] = full
         off += max_rows * U * cc * es
     return out
+
+
+class PlaneGatherer:
+    """Reassembly of the depth map on rank `dst`, with its buffers allocated once.
+
+    Equal scanline blocks (V divisible by the world size -- 1080 / 8 = 135): every plane is
+    gathered straight into row-block views of the final [V, U] plane, no staging copy on either
+    side (eight small collectives, ~5 MB per rank in total).  Unequal blocks: one gather of the
+    zero-padded packed buffer (pack_planes / unpack_planes)."""
+
+    def __init__(self, shard: Shard, U: int, C: int, device, group=None, dst: int = 0):
+        self.shard, self.U, self.C, self.group, self.dst = shard, U, C, group, dst
+        self.parts = row_partition(shard.V, shard.world)
+        sizes = {b - a for a, b in self.parts}
+        self.equal = len(sizes) == 1
+        self.max_rows = max(sizes)
+        self.full: Optional[Dict[str, torch.Tensor]] = None
+        if shard.rank == dst:
+            self.full = {}
+            for name, dt, per_c in PLANES:
+                shape = (shard.V, U, C) if per_c else (shard.V, U)
+                self.full[name] = torch.empty(shape, dtype=dt, device=device)
+            if not self.equal:
+                n = self.max_rows * _row_bytes(U, C)
+                self.recv = [torch.empty(n, dtype=torch.uint8, device=device) for _ in range(shard.world)]
+
+    def __call__(self, planes: Dict[str, torch.Tensor]) -> Optional[Dict[str, torch.Tensor]]:
+        sh = self.shard
+        if sh.world == 1:
+            return planes
+        # rehearsal on a box without RCCL peers: gloo moves CPU tensors only
+        via_host = dist.get_backend(self.group) == "gloo" and planes["depth"].is_cuda
+        if self.equal:
+            for name, _, _ in PLANES:
+                src = planes[name][sh.interior]
+                if via_host:
+                    src = src.cpu()
+                if sh.rank == self.dst:
+                    if via_host:
+                        recv = [torch.empty_like(src) for _ in self.parts]
+                        dist.gather(src, recv, dst=self.dst, group=self.group)
+                        for (a, b), r in zip(self.parts, recv):
+                            self.full[name][a:b].copy_(r)
+                    else:
+                        dist.gather(src, [self.full[name][a:b] for a, b in self.parts], dst=self.dst, group=self.group)
+                else:
+                    dist.gather(src, None, dst=self.dst, group=self.group)
+            return self.full
+        if via_host:
+            raise RuntimeError("gloo rehearsal supports equal scanline blocks only")
+        buf = pack_planes(planes, sh.interior, self.max_rows, self.U, self.C)
+        if sh.rank == self.dst:
+            dist.gather(buf, self.recv, dst=self.dst, group=self.group)
+            out = unpack_planes(self.recv, self.parts, self.max_rows, self.U, self.C)
+            for k in out:
+                self.full[k].copy_(out[k])
+            return self.full
+        dist.gather(buf, None, dst=self.dst, group=self.group)
+        return None
 
 
 def gather_planes(planes: Dict[str, torch.Tensor], shard: Shard, U: int, C: int, group=None,
