@@ -187,6 +187,34 @@ int rslf_depth1d_pile_run_host(rslf_ctx* ctx, const rslf_volume* vol, float dmin
                                float* h_rbar_vu, int32_t* h_idx_vu, float* h_score_vu, float* h_depth_raw_vu,
                                rslf_stats* stats);
 
+/* ---- "next" row: the 2-D sweep over all views ------ */
+/* Planes here are [S][V][U] (the reference's Vec<Mat> indexed by s, dc.hpp:208-215),
+ * d_rbar_svu is [S][V][U][C]. */
+
+/* rslf::compute_2D_edge_confidence -- core.hpp:323-330, impl :901-931: the pile edge
+ * confidence for every view.  d_Ce_svu in/out (accumulates, pass zeros). */
+int rslf_edge_confidence_2d(rslf_ctx* ctx, const rslf_volume* vol, const rslf_params* p,
+                            float* d_Ce_svu, uint8_t* d_Ce_mask_svu);
+
+/* rslf::compute_2D_depth_epi -- core.hpp:336-351, impl :933-1133 (default build: neither
+ * _USE_DISP_CONFIDENCE_SCORE nor _USE_LINE_CONFIDENCE_SCORE, so propagation is gated by the edge
+ * mask, :1099-1103).  Views are visited s_hat = floor(S/2), s_hat+1, s_hat-1, ... (:981-990); each
+ * visit runs rslf_depth_epi_pile on the running mask (:1012-1028) and then propagates the
+ * median-filtered disparities along their EPI lines into every view (:1088-1129).
+ *   d_dmin_svu/d_dmax_svu  [S][V][U], both NULL => scalars dmin/dmax (dc.hpp:718-722)
+ *   d_scan_mask_svu        nullable out: the running masks after the last visit
+ *   stats->units           sums the units of all visits */
+int rslf_depth_epi_2d(rslf_ctx* ctx, const rslf_volume* vol, const float* d_dmin_svu, const float* d_dmax_svu,
+                      float dmin, float dmax, int dim_d,
+                      float* d_Ce_svu, uint8_t* d_Ce_mask_svu, float* d_Cd_svu, float* d_depth_svu,
+                      float* d_rbar_svu, const rslf_params* p, uint8_t* d_scan_mask_svu, rslf_stats* stats);
+
+/* rslf::Depth2DComputer<T>::run() -- include/rslf_depth_computation.hpp:748-805 with the
+ * constructor's output allocation (:718-750): zero-fills the outputs, then the two calls above. */
+int rslf_depth2d_run(rslf_ctx* ctx, const rslf_volume* vol, float dmin, float dmax, int dim_d, const rslf_params* p,
+                     float* d_Ce_svu, uint8_t* d_Ce_mask_svu, float* d_Cd_svu, float* d_depth_svu,
+                     float* d_rbar_svu, uint8_t* d_scan_mask_svu, rslf_stats* stats);
+
 /* ---- measurement ------------------------------------------------------ */
 /* Duration in milliseconds of the last scan-kernel launch (K2) of this
  * context, from HIP events recorded on the context's stream around that

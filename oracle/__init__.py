@@ -74,6 +74,9 @@ def lib():
         L.oracle_depth1d_pile_run.argtypes = [
             _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int,
             C.POINTER(OracleParams), _f32p, _u8p, _f32p, _f32p, _f32p, _i32p, _f32p, _f32p]
+        L.oracle_depth2d_run.argtypes = [
+            _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.POINTER(OracleParams), C.c_float,
+            _f32p, _u8p, _f32p, _f32p, _f32p, _u8p]
         L.oracle_num_threads.restype = C.c_int
         L.oracle_set_num_threads.argtypes = [C.c_int]
         _lib = L
@@ -200,6 +203,34 @@ def depth1d_pile_run(vol, dmin, dmax, dim_d, s_hat=-1, params=None) -> PileResul
                                   Ce.reshape(-1), cm.reshape(-1), Cd.reshape(-1), depth.reshape(-1),
                                   rbar.reshape(-1), idx.reshape(-1), score.reshape(-1), raw.reshape(-1))
     return PileResult(Ce, cm, Cd, depth, rbar, idx, score, raw)
+
+
+@dataclass
+class SweepResult:
+    """Outputs of Depth2DComputer::run() (dc.hpp:208-215), all [S,V,U(,C)]."""
+
+    edge_confidence: np.ndarray
+    edge_mask: np.ndarray
+    disp_confidence: np.ndarray
+    depth: np.ndarray
+    rbar: np.ndarray
+    scan_mask: np.ndarray     # the running masks after the last view (not kept by the reference)
+
+
+def depth2d_run(vol, dmin, dmax, dim_d, params=None, propagation_epsilon=0.1) -> SweepResult:
+    """Depth2DComputer ctor+run() (dc.hpp:651-805) on a normalised volume [V,S,U,C]."""
+    vol = np.ascontiguousarray(vol, dtype=np.float32)
+    V, S, U, Cc = vol.shape
+    p = params or default_params()
+    Ce = np.zeros((S, V, U), np.float32)
+    cm = np.zeros((S, V, U), np.uint8)
+    Cd = np.zeros((S, V, U), np.float32)
+    depth = np.zeros((S, V, U), np.float32)
+    rbar = np.zeros((S, V, U, Cc), np.float32)
+    sm = np.zeros((S, V, U), np.uint8)
+    lib().oracle_depth2d_run(vol.reshape(-1), V, S, U, Cc, dmin, dmax, dim_d, C.byref(p), np.float32(propagation_epsilon),
+                             Ce.reshape(-1), cm.reshape(-1), Cd.reshape(-1), depth.reshape(-1), rbar.reshape(-1), sm.reshape(-1))
+    return SweepResult(Ce, cm, Cd, depth, rbar, sm)
 
 
 def num_threads() -> int:

@@ -209,3 +209,48 @@ def depth1d_pile_run(vol, dmin, dmax, D, s_hat=-1, p=None):
     out["depth"] = selective_median(out["depth_raw"], vol, s_hat, out["Ce_mask"],
                                     p["median_filter_size"], p["median_filter_epsilon"])
     return out
+
+
+def depth2d_run(vol, dmin, dmax, D, p=None, propagation_epsilon=F(0.1)):
+    """Depth2DComputer ctor + run() (dc.hpp:651-805): compute_2D_edge_confidence (core.hpp:901-931)
+    and compute_2D_depth_epi (core.hpp:933-1133, default build: propagation gated by the edge mask)."""
+    p = p or default_params()
+    V, S, U, C = vol.shape
+    Ce = np.zeros((S, V, U), F); cm = np.zeros((S, V, U), np.uint8)
+    for s in range(S):
+        for v in range(V):
+            Ce[s, v], cm[s, v] = edge_confidence_row(vol[v, s], p)
+    Cd = np.zeros((S, V, U), F); depth = np.zeros((S, V, U), F); rbar = np.zeros((S, V, U, C), F)
+    mask = cm.copy()                                            # core.hpp:958-965
+    s_mid = int(np.floor(S / 2.0))
+    order = [s_mid]
+    for off in range(1, S - s_mid):                             # core.hpp:981-990
+        order.append(s_mid + off)
+        if s_mid - off > -1:
+            order.append(s_mid - off)
+    dmin_u = np.full(U, dmin, F); dmax_u = np.full(U, dmax, F)
+    for s_hat in order:
+        for v in range(V):                                      # core.hpp:1012-1028 (scan, per EPI)
+            r = depth_epi(vol[v], dmin_u, dmax_u, D, s_hat, Ce[s_hat, v], cm[s_hat, v], p, mask_u=mask[s_hat, v])
+            mask[s_hat, v] = cm[s_hat, v] & mask[s_hat, v]      # core.hpp:511 (AND in place, before rejections)
+            scanned = mask[s_hat, v] > 0
+            Ce[s_hat, v], cm[s_hat, v] = r["Ce"], r["Ce_mask"]
+            sel = r["idx"] >= 0
+            Cd[s_hat, v][sel] = r["Cd"][sel]
+            depth[s_hat, v][sel] = r["depth"][sel]              # raw depths land in the stored plane
+            rbar[s_hat, v][sel] = r["rbar"][sel]
+        filtered = selective_median(depth[s_hat], vol, s_hat, cm[s_hat], p["median_filter_size"], p["median_filter_epsilon"])
+        for v in range(V):                                      # core.hpp:1088-1129
+            for u in range(U):
+                if not cm[s_hat, v, u]:
+                    continue
+                cur = filtered[v, u]
+                for s in range(S):
+                    off = F(F(cur * F(s_hat - s)) * F(p["slope_factor"]))
+                    ri = u + int(np.sign(off) * np.floor(np.abs(off) + F(0.5)))   # std::round: half away from zero
+                    if -1 < ri < U and mask[s, v, ri]:
+                        if _norm((vol[v, s, ri] - rbar[s_hat, v, u])[None])[0] < F(propagation_epsilon):
+                            depth[s, v, ri] = cur
+                            mask[s, v, ri] = 0
+                            Cd[s, v, ri] = Cd[s_hat, v, u]
+    return dict(Ce=Ce, Ce_mask=cm, Cd=Cd, depth=depth, rbar=rbar, scan_mask=mask)

@@ -620,3 +620,119 @@ void oracle_depth1d_pile_run(const float* vol, int V, int S, int U, int C,
     free(dmin_vu);
     free(dmax_vu);
 }
+
+/* ======================================================================
+ * "next" row: compute_2D_edge_confidence / compute_2D_depth_epi
+ * (core.hpp:901-1133) and Depth2DComputer (dc.hpp:651-805)
+ * ====================================================================== */
+
+void oracle_edge_confidence_2d(const float* vol, int V, int S, int U, int C,
+                               float* Ce_svu, uint8_t* mask_svu, const oracle_params* p)
+{
+    const size_t n = (size_t)V * U;
+    for (int s = 0; s < S; s++) /* core.hpp:918-934 */
+        oracle_edge_confidence_pile(vol, V, S, U, C, s, Ce_svu + (size_t)s * n, mask_svu + (size_t)s * n, p);
+}
+
+void oracle_depth_epi_2d(const float* vol, int V, int S, int U, int C,
+                         const float* dmin_svu, const float* dmax_svu, int dim_d,
+                         float* Ce_svu, uint8_t* Ce_mask_svu, float* Cd_svu,
+                         float* depth_svu, float* rbar_svu, const oracle_params* p,
+                         float propagation_epsilon, uint8_t* scan_mask_svu)
+{
+    const size_t n = (size_t)V * U;
+    const int s_mid = (int)floor(S / 2.0); /* core.hpp:954 */
+
+    /* core.hpp:958-965: running masks start as clones of the edge masks */
+    uint8_t* mask_svu = (uint8_t*)malloc((size_t)S * n);
+    memcpy(mask_svu, Ce_mask_svu, (size_t)S * n);
+
+    /* core.hpp:981-990: visiting order */
+    int* order = (int*)malloc(sizeof(int) * (size_t)(2 * S + 2));
+    int n_order = 0;
+    order[n_order++] = s_mid;
+    for (int off = 1; off < S - s_mid; off++) {
+        order[n_order++] = s_mid + off;
+        if (s_mid - off > -1)
+            order[n_order++] = s_mid - off;
+    }
+
+    float* filtered = (float*)malloc(sizeof(float) * n);
+    float* tmp = (float*)malloc(sizeof(float) * n);
+
+    for (int k = 0; k < n_order; k++) {
+        const int s_hat = order[k];
+        float* Ce = Ce_svu + (size_t)s_hat * n;
+        uint8_t* Cem = Ce_mask_svu + (size_t)s_hat * n;
+        float* Cd = Cd_svu + (size_t)s_hat * n;
+        float* depth = depth_svu + (size_t)s_hat * n;
+        float* rbar = rbar_svu + (size_t)s_hat * n * C;
+        uint8_t* mask = mask_svu + (size_t)s_hat * n;
+
+        /* core.hpp:1012-1028: the pile scan writes raw depths into the stored plane ... */
+        memcpy(tmp, depth, sizeof(float) * n);
+        oracle_depth_epi_pile(vol, V, S, U, C, dmin_svu + (size_t)s_hat * n, dmax_svu + (size_t)s_hat * n,
+                              dim_d, s_hat, Ce, Cem, Cd, tmp, rbar, p, mask, NULL, NULL, depth);
+        /* ... (depth now holds the pre-median plane, as the storage does after core.hpp:819-854)
+         * and core.hpp:892 leaves the median in the local header only: */
+        memcpy(filtered, tmp, sizeof(float) * n);
+
+        /* core.hpp:1088-1129: propagation, rows in parallel, u ascending within a row */
+#pragma omp parallel for schedule(static)
+        for (int v = 0; v < V; v++) {
+            for (int u = 0; u < U; u++) {
+                if (!Cem[(size_t)v * U + u]) /* core.hpp:1103 */
+                    continue;
+                const float cur = filtered[(size_t)v * U + u];
+                const float* rb = rbar + ((size_t)v * U + u) * C;
+                for (int s = 0; s < S; s++) {
+                    /* core.hpp:1109: u + (int)std::round(depth * (s_hat - s) * slope) */
+                    float off = cur * (float)(s_hat - s);
+                    off = off * p->slope_factor;
+                    const int ri = u + (int)roundf(off);
+                    if (ri > -1 && ri < U && mask_svu[(size_t)s * n + (size_t)v * U + ri]) {
+                        const float* e = vol + (((size_t)v * S + s) * U + ri) * C;
+                        float df[3];
+                        for (int c = 0; c < C; c++)
+                            df[c] = e[c] - rb[c];
+                        if (norm_px(df, C) < propagation_epsilon) { /* core.hpp:1116 */
+                            depth_svu[(size_t)s * n + (size_t)v * U + ri] = cur;
+                            mask_svu[(size_t)s * n + (size_t)v * U + ri] = 0;
+                            Cd_svu[(size_t)s * n + (size_t)v * U + ri] = Cd[(size_t)v * U + u];
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (scan_mask_svu)
+        memcpy(scan_mask_svu, mask_svu, (size_t)S * n);
+    free(filtered);
+    free(tmp);
+    free(order);
+    free(mask_svu);
+}
+
+void oracle_depth2d_run(const float* vol, int V, int S, int U, int C,
+                        float dmin, float dmax, int dim_d, const oracle_params* p,
+                        float propagation_epsilon,
+                        float* Ce_svu, uint8_t* Ce_mask_svu, float* Cd_svu,
+                        float* depth_svu, float* rbar_svu, uint8_t* scan_mask_svu)
+{
+    const size_t n = (size_t)S * V * U;
+    float* dmin_svu = (float*)malloc(sizeof(float) * n);
+    float* dmax_svu = (float*)malloc(sizeof(float) * n);
+    for (size_t i = 0; i < n; i++) { /* dc.hpp:718-722 */
+        dmin_svu[i] = dmin;
+        dmax_svu[i] = dmax;
+    }
+    memset(Ce_svu, 0, sizeof(float) * n);   /* uninitialised in the reference (dc.hpp:735) */
+    memset(Cd_svu, 0, sizeof(float) * n);   /* uninitialised in the reference (dc.hpp:738) */
+    memset(depth_svu, 0, sizeof(float) * n);       /* dc.hpp:746 */
+    memset(rbar_svu, 0, sizeof(float) * n * C);    /* dc.hpp:749 */
+    oracle_edge_confidence_2d(vol, V, S, U, C, Ce_svu, Ce_mask_svu, p);   /* dc.hpp:772 */
+    oracle_depth_epi_2d(vol, V, S, U, C, dmin_svu, dmax_svu, dim_d, Ce_svu, Ce_mask_svu, Cd_svu, depth_svu,
+                        rbar_svu, p, propagation_epsilon, scan_mask_svu);      /* dc.hpp:780 */
+    free(dmin_svu);
+    free(dmax_svu);
+}

@@ -119,6 +119,38 @@ void oracle_depth1d_pile_run(const float* vol, int V, int S, int U, int C,
                              int32_t* idx_vu, float* score_vu,
                              float* depth_raw_vu);
 
+/* ---- "next" row: the 2-D sweep -------------------- */
+
+/* compute_2D_edge_confidence (core.hpp:901-931): the pile edge confidence for
+ * every view s.  Ce_svu [S][V][U] accumulates (pass zeros), mask_svu [S][V][U]. */
+void oracle_edge_confidence_2d(const float* vol, int V, int S, int U, int C,
+                               float* Ce_svu, uint8_t* mask_svu, const oracle_params* p);
+
+/* compute_2D_depth_epi (core.hpp:933-1133), default build (neither
+ * _USE_DISP_CONFIDENCE_SCORE nor _USE_LINE_CONFIDENCE_SCORE: propagation is gated
+ * by the edge mask, core.hpp:1099-1103).  Views are visited s_hat, s_hat+1,
+ * s_hat-1, ... (core.hpp:981-990); each visit runs the pile scan with the running
+ * mask (core.hpp:1012-1028) and then paints its disparities along their EPI lines
+ * into the other views (core.hpp:1088-1129).
+ *   dmin_svu/dmax_svu [S][V][U]; Ce_svu, Ce_mask_svu in/out; Cd_svu, depth_svu,
+ *   rbar_svu ([S][V][U][C]) in/out (pass zeros); scan_mask_svu (nullable) receives
+ *   the final running masks.
+ * Note core.hpp:892 rebinds only the LOCAL header best_depth_v_u to the median
+ * result: the stored plane of the visited view keeps the raw arg-max depths and
+ * then receives the median-filtered values the propagation paints into it. */
+void oracle_depth_epi_2d(const float* vol, int V, int S, int U, int C,
+                         const float* dmin_svu, const float* dmax_svu, int dim_d,
+                         float* Ce_svu, uint8_t* Ce_mask_svu, float* Cd_svu,
+                         float* depth_svu, float* rbar_svu, const oracle_params* p,
+                         float propagation_epsilon, uint8_t* scan_mask_svu);
+
+/* Depth2DComputer ctor + run() (dc.hpp:651-805) on a normalised volume. */
+void oracle_depth2d_run(const float* vol, int V, int S, int U, int C,
+                        float dmin, float dmax, int dim_d, const oracle_params* p,
+                        float propagation_epsilon,
+                        float* Ce_svu, uint8_t* Ce_mask_svu, float* Cd_svu,
+                        float* depth_svu, float* rbar_svu, uint8_t* scan_mask_svu);
+
 int oracle_num_threads(void);
 void oracle_set_num_threads(int n);
 

@@ -23,6 +23,7 @@ SYMBOLS = [
     "rslf_volume_upload_images_f32", "rslf_volume_upload_images_u8", "rslf_volume_pack_device_f32",
     "rslf_edge_confidence_pile", "rslf_depth_epi_pile", "rslf_selective_median",
     "rslf_depth1d_pile_run", "rslf_depth1d_pile_run_host", "rslf_last_scan_kernel_ms",
+    "rslf_edge_confidence_2d", "rslf_depth_epi_2d", "rslf_depth2d_run",
 ]
 
 
@@ -124,6 +125,9 @@ def lib():
                                         C.POINTER(RslfStats)]
     L.rslf_depth1d_pile_run_host.argtypes = L.rslf_depth1d_pile_run.argtypes
     L.rslf_last_scan_kernel_ms.argtypes = [vp, C.POINTER(cf)]
+    L.rslf_edge_confidence_2d.argtypes = [vp, vp, C.POINTER(RslfParams), vp, vp]
+    L.rslf_depth_epi_2d.argtypes = [vp, vp, vp, vp, cf, cf, ci, vp, vp, vp, vp, vp, C.POINTER(RslfParams), vp, C.POINTER(RslfStats)]
+    L.rslf_depth2d_run.argtypes = [vp, vp, cf, cf, ci, C.POINTER(RslfParams), vp, vp, vp, vp, vp, vp, C.POINTER(RslfStats)]
     for name in SYMBOLS:
         f = getattr(L, name)   # AttributeError here = the library does not export the ABI
         if f.restype is C.c_int and name not in ("rslf_abi_version", "rslf_device_count"):

@@ -1,0 +1,84 @@
+// K4: disparity propagation of the 2-D sweep ("next" row).
+//
+// rslf::compute_2D_depth_epi, propagation part
+// (include/rslf_depth_computation_core.hpp:1088-1129, default build: gated by the edge mask,
+// :1099-1103).  For every confident pixel u of the visited view s_hat (ascending u within a
+// scanline), the reference paints its disparity into every view s at column
+// u + round(d * (s_hat - s) * slope) if that pixel is still in the running mask and its radiance is
+// within propagation_epsilon of rbar(u); painting clears the mask, so the FIRST u (smallest) that
+// qualifies wins a target pixel.  Qualifying does not depend on the order (the mask test only asks
+// "not painted yet in this or an earlier visit"), so the sequential loop equals:
+//   claim:  every source does atomicMin(winner[target], u) on the targets it qualifies for
+//   apply:  every claimed target takes the values of its winner and leaves the mask.
+// Both passes are HBM-bound streaming kernels (a few bytes per (s, v, u)).
+#pragma once
+
+#include "rslf_device.hpp"
+
+namespace rslf {
+
+constexpr int kNoWinner = 0x7F7F7F7F;   // what hipMemset(0x7F) leaves; >= any column index
+
+template <int C>
+__global__ __launch_bounds__(256) void k4_propagate_claim(VolView vol, int s_hat, const float* __restrict__ filtered_vu,
+                                                         const uint8_t* __restrict__ edge_mask_vu,
+                                                         const float* __restrict__ rbar_vu,
+                                                         const uint8_t* __restrict__ mask_svu, int* __restrict__ winner_svu,
+                                                         float slope, float prop_eps)
+{
+    const int v = blockIdx.y;
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= vol.U)
+        return;
+    const long long o = (long long)v * vol.U + u;
+    if (!edge_mask_vu[o])   // core.hpp:1103
+        return;
+    const float cur = filtered_vu[o];
+    float rb[C];
+#pragma unroll
+    for (int c = 0; c < C; c++)
+        rb[c] = rbar_vu[o * C + c];
+    const long long plane = (long long)vol.V * vol.U;
+    for (int s = 0; s < vol.S; s++) {
+        // core.hpp:1109: u + (int)std::round(depth * (s_hat - s) * slope_factor)
+        float off = cur * (float)(s_hat - s);
+        off = off * slope;
+        const int ri = u + (int)roundf(off);
+        if (ri < 0 || ri >= vol.U)
+            continue;
+        const long long t = (long long)s * plane + (long long)v * vol.U + ri;
+        if (!mask_svu[t])
+            continue;
+        const float* e = vol.row(v, s, 0);
+        float df[C];
+#pragma unroll
+        for (int c = 0; c < C; c++)
+            df[c] = e[(long long)c * vol.pitch + ri] - rb[c];
+        const float nr = (C == 1) ? norm1(df[0]) : norm3(df[0], df[C > 1 ? 1 : 0], df[C > 2 ? 2 : 0]);
+        if (nr < prop_eps)   // core.hpp:1116
+            atomicMin(&winner_svu[t], u);
+    }
+}
+
+__global__ __launch_bounds__(256) void k4_propagate_apply(int S, int V, int U, int s_hat, const float* __restrict__ filtered_vu,
+                                                         const float* __restrict__ Cd_hat_vu, float* __restrict__ depth_svu,
+                                                         float* __restrict__ Cd_svu, uint8_t* __restrict__ mask_svu,
+                                                         int* __restrict__ winner_svu)
+{
+    const long long plane = (long long)V * U;
+    const long long n = (long long)S * plane;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
+        const int w = winner_svu[t];
+        if (w >= U)
+            continue;
+        const long long vu = t % plane;
+        const long long src = vu - (vu % U) + w;     // (v, w)
+        // s == s_hat: w == u, both assignments are self-assignments (core.hpp:1119-1121)
+        depth_svu[t] = filtered_vu[src];
+        Cd_svu[t] = Cd_hat_vu[src];
+        mask_svu[t] = 0;
+        winner_svu[t] = kNoWinner;
+    }
+}
+
+}  // namespace rslf

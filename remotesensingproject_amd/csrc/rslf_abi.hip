@@ -16,6 +16,7 @@
 #include "k1_edge.hpp"
 #include "k2_scan.hpp"
 #include "k3_median.hpp"
+#include "k4_propagate.hpp"
 
 using namespace rslf;
 
@@ -59,6 +60,13 @@ struct rslf_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool ev_valid = false;
     int last_spad = 0;   // register-scan slot count of the last K2 launch, 0 = generic
+    bool keep_total = false;   // the 2-D sweep sums the scanned pixels of all its visits
+    // 2-D sweep scratch
+    int* winner = nullptr;        // [S][V][U]
+    uint8_t* sweep_mask = nullptr;
+    float* filtered = nullptr;    // [V][U]
+    float* raw = nullptr;         // [V][U]
+    size_t sweep_cap = 0;
 };
 
 struct rslf_volume {
@@ -242,6 +250,10 @@ extern "C" int rslf_ctx_destroy(rslf_ctx* ctx)
     (void)hipFree(ctx->partial);
     (void)hipFree(ctx->minmax);
     (void)hipFree(ctx->staging);
+    (void)hipFree(ctx->winner);
+    (void)hipFree(ctx->sweep_mask);
+    (void)hipFree(ctx->filtered);
+    (void)hipFree(ctx->raw);
     if (ctx->ev0)
         (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1)
@@ -660,7 +672,8 @@ extern "C" int rslf_depth_epi_pile(rslf_ctx* ctx, const rslf_volume* vol, const 
         HIP_TRY(hipMemsetAsync(d_idx_vu, 0xFF, n * sizeof(int32_t), st));   // -1
     if (d_score_vu)
         HIP_TRY(hipMemsetAsync(d_score_vu, 0, n * sizeof(float), st));
-    HIP_TRY(hipMemsetAsync(ctx->total, 0, sizeof(unsigned long long), st));
+    if (!ctx->keep_total)
+        HIP_TRY(hipMemsetAsync(ctx->total, 0, sizeof(unsigned long long), st));
 
     hipLaunchKernelGGL(k_compact_mask, dim3(vol->V), dim3(256), 0, st, d_Ce_mask_vu, d_mask_vu, vol->U, ctx->list, ctx->count,
                        ctx->total);
@@ -824,6 +837,146 @@ extern "C" int rslf_depth1d_pile_run_host(rslf_ctx* ctx, const rslf_volume* vol,
     }
     (void)hipFree(blk);
     return rc;
+}
+
+// ---- "next" row: the 2-D sweep ----------------------------------------------
+
+extern "C" int rslf_edge_confidence_2d(rslf_ctx* ctx, const rslf_volume* vol, const rslf_params* p, float* d_Ce_svu,
+                                       uint8_t* d_Ce_mask_svu)
+{
+    if (!ctx || !vol || !d_Ce_svu || !d_Ce_mask_svu)
+        return fail(RSLF_ERR_INVALID_ARG, "NULL argument");
+    const size_t n = (size_t)vol->V * vol->U;
+    for (int s = 0; s < vol->S; s++) {   // core.hpp:918-934
+        int rc = rslf_edge_confidence_pile(ctx, vol, s, p, d_Ce_svu + (size_t)s * n, d_Ce_mask_svu + (size_t)s * n);
+        if (rc)
+            return rc;
+    }
+    return RSLF_OK;
+}
+
+static int ensure_sweep_scratch(rslf_ctx* ctx, const rslf_volume* vol)
+{
+    const size_t n = (size_t)vol->S * vol->V * vol->U;
+    if (n > ctx->sweep_cap) {
+        (void)hipFree(ctx->winner);
+        (void)hipFree(ctx->sweep_mask);
+        (void)hipFree(ctx->filtered);
+        (void)hipFree(ctx->raw);
+        ctx->winner = nullptr;
+        ctx->sweep_mask = nullptr;
+        ctx->filtered = nullptr;
+        ctx->raw = nullptr;
+        ctx->sweep_cap = 0;
+        HIP_TRY(hipMalloc(&ctx->winner, n * sizeof(int)));
+        HIP_TRY(hipMalloc(&ctx->sweep_mask, n));
+        HIP_TRY(hipMalloc(&ctx->filtered, (size_t)vol->V * vol->U * sizeof(float)));
+        HIP_TRY(hipMalloc(&ctx->raw, (size_t)vol->V * vol->U * sizeof(float)));
+        ctx->sweep_cap = n;
+        // every claim pass is undone by its apply pass, so one fill lasts
+        HIP_TRY(hipMemsetAsync(ctx->winner, 0x7F, n * sizeof(int), ctx->stream));
+    }
+    return RSLF_OK;
+}
+
+extern "C" int rslf_depth_epi_2d(rslf_ctx* ctx, const rslf_volume* vol, const float* d_dmin_svu, const float* d_dmax_svu,
+                                 float dmin, float dmax, int dim_d, float* d_Ce_svu, uint8_t* d_Ce_mask_svu, float* d_Cd_svu,
+                                 float* d_depth_svu, float* d_rbar_svu, const rslf_params* p, uint8_t* d_scan_mask_svu,
+                                 rslf_stats* stats)
+{
+    if (!ctx || !vol || !d_Ce_svu || !d_Ce_mask_svu || !d_Cd_svu || !d_depth_svu || !d_rbar_svu)
+        return fail(RSLF_ERR_INVALID_ARG, "NULL argument");
+    int rc = check_params(p);
+    if (rc)
+        return rc;
+    if ((d_dmin_svu == nullptr) != (d_dmax_svu == nullptr))
+        return fail(RSLF_ERR_INVALID_ARG, "d_dmin_svu and d_dmax_svu must both be given or both be NULL");
+    HIP_TRY(hipSetDevice(ctx->device));
+    rc = ensure_sweep_scratch(ctx, vol);
+    if (rc)
+        return rc;
+    const int S = vol->S, V = vol->V, U = vol->U, C = vol->C;
+    const size_t n = (size_t)V * U;
+    hipStream_t st = ctx->stream;
+    uint8_t* mask_svu = d_scan_mask_svu ? d_scan_mask_svu : ctx->sweep_mask;
+    // core.hpp:958-965: running masks start as clones of the edge masks
+    HIP_TRY(hipMemcpyAsync(mask_svu, d_Ce_mask_svu, (size_t)S * n, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemsetAsync(ctx->total, 0, sizeof(unsigned long long), st));
+
+    std::vector<int> order;   // core.hpp:981-990
+    const int s_mid = (int)std::floor(S / 2.0);
+    order.push_back(s_mid);
+    for (int off = 1; off < S - s_mid; off++) {
+        order.push_back(s_mid + off);
+        if (s_mid - off > -1)
+            order.push_back(s_mid - off);
+    }
+
+    const dim3 grid_vu((U + 255) / 256, V);
+    const unsigned apply_blocks = (unsigned)std::min<size_t>(((size_t)S * n + 255) / 256, 256 * 8 * 4);
+    ctx->keep_total = true;
+    for (int s_hat : order) {
+        float* depth = d_depth_svu + (size_t)s_hat * n;
+        float* Cd = d_Cd_svu + (size_t)s_hat * n;
+        float* rbar = d_rbar_svu + (size_t)s_hat * n * C;
+        uint8_t* cem = d_Ce_mask_svu + (size_t)s_hat * n;
+        // core.hpp:1012-1028.  The pile call leaves the median in `depth` and the raw plane in ctx->raw ...
+        rc = rslf_depth_epi_pile(ctx, vol, d_dmin_svu ? d_dmin_svu + (size_t)s_hat * n : nullptr,
+                                 d_dmax_svu ? d_dmax_svu + (size_t)s_hat * n : nullptr, dmin, dmax, dim_d, s_hat,
+                                 d_Ce_svu + (size_t)s_hat * n, cem, Cd, depth, rbar, p, mask_svu + (size_t)s_hat * n, nullptr,
+                                 nullptr, ctx->raw, nullptr);
+        if (rc) {
+            ctx->keep_total = false;
+            return rc;
+        }
+        // ... while in the reference the stored plane keeps the RAW depths and only the local header is
+        // rebound to the median (core.hpp:892): put them where the reference has them.
+        HIP_TRY(hipMemcpyAsync(ctx->filtered, depth, n * sizeof(float), hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipMemcpyAsync(depth, ctx->raw, n * sizeof(float), hipMemcpyDeviceToDevice, st));
+        // core.hpp:1088-1129
+        if (C == 1)
+            hipLaunchKernelGGL(k4_propagate_claim<1>, grid_vu, dim3(256), 0, st, view_of(vol), s_hat, ctx->filtered, cem, rbar,
+                               mask_svu, ctx->winner, p->slope_factor, p->propagation_epsilon);
+        else
+            hipLaunchKernelGGL(k4_propagate_claim<3>, grid_vu, dim3(256), 0, st, view_of(vol), s_hat, ctx->filtered, cem, rbar,
+                               mask_svu, ctx->winner, p->slope_factor, p->propagation_epsilon);
+        HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(k4_propagate_apply, dim3(apply_blocks), dim3(256), 0, st, S, V, U, s_hat, ctx->filtered, Cd,
+                           d_depth_svu, d_Cd_svu, mask_svu, ctx->winner);
+        HIP_TRY(hipGetLastError());
+    }
+    ctx->keep_total = false;
+    if (stats) {
+        unsigned long long tot = 0;
+        HIP_TRY(hipMemcpyAsync(&tot, ctx->total, sizeof(tot), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        stats->pixels_scanned = (int64_t)tot;
+        stats->units = (int64_t)tot * dim_d;
+        stats->scan_kernel = ctx->last_spad ? RSLF_SCAN_REG : RSLF_SCAN_GENERIC;
+        stats->s_pad = ctx->last_spad;
+    }
+    return RSLF_OK;
+}
+
+extern "C" int rslf_depth2d_run(rslf_ctx* ctx, const rslf_volume* vol, float dmin, float dmax, int dim_d, const rslf_params* p,
+                                float* d_Ce_svu, uint8_t* d_Ce_mask_svu, float* d_Cd_svu, float* d_depth_svu, float* d_rbar_svu,
+                                uint8_t* d_scan_mask_svu, rslf_stats* stats)
+{
+    if (!ctx || !vol || !d_Ce_svu || !d_Ce_mask_svu || !d_Cd_svu || !d_depth_svu || !d_rbar_svu)
+        return fail(RSLF_ERR_INVALID_ARG, "NULL argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t n = (size_t)vol->S * vol->V * vol->U;
+    hipStream_t st = ctx->stream;
+    // dc.hpp:733-750 (C_e and C_d are uninitialised there; zero is the intended start)
+    HIP_TRY(hipMemsetAsync(d_Ce_svu, 0, n * sizeof(float), st));
+    HIP_TRY(hipMemsetAsync(d_Cd_svu, 0, n * sizeof(float), st));
+    HIP_TRY(hipMemsetAsync(d_depth_svu, 0, n * sizeof(float), st));
+    HIP_TRY(hipMemsetAsync(d_rbar_svu, 0, n * vol->C * sizeof(float), st));
+    int rc = rslf_edge_confidence_2d(ctx, vol, p, d_Ce_svu, d_Ce_mask_svu);   // dc.hpp:772
+    if (rc)
+        return rc;
+    return rslf_depth_epi_2d(ctx, vol, nullptr, nullptr, dmin, dmax, dim_d, d_Ce_svu, d_Ce_mask_svu, d_Cd_svu, d_depth_svu,   // dc.hpp:780
+                             d_rbar_svu, p, d_scan_mask_svu, stats);
 }
 
 extern "C" int rslf_last_scan_kernel_ms(rslf_ctx* ctx, float* ms)

@@ -336,3 +336,99 @@ class Depth1DComputer_pile:
             score=self.m_score_v_u.cpu().numpy(),
             depth_raw=self.m_depth_raw_v_u.cpu().numpy(),
         )
+
+
+# ---- "next" row: the 2-D sweep -------------------------
+
+def compute_2D_edge_confidence(vol: Volume, a_edge_confidence_s_v_u: torch.Tensor,
+                               a_parameters: Depth1DParameters | None = None) -> torch.Tensor:
+    """core.hpp:323-330.  Accumulates into a_edge_confidence_s_v_u ([S,V,U] f32, pass zeros);
+    returns the masks [S,V,U] u8."""
+    p = (a_parameters or Depth1DParameters()).to_c()
+    mask = torch.empty((vol.S, vol.V, vol.U), dtype=torch.uint8, device=a_edge_confidence_s_v_u.device)
+    vol.ctx.use_current_stream()
+    check(_lib.lib().rslf_edge_confidence_2d(vol.ctx._h, vol._h, C.byref(p), _ptr(a_edge_confidence_s_v_u), _ptr(mask)),
+          "rslf_edge_confidence_2d")
+    return mask
+
+
+def compute_2D_depth_epi(vol: Volume, a_dmin_s_v_u, a_dmax_s_v_u, a_dim_d: int, a_edge_confidence_s_v_u: torch.Tensor,
+                         a_edge_confidence_mask_s_v_u: torch.Tensor, a_disp_confidence_s_v_u: torch.Tensor,
+                         a_best_depth_s_v_u: torch.Tensor, a_rbar_s_v_u: torch.Tensor,
+                         a_parameters: Depth1DParameters | None = None, *, scan_mask_s_v_u: torch.Tensor | None = None,
+                         want_stats: bool = False) -> RslfStats | None:
+    """core.hpp:336-351 (the line-confidence argument does not exist in the default build).
+    a_dmin_s_v_u / a_dmax_s_v_u: [S,V,U] f32 CUDA tensors or Python floats."""
+    p = (a_parameters or Depth1DParameters()).to_c()
+    planes = isinstance(a_dmin_s_v_u, torch.Tensor)
+    st = RslfStats() if want_stats else None
+    vol.ctx.use_current_stream()
+    check(_lib.lib().rslf_depth_epi_2d(
+        vol.ctx._h, vol._h, _ptr(a_dmin_s_v_u if planes else None), _ptr(a_dmax_s_v_u if planes else None),
+        0.0 if planes else float(a_dmin_s_v_u), 0.0 if planes else float(a_dmax_s_v_u), a_dim_d,
+        _ptr(a_edge_confidence_s_v_u), _ptr(a_edge_confidence_mask_s_v_u), _ptr(a_disp_confidence_s_v_u),
+        _ptr(a_best_depth_s_v_u), _ptr(a_rbar_s_v_u), C.byref(p), _ptr(scan_mask_s_v_u),
+        C.byref(st) if st is not None else None), "rslf_depth_epi_2d")
+    return st
+
+
+class Depth2DComputer:
+    """rslf::Depth2DComputer<T> (dc.hpp:166-225, :651-805): disparities for every view of the light field,
+    visiting the views from the centre outwards and propagating along EPI lines."""
+
+    def __init__(self, epis, dmin: float, dmax: float, dim_d: int, epi_scale_factor: float = -1.0,
+                 parameters: Depth1DParameters | None = None, verbose: bool = False, ctx: Context | None = None):
+        self.m_parameters = parameters or Depth1DParameters.get_default()
+        if isinstance(epis, Volume):
+            self.m_epis = epis
+        elif isinstance(epis, (list, tuple)):
+            self.m_epis = Volume.from_epis(epis, epi_scale_factor, ctx)
+        elif isinstance(epis, np.ndarray):
+            a = epis[..., 0] if (epis.ndim == 4 and epis.shape[3] == 1) else epis
+            self.m_epis = Volume.from_epis(list(a), epi_scale_factor, ctx)
+        else:
+            self.m_epis = Volume.from_dense(epis, epi_scale_factor if epi_scale_factor > 0 else 1.0, ctx)
+        vol = self.m_epis
+        self.m_dim_d, self.m_dmin, self.m_dmax = int(dim_d), float(dmin), float(dmax)
+        self.m_accept_all = False
+        dev = vol.ctx.device
+        S, V, U, C_ = vol.S, vol.V, vol.U, vol.C
+        self.m_edge_confidence_s_v_u = torch.empty((S, V, U), dtype=torch.float32, device=dev)
+        self.m_edge_confidence_mask_s_v_u = torch.empty((S, V, U), dtype=torch.uint8, device=dev)
+        self.m_disp_confidence_s_v_u = torch.empty((S, V, U), dtype=torch.float32, device=dev)
+        self.m_best_depth_s_v_u = torch.empty((S, V, U), dtype=torch.float32, device=dev)
+        self.m_rbar_s_v_u = torch.empty((S, V, U, C_), dtype=torch.float32, device=dev)
+        self.m_scan_mask_s_v_u = torch.empty((S, V, U), dtype=torch.uint8, device=dev)
+        self.stats: RslfStats | None = None
+
+    def run(self, want_stats: bool = True) -> None:
+        """dc.hpp:748-805."""
+        vol = self.m_epis
+        p = self.m_parameters.to_c()
+        st = RslfStats() if want_stats else None
+        vol.ctx.use_current_stream()
+        check(_lib.lib().rslf_depth2d_run(
+            vol.ctx._h, vol._h, self.m_dmin, self.m_dmax, self.m_dim_d, C.byref(p), _ptr(self.m_edge_confidence_s_v_u),
+            _ptr(self.m_edge_confidence_mask_s_v_u), _ptr(self.m_disp_confidence_s_v_u), _ptr(self.m_best_depth_s_v_u),
+            _ptr(self.m_rbar_s_v_u), _ptr(self.m_scan_mask_s_v_u), C.byref(st) if st is not None else None),
+            "rslf_depth2d_run")
+        self.stats = st
+
+    def get_depths_s_v_u(self) -> torch.Tensor:
+        return self.m_best_depth_s_v_u
+
+    def set_accept_all(self, b: bool) -> None:
+        self.m_accept_all = bool(b)
+
+    def get_valid_depths_mask_s_v_u(self) -> torch.Tensor:
+        """dc.hpp:893-915, default build: C_e > edge threshold (or everything > -1 with accept_all)."""
+        thr = -1.0 if self.m_accept_all else float(np.float32(self.m_parameters.par_edge_score_threshold))
+        return (self.m_edge_confidence_s_v_u > thr).to(torch.uint8) * 255
+
+    def results(self) -> dict:
+        torch.cuda.synchronize(self.m_epis.ctx.device)
+        return dict(edge_confidence=self.m_edge_confidence_s_v_u.cpu().numpy(),
+                    edge_mask=self.m_edge_confidence_mask_s_v_u.cpu().numpy(),
+                    disp_confidence=self.m_disp_confidence_s_v_u.cpu().numpy(),
+                    depth=self.m_best_depth_s_v_u.cpu().numpy(), rbar=self.m_rbar_s_v_u.cpu().numpy(),
+                    scan_mask=self.m_scan_mask_s_v_u.cpu().numpy())
