@@ -163,6 +163,24 @@ int rslf_depth_epi_pile(rslf_ctx* ctx, const rslf_volume* vol,
                         int32_t* d_idx_vu, float* d_score_vu, float* d_depth_raw_vu,
                         rslf_stats* stats);
 
+/* rslf::compute_1D_depth_epi -- core.hpp:251-267, impl :480-661 -- for every EPI of the volume and
+ * nothing else (no selective median): the first half of rslf_depth_epi_pile, same arguments, and all
+ * the single-EPI class rslf::Depth1DComputer<T> needs. */
+int rslf_depth_epi_scan(rslf_ctx* ctx, const rslf_volume* vol,
+                        const float* d_dmin_vu, const float* d_dmax_vu, float dmin, float dmax,
+                        int dim_d, int s_hat,
+                        float* d_Ce_vu, uint8_t* d_Ce_mask_vu, float* d_Cd_vu, float* d_depth_vu,
+                        float* d_rbar_vu, const rslf_params* p, uint8_t* d_mask_vu,
+                        int32_t* d_idx_vu, float* d_score_vu, rslf_stats* stats);
+
+/* rslf::Depth1DComputer<T>::run() -- include/rslf_depth_computation.hpp:325-371 with the
+ * constructor's zero-filled outputs (:313-322): edge confidence and scan of each EPI on its own, no
+ * median.  The reference's class holds one EPI; a volume of V EPIs is V independent instances. */
+int rslf_depth1d_run(rslf_ctx* ctx, const rslf_volume* vol, float dmin, float dmax, int dim_d, int s_hat,
+                     const rslf_params* p,
+                     float* d_Ce_vu, uint8_t* d_Ce_mask_vu, float* d_Cd_vu, float* d_depth_vu,
+                     float* d_rbar_vu, int32_t* d_idx_vu, float* d_score_vu, rslf_stats* stats);
+
 /* rslf::selective_median_filter -- core.hpp:366-375, impl :663-718.
  * d_dst_vu must not alias d_src_vu; it is fully written (0 where mask is 0). */
 int rslf_selective_median(rslf_ctx* ctx, const rslf_volume* vol, const float* d_src_vu, float* d_dst_vu,

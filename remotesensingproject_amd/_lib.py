@@ -24,6 +24,7 @@ SYMBOLS = [
     "rslf_edge_confidence_pile", "rslf_depth_epi_pile", "rslf_selective_median",
     "rslf_depth1d_pile_run", "rslf_depth1d_pile_run_host", "rslf_last_scan_kernel_ms",
     "rslf_edge_confidence_2d", "rslf_depth_epi_2d", "rslf_depth2d_run",
+    "rslf_depth_epi_scan", "rslf_depth1d_run",
 ]
 
 
@@ -121,6 +122,10 @@ def lib():
     L.rslf_depth_epi_pile.argtypes = [vp, vp, vp, vp, cf, cf, ci, ci, vp, vp, vp, vp, vp, C.POINTER(RslfParams),
                                       vp, vp, vp, vp, C.POINTER(RslfStats)]
     L.rslf_selective_median.argtypes = [vp, vp, vp, vp, ci, ci, vp, cf]
+    L.rslf_depth_epi_scan.argtypes = [vp, vp, vp, vp, cf, cf, ci, ci, vp, vp, vp, vp, vp, C.POINTER(RslfParams),
+                                      vp, vp, vp, C.POINTER(RslfStats)]
+    L.rslf_depth1d_run.argtypes = [vp, vp, cf, cf, ci, ci, C.POINTER(RslfParams), vp, vp, vp, vp, vp, vp, vp,
+                                   C.POINTER(RslfStats)]
     L.rslf_depth1d_pile_run.argtypes = [vp, vp, cf, cf, ci, ci, C.POINTER(RslfParams), vp, vp, vp, vp, vp, vp, vp, vp,
                                         C.POINTER(RslfStats)]
     L.rslf_depth1d_pile_run_host.argtypes = L.rslf_depth1d_pile_run.argtypes

@@ -642,11 +642,18 @@ static int pick_spad(int S, int C)
     return best;
 }
 
-extern "C" int rslf_depth_epi_pile(rslf_ctx* ctx, const rslf_volume* vol, const float* d_dmin_vu, const float* d_dmax_vu,
+static void fill_stats(rslf_ctx* ctx, unsigned long long tot, int dim_d, rslf_stats* stats)
+{
+    stats->pixels_scanned = (int64_t)tot;
+    stats->units = (int64_t)tot * dim_d;
+    stats->scan_kernel = ctx->last_spad ? RSLF_SCAN_REG : RSLF_SCAN_GENERIC;
+    stats->s_pad = ctx->last_spad;
+}
+
+extern "C" int rslf_depth_epi_scan(rslf_ctx* ctx, const rslf_volume* vol, const float* d_dmin_vu, const float* d_dmax_vu,
                                    float dmin, float dmax, int dim_d, int s_hat, float* d_Ce_vu, uint8_t* d_Ce_mask_vu,
                                    float* d_Cd_vu, float* d_depth_vu, float* d_rbar_vu, const rslf_params* p,
-                                   uint8_t* d_mask_vu, int32_t* d_idx_vu, float* d_score_vu, float* d_depth_raw_vu,
-                                   rslf_stats* stats)
+                                   uint8_t* d_mask_vu, int32_t* d_idx_vu, float* d_score_vu, rslf_stats* stats)
 {
     if (!ctx || !vol || !d_Ce_vu || !d_Ce_mask_vu || !d_Cd_vu || !d_depth_vu || !d_rbar_vu)
         return fail(RSLF_ERR_INVALID_ARG, "NULL argument");
@@ -729,10 +736,32 @@ extern "C" int rslf_depth_epi_pile(rslf_ctx* ctx, const rslf_volume* vol, const 
     HIP_TRY(hipEventRecord(ctx->ev1, st));
     ctx->ev_valid = true;
 
+    if (stats) {
+        unsigned long long tot = 0;
+        HIP_TRY(hipMemcpyAsync(&tot, ctx->total, sizeof(tot), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        fill_stats(ctx, tot, dim_d, stats);
+    }
+    return RSLF_OK;
+}
+
+extern "C" int rslf_depth_epi_pile(rslf_ctx* ctx, const rslf_volume* vol, const float* d_dmin_vu, const float* d_dmax_vu,
+                                   float dmin, float dmax, int dim_d, int s_hat, float* d_Ce_vu, uint8_t* d_Ce_mask_vu,
+                                   float* d_Cd_vu, float* d_depth_vu, float* d_rbar_vu, const rslf_params* p,
+                                   uint8_t* d_mask_vu, int32_t* d_idx_vu, float* d_score_vu, float* d_depth_raw_vu,
+                                   rslf_stats* stats)
+{
+    // core.hpp:799-854: the scan of every EPI ...
+    int rc = rslf_depth_epi_scan(ctx, vol, d_dmin_vu, d_dmax_vu, dmin, dmax, dim_d, s_hat, d_Ce_vu, d_Ce_mask_vu, d_Cd_vu,
+                                 d_depth_vu, d_rbar_vu, p, d_mask_vu, d_idx_vu, d_score_vu, nullptr);
+    if (rc)
+        return rc;
+    const size_t n = (size_t)vol->V * vol->U;
+    hipStream_t st = ctx->stream;
     if (d_depth_raw_vu)
         HIP_TRY(hipMemcpyAsync(d_depth_raw_vu, d_depth_vu, n * sizeof(float), hipMemcpyDeviceToDevice, st));
 
-    // core.hpp:881-892: median over the EDGE mask, result replaces best_depth
+    // ... then core.hpp:881-892: median over the EDGE mask, result replaces best_depth
     rc = rslf_selective_median(ctx, vol, d_depth_vu, ctx->depth_tmp, s_hat, p->median_filter_size, d_Ce_mask_vu,
                                p->median_filter_epsilon);
     if (rc)
@@ -743,10 +772,7 @@ extern "C" int rslf_depth_epi_pile(rslf_ctx* ctx, const rslf_volume* vol, const 
         unsigned long long tot = 0;
         HIP_TRY(hipMemcpyAsync(&tot, ctx->total, sizeof(tot), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
-        stats->pixels_scanned = (int64_t)tot;
-        stats->units = (int64_t)tot * dim_d;
-        stats->scan_kernel = spad ? RSLF_SCAN_REG : RSLF_SCAN_GENERIC;
-        stats->s_pad = spad;
+        fill_stats(ctx, tot, dim_d, stats);
     }
     return RSLF_OK;
 }
@@ -779,6 +805,28 @@ extern "C" int rslf_depth1d_pile_run(rslf_ctx* ctx, const rslf_volume* vol, floa
         return rc;
     return rslf_depth_epi_pile(ctx, vol, nullptr, nullptr, dmin, dmax, dim_d, s_hat, d_Ce_vu, d_Ce_mask_vu, d_Cd_vu,   // dc.hpp:547
                                d_depth_vu, d_rbar_vu, p, nullptr, d_idx_vu, d_score_vu, d_depth_raw_vu, stats);
+}
+
+extern "C" int rslf_depth1d_run(rslf_ctx* ctx, const rslf_volume* vol, float dmin, float dmax, int dim_d, int s_hat,
+                                const rslf_params* p, float* d_Ce_vu, uint8_t* d_Ce_mask_vu, float* d_Cd_vu, float* d_depth_vu,
+                                float* d_rbar_vu, int32_t* d_idx_vu, float* d_score_vu, rslf_stats* stats)
+{
+    if (!ctx || !vol || !d_Ce_vu || !d_Ce_mask_vu || !d_Cd_vu || !d_depth_vu || !d_rbar_vu)
+        return fail(RSLF_ERR_INVALID_ARG, "NULL argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    s_hat = resolve_s_hat(s_hat, vol->S);   // dc.hpp:303-311
+    const size_t n = (size_t)vol->V * vol->U;
+    hipStream_t st = ctx->stream;
+    // dc.hpp:313-322: zero-initialised outputs
+    HIP_TRY(hipMemsetAsync(d_Ce_vu, 0, n * sizeof(float), st));
+    HIP_TRY(hipMemsetAsync(d_Cd_vu, 0, n * sizeof(float), st));
+    HIP_TRY(hipMemsetAsync(d_depth_vu, 0, n * sizeof(float), st));
+    HIP_TRY(hipMemsetAsync(d_rbar_vu, 0, n * vol->C * sizeof(float), st));
+    int rc = rslf_edge_confidence_pile(ctx, vol, s_hat, p, d_Ce_vu, d_Ce_mask_vu);   // dc.hpp:347
+    if (rc)
+        return rc;
+    return rslf_depth_epi_scan(ctx, vol, nullptr, nullptr, dmin, dmax, dim_d, s_hat, d_Ce_vu, d_Ce_mask_vu, d_Cd_vu,   // dc.hpp:356
+                               d_depth_vu, d_rbar_vu, p, nullptr, d_idx_vu, d_score_vu, stats);
 }
 
 extern "C" int rslf_depth1d_pile_run_host(rslf_ctx* ctx, const rslf_volume* vol, float dmin, float dmax, int dim_d, int s_hat,

@@ -432,3 +432,68 @@ class Depth2DComputer:
                     disp_confidence=self.m_disp_confidence_s_v_u.cpu().numpy(),
                     depth=self.m_best_depth_s_v_u.cpu().numpy(), rbar=self.m_rbar_s_v_u.cpu().numpy(),
                     scan_mask=self.m_scan_mask_s_v_u.cpu().numpy())
+
+
+# ---- "next" row: the single-EPI class -------------------
+
+def compute_1D_depth_epi(vol: Volume, a_dmin_v_u, a_dmax_v_u, a_dim_d: int, a_s_hat: int,
+                         a_edge_confidence_v_u: torch.Tensor, a_edge_confidence_mask_v_u: torch.Tensor,
+                         a_disp_confidence_v_u: torch.Tensor, a_best_depth_v_u: torch.Tensor, a_rbar_v_u: torch.Tensor,
+                         a_parameters: Depth1DParameters | None = None, a_mask_v_u: torch.Tensor | None = None, *,
+                         idx_v_u: torch.Tensor | None = None, score_v_u: torch.Tensor | None = None,
+                         want_stats: bool = False) -> RslfStats | None:
+    """core.hpp:251-267 for every EPI of the volume: the scan alone, no selective median."""
+    p = (a_parameters or Depth1DParameters()).to_c()
+    planes = isinstance(a_dmin_v_u, torch.Tensor)
+    st = RslfStats() if want_stats else None
+    vol.ctx.use_current_stream()
+    check(_lib.lib().rslf_depth_epi_scan(
+        vol.ctx._h, vol._h, _ptr(a_dmin_v_u if planes else None), _ptr(a_dmax_v_u if planes else None),
+        0.0 if planes else float(a_dmin_v_u), 0.0 if planes else float(a_dmax_v_u), a_dim_d, a_s_hat,
+        _ptr(a_edge_confidence_v_u), _ptr(a_edge_confidence_mask_v_u), _ptr(a_disp_confidence_v_u),
+        _ptr(a_best_depth_v_u), _ptr(a_rbar_v_u), C.byref(p), _ptr(a_mask_v_u), _ptr(idx_v_u), _ptr(score_v_u),
+        C.byref(st) if st is not None else None), "rslf_depth_epi_scan")
+    return st
+
+
+class Depth1DComputer:
+    """rslf::Depth1DComputer<T> (dc.hpp:26-70, :256-371): ONE EPI ([S,U] or [S,U,3], uint8 or float32), edge
+    confidence + scan, no median.  Results are [U] CUDA tensors."""
+
+    def __init__(self, epi, dmin: float, dmax: float, dim_d: int, s_hat: int = -1, epi_scale_factor: float = -1.0,
+                 parameters: Depth1DParameters | None = None, ctx: Context | None = None):
+        self.m_parameters = parameters or Depth1DParameters.get_default()
+        self.m_epi = Volume.from_epis([np.asarray(epi)], epi_scale_factor, ctx)
+        vol = self.m_epi
+        self.m_dim_d, self.m_dmin, self.m_dmax = int(dim_d), float(dmin), float(dmax)
+        self.m_s_hat = int(np.floor((0.0 + vol.S) / 2)) if (s_hat < 0 or s_hat > vol.S - 1) else int(s_hat)   # dc.hpp:303-311
+        dev = vol.ctx.device
+        U, C_ = vol.U, vol.C
+        self.m_edge_confidence_u = torch.empty((1, U), dtype=torch.float32, device=dev)
+        self.m_edge_confidence_mask_u = torch.empty((1, U), dtype=torch.uint8, device=dev)
+        self.m_disp_confidence_u = torch.empty((1, U), dtype=torch.float32, device=dev)
+        self.m_best_depth_u = torch.empty((1, U), dtype=torch.float32, device=dev)
+        self.m_rbar_u = torch.empty((1, U, C_), dtype=torch.float32, device=dev)
+        self.m_depth_idx_u = torch.empty((1, U), dtype=torch.int32, device=dev)
+        self.m_score_u = torch.empty((1, U), dtype=torch.float32, device=dev)
+        self.stats: RslfStats | None = None
+
+    def run(self) -> None:
+        """dc.hpp:325-371."""
+        vol = self.m_epi
+        p = self.m_parameters.to_c()
+        st = RslfStats()
+        vol.ctx.use_current_stream()
+        check(_lib.lib().rslf_depth1d_run(
+            vol.ctx._h, vol._h, self.m_dmin, self.m_dmax, self.m_dim_d, self.m_s_hat, C.byref(p),
+            _ptr(self.m_edge_confidence_u), _ptr(self.m_edge_confidence_mask_u), _ptr(self.m_disp_confidence_u),
+            _ptr(self.m_best_depth_u), _ptr(self.m_rbar_u), _ptr(self.m_depth_idx_u), _ptr(self.m_score_u), C.byref(st)),
+            "rslf_depth1d_run")
+        self.stats = st
+
+    def results(self) -> dict:
+        torch.cuda.synchronize(self.m_epi.ctx.device)
+        return dict(edge_confidence=self.m_edge_confidence_u[0].cpu().numpy(), edge_mask=self.m_edge_confidence_mask_u[0].cpu().numpy(),
+                    disp_confidence=self.m_disp_confidence_u[0].cpu().numpy(), depth=self.m_best_depth_u[0].cpu().numpy(),
+                    rbar=self.m_rbar_u[0].cpu().numpy(), depth_idx=self.m_depth_idx_u[0].cpu().numpy(),
+                    score=self.m_score_u[0].cpu().numpy())
