@@ -283,6 +283,177 @@ __global__ __launch_bounds__(64 * kScanWaves) void k2_scan_generic(ScanArgs a)
 }
 
 // ---------------------------------------------------------------------------
+// Streaming variant: any S, C in {1,3}, radiances in [0, 1e6].  For shapes whose samples do not
+// fit the register file (C = 1 beyond 256 views, RGB beyond 104 -- BASELINE.json's 201-view RGB
+// config).  Like the generic kernel it re-gathers the samples on every mean-shift pass, but with the
+// register variant's economies: hypothesis-uniform view offsets come from an LDS table (one
+// broadcast read per sample), validity is one unsigned compare, invalid samples are the 1e30
+// sentinel (K = 0, P = 0 exactly), K is one clamp instruction, and four samples are in flight.
+// Per (sample, pass): ~9 + 3C gather and 7 / 19 mean-shift instructions; the 2C-float loads per
+// sample make it L1-bandwidth bound at about half the register variant's rate.
+// ---------------------------------------------------------------------------
+template <int C, bool BORDER, bool UNIFORM_D>
+__device__ __forceinline__ void scan_stream_body(const ScanArgs& a, int v, int u, int d0, int d1, Best<C>& best,
+                                                 float* __restrict__ otab)
+{
+    const VolView& vol = a.vol;
+    const float* epi = vol.row(v, 0, 0);
+    const float uf = (float)u;
+    const unsigned Um1_bits = __float_as_uint((float)(vol.U - 1));
+    const int S = vol.S;
+    const int lane = threadIdx.x & 63;
+    const long long o = (long long)v * vol.U + u;
+    const float dmin = a.dmin_vu ? a.dmin_vu[o] : a.dmin;
+    const float dmax = a.dmax_vu ? a.dmax_vu[o] : a.dmax;
+    const float range = dmax - dmin;
+    const float denom = (float)(a.dim_d - 1);
+    const float kq = (C == 1) ? a.k.k1 : a.k.inv_h2;
+    const float slope = a.k.slope;
+    const unsigned stride_b = (unsigned)vol.stride_s << 2;
+    const unsigned pitch_b = (unsigned)vol.pitch << 2;
+    float centre[C];
+#pragma unroll
+    for (int c = 0; c < C; c++)
+        centre[c] = epi[(long long)a.s_hat * vol.stride_s + (long long)c * vol.pitch + u];
+
+    for (int d = d0; d < d1; d++) {
+        const float Dd = hypothesis(dmin, range, denom, d);
+        if (UNIFORM_D) {
+            for (int s = lane; s < S; s += 64) {
+                float off = (float)(a.s_hat - s) * Dd;   // core.hpp:542,550
+                otab[s] = off * slope;                   // core.hpp:551
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        float rbar[C];
+#pragma unroll
+        for (int c = 0; c < C; c++)
+            rbar[c] = centre[c];                         // core.hpp:577
+        float B = 0.0f;
+        int card = BORDER ? 0 : S;
+        for (int it = 0; it < a.k.n_iter; it++) {        // core.hpp:584-610
+            float A[C];
+#pragma unroll
+            for (int c = 0; c < C; c++)
+                A[c] = 0.0f;
+            B = 0.0f;
+            int ncard = 0;
+            unsigned rowb = 0;
+            // G samples per trip, hand-unrolled: all G address computations and loads are issued before
+            // the first blend, so G*C loads are in flight per wave (hipcc does not unroll this loop itself
+            // and would otherwise wait for every single load).  Slots past S in the last trip are sentinels.
+            constexpr int G = (C == 1) ? 8 : 4;
+#pragma unroll 1
+            for (int s0 = 0; s0 < S; s0 += G) {
+                float tt[G], e0[C][G], e1[C][G];
+                bool ok[G];
+#pragma unroll
+                for (int j = 0; j < G; j++) {
+                    const int s = s0 + j;
+                    const bool live = s < S;             // wave-uniform
+                    const int sc = live ? s : S - 1;
+                    float x;
+                    if (UNIFORM_D) {
+                        x = otab[sc];
+                    } else {
+                        x = (float)(a.s_hat - sc) * Dd;
+                        x = x * slope;
+                    }
+                    x = x + uf;                          // core.hpp:552
+                    const float fl = floorf(x);          // interp.hpp:179
+                    tt[j] = x - fl;                      // interp.hpp:181
+                    int i0 = (int)fl;
+                    ok[j] = live;
+                    if (BORDER) {
+                        ok[j] = live && (__float_as_uint(x) <= Um1_bits);   // interp.hpp:182 (x is never -0)
+                        i0 = ok[j] ? i0 : 0;
+                    }
+                    const unsigned byteoff = ((unsigned)i0 << 2) + (live ? rowb : 0u);
+                    rowb += stride_b;
+#pragma unroll
+                    for (int c = 0; c < C; c++) {
+                        const float* p = (const float*)((const char*)epi + (byteoff + (unsigned)c * pitch_b));
+                        e0[c][j] = p[0];
+                        e1[c][j] = p[1];   // one global_load_dwordx2 with e0 (two dword loads measured 5-9 % slower)
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < G; j++) {
+                    const float omt = 1.0f - tt[j];
+                    float R[C], q[C];
+#pragma unroll
+                    for (int c = 0; c < C; c++) {
+                        const float m0 = omt * e0[c][j];     // interp.hpp:184
+                        const float m1 = tt[j] * e1[c][j];
+                        float r = m0 + m1;
+                        r = ok[j] ? r : kSentinel;           // interp.hpp:189 stand-in: K = 0 and r * K = 0 exactly
+                        R[c] = r;
+                        const float delta = r - rbar[c];     // core.hpp:591
+                        const float tq = kq * delta;         // kernels.cpp:21 / :43
+                        q[c] = tq * delta;
+                    }
+                    float qs = q[0];
+                    if (C == 3) {
+                        qs = q[0] + q[C - 1];                // OpenCV 3.x reduceC_: (q0 + q2) + q1
+                        qs = qs + q[C > 1 ? 1 : 0];
+                    }
+                    const float K = kernel_weight(qs);       // kernels.cpp:23-25 / :51-53
+#pragma unroll
+                    for (int c = 0; c < C; c++) {
+                        const float pr = R[c] * K;           // core.cpp:28 / :36
+                        A[c] = A[c] + pr;                    // core.hpp:602
+                    }
+                    B = B + K;                               // core.hpp:603
+                    if (BORDER)
+                        ncard += ok[j] ? 1 : 0;
+                }
+            }
+            if (BORDER)
+                card = ncard;
+#pragma unroll
+            for (int c = 0; c < C; c++) {
+                const float qd = (B != 0.0f) ? (A[c] / B) : 0.0f;   // core.cpp:42 / :50
+                rbar[c] = (qd > 0.0f) ? qd : 0.0f;                  // core.hpp:609
+            }
+        }
+        const float cardf = (float)card;
+        float sc = (card != 0) ? (B / cardf) : 0.0f;     // core.hpp:616-620
+        sc = (sc > 0.0f) ? sc : 0.0f;                    // core.hpp:622
+        best.offer(sc, d, Dd, rbar);
+    }
+}
+
+template <int C>
+__global__ __launch_bounds__(64 * kScanWaves) void k2_scan_stream(ScanArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float s_stream_otab[];   // [kScanWaves][S]
+    int v, u;
+    bool active;
+    if (!scan_tile(a, v, u, active))
+        return;
+    int d0, d1;
+    scan_chunk(a, d0, d1);
+    bool interior = false;
+    if (!a.dmin_vu) {
+        const float max_ds = (float)max(a.s_hat, a.vol.S - 1 - a.s_hat);
+        const float max_d = fmaxf(fabsf(a.dmin), fabsf(a.dmax));
+        const float reach = max_ds * max_d * fabsf(a.k.slope) + 2.0f;
+        const float uf = (float)u;
+        interior = __all((uf - reach >= 0.0f) && (uf + reach <= (float)(a.vol.U - 1)));
+    }
+    float* otab = s_stream_otab + (size_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * a.vol.S;
+    Best<C> best;
+    best.init();
+    if (interior)
+        scan_stream_body<C, false, true>(a, v, u, d0, d1, best, otab);
+    else if (!a.dmin_vu)
+        scan_stream_body<C, true, true>(a, v, u, d0, d1, best, otab);
+    else
+        scan_stream_body<C, true, false>(a, v, u, d0, d1, best, otab);
+    scan_epilogue<C>(a, v, u, active, best);
+}
+
+// ---------------------------------------------------------------------------
 // Register variant: C*SPAD sample registers, every radiance in [0, 1e6].
 //
 // The S samples (x C channels) of one (pixel, hypothesis) are gathered once into

@@ -59,7 +59,8 @@ struct rslf_ctx {
     size_t staging_cap = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool ev_valid = false;
-    int last_spad = 0;   // register-scan slot count of the last K2 launch, 0 = generic
+    int last_spad = 0;   // register-scan slot count of the last K2 launch, 0 = none
+    int last_kernel = 0; // RSLF_SCAN_* of the last K2 launch
     bool keep_total = false;   // the 2-D sweep sums the scanned pixels of all its visits
     // 2-D sweep scratch
     int* winner = nullptr;        // [S][V][U]
@@ -646,7 +647,7 @@ static void fill_stats(rslf_ctx* ctx, unsigned long long tot, int dim_d, rslf_st
 {
     stats->pixels_scanned = (int64_t)tot;
     stats->units = (int64_t)tot * dim_d;
-    stats->scan_kernel = ctx->last_spad ? RSLF_SCAN_REG : RSLF_SCAN_GENERIC;
+    stats->scan_kernel = ctx->last_kernel;
     stats->s_pad = ctx->last_spad;
 }
 
@@ -717,16 +718,31 @@ extern "C" int rslf_depth_epi_scan(rslf_ctx* ctx, const rslf_volume* vol, const 
     int spad = 0;
     if (vol->min_value >= 0.0f && vol->max_value <= 1.0e6f)
         spad = pick_spad(vol->S, vol->C);
-    const char* force = getenv("RSLF_FORCE_SCAN");   // "generic": parity tests exercise the fallback on small cases
-    if (force && strcmp(force, "generic") == 0)
+    // Streaming variant: same non-negativity precondition, any S that fits the LDS offset table.
+    bool stream_ok = vol->min_value >= 0.0f && vol->max_value <= 1.0e6f &&
+                     (size_t)kScanWaves * vol->S * sizeof(float) <= (size_t)48 << 10;
+    const char* force = getenv("RSLF_FORCE_SCAN");   // parity tests exercise every variant on small cases
+    if (force && strcmp(force, "generic") == 0) {
         spad = 0;
+        stream_ok = false;
+    } else if (force && strcmp(force, "stream") == 0) {
+        spad = 0;
+    }
 
     ctx->last_spad = spad;
+    ctx->last_kernel = spad ? RSLF_SCAN_REG : (stream_ok ? RSLF_SCAN_STREAM : RSLF_SCAN_GENERIC);
     HIP_TRY(hipEventRecord(ctx->ev0, st));
     if (spad) {
         rc = launch_scan_reg(spad, vol->C, a, grid, st);
         if (rc)
             return rc;
+    } else if (stream_ok) {
+        // too many samples for the register file: re-gather every pass (k2_scan_stream)
+        const size_t lds = (size_t)kScanWaves * vol->S * sizeof(float);
+        if (vol->C == 1)
+            hipLaunchKernelGGL(k2_scan_stream<1>, grid, dim3(64 * kScanWaves), lds, st, a);
+        else
+            hipLaunchKernelGGL(k2_scan_stream<3>, grid, dim3(64 * kScanWaves), lds, st, a);
     } else if (vol->C == 1) {
         hipLaunchKernelGGL(k2_scan_generic<1>, grid, dim3(64 * kScanWaves), 0, st, a);
     } else {
@@ -879,7 +895,7 @@ extern "C" int rslf_depth1d_pile_run_host(rslf_ctx* ctx, const rslf_volume* vol,
         if (hipMemcpy(&tot, ctx->total, sizeof(tot), hipMemcpyDeviceToHost) == hipSuccess) {
             stats->pixels_scanned = (int64_t)tot;
             stats->units = (int64_t)tot * dim_d;
-            stats->scan_kernel = ctx->last_spad ? RSLF_SCAN_REG : RSLF_SCAN_GENERIC;
+            stats->scan_kernel = ctx->last_kernel;
             stats->s_pad = ctx->last_spad;
         }
     }
@@ -1000,7 +1016,7 @@ extern "C" int rslf_depth_epi_2d(rslf_ctx* ctx, const rslf_volume* vol, const fl
         HIP_TRY(hipStreamSynchronize(st));
         stats->pixels_scanned = (int64_t)tot;
         stats->units = (int64_t)tot * dim_d;
-        stats->scan_kernel = ctx->last_spad ? RSLF_SCAN_REG : RSLF_SCAN_GENERIC;
+        stats->scan_kernel = ctx->last_kernel;
         stats->s_pad = ctx->last_spad;
     }
     return RSLF_OK;

@@ -86,7 +86,7 @@ def test_pile_3ch(rs, oracle_mod, kind, S):
     ref = oracle_mod.depth1d_pile_run(vol, -1.0, dm, D)
     comp, got = _run(rs, vol, -1.0, dm, D)
     assert_pile_parity(got, ref, label="3ch_%s_%d" % (kind, S))
-    assert comp.stats.scan_kernel == (1 if S <= 104 else 0)
+    assert comp.stats.scan_kernel == (1 if S <= 104 else 2)   # beyond the register file: streaming variant
 
 
 def test_generic_kernel_matches_on_3ch(rs, oracle_mod, monkeypatch):
@@ -107,6 +107,47 @@ def test_generic_kernel_matches_on_1ch(rs, oracle_mod, monkeypatch):
     comp, got = _run(rs, vol, -2.0, 2.0, D)
     assert comp.stats.scan_kernel == 0
     assert_pile_parity(got, ref, label="forced_generic")
+
+
+@pytest.mark.parametrize("C_,S,U,kind", [(1, 33, 130, "noise"), (1, 9, 70, "struct"), (3, 17, 90, "noise"), (3, 21, 200, "struct"),
+                                         (1, 300, 150, "noise")])
+def test_stream_kernel(rs, oracle_mod, monkeypatch, C_, S, U, kind):
+    """The re-gather variant used beyond the register file (e.g. 201-view RGB), forced on small shapes:
+    border and interior tiles, both channel counts, S beyond every register variant."""
+    monkeypatch.setenv("RSLF_FORCE_SCAN", "stream")
+    V, D = 4, 10
+    dm = 2.0 if S < 100 else 0.4
+    vol = _vol(kind, U, V, S, C_, 300 + S, -1.0, dm)
+    ref = oracle_mod.depth1d_pile_run(vol, -1.0, dm, D)
+    comp, got = _run(rs, vol, -1.0, dm, D)
+    assert comp.stats.scan_kernel == 2
+    assert_pile_parity(got, ref, label="stream_C%d_S%d" % (C_, S))
+
+
+def test_stream_kernel_per_pixel_ranges(rs, oracle_mod, monkeypatch):
+    import torch
+    monkeypatch.setenv("RSLF_FORCE_SCAN", "stream")
+    rng = np.random.default_rng(51)
+    V, S, U, D = 3, 13, 110, 9
+    vol = rng.uniform(0.0, 1.0, size=(V, S, U, 3)).astype(np.float32)
+    dmin = rng.uniform(-2.0, 0.0, size=(V, U)).astype(np.float32)
+    dmax = (dmin + rng.uniform(0.0, 3.0, size=(V, U))).astype(np.float32)
+    Ce, cm = oracle_mod.edge_confidence_pile(vol, 6)
+    ref = oracle_mod.depth_epi_pile(vol, dmin, dmax, D, 6, Ce, cm)
+    v = rs.Volume.from_dense(vol)
+    dev = "cuda"
+    t = lambda a: torch.from_numpy(a.copy()).to(dev)
+    tCe, tcm = t(Ce), t(cm)
+    tCd = torch.zeros((V, U), device=dev); tdepth = torch.zeros((V, U), device=dev); trbar = torch.zeros((V, U, 3), device=dev)
+    tidx = torch.empty((V, U), dtype=torch.int32, device=dev); tsc = torch.empty((V, U), device=dev)
+    st = rs.compute_1D_depth_epi_pile(v, t(dmin), t(dmax), D, 6, tCe, tcm, tCd, tdepth, trbar, None, None, idx_v_u=tidx,
+                                      score_v_u=tsc, want_stats=True)
+    torch.cuda.synchronize()
+    assert st.scan_kernel == 2
+    assert np.array_equal(tidx.cpu().numpy(), ref.depth_idx)
+    assert np.array_equal(tsc.cpu().numpy(), ref.score)
+    assert np.array_equal(tdepth.cpu().numpy(), ref.depth)
+    assert np.array_equal(trbar.cpu().numpy(), ref.rbar)
 
 
 def test_negative_radiances_take_generic_path(rs, oracle_mod):
