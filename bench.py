@@ -69,6 +69,44 @@ def cpu_baseline(cfg: dict, budget_s: float = 12.0) -> dict:
     }
 
 
+def bench_sweep2d(args) -> None:
+    """Depth2DComputer::run() (dc.hpp:748-805) on a synthetic field: a step = edge confidence of every view
+    + one visit per view (scan on the running mask, median, propagation).  Units = pixels actually scanned,
+    summed over the visits, x hypotheses."""
+    import torch
+    from remotesensingproject_amd import depth as rs
+    from remotesensingproject_amd.synth import CONFIGS, make_lightfield
+    if args.gpus != 1:
+        raise SystemExit("the 2-D sweep bench is single-GPU")
+    cfg = dict(CONFIGS[args.config if args.config != "c3" else "c2"])
+    if args.rows:
+        cfg["V"] = args.rows
+    U, V, S, C, D = cfg["U"], cfg["V"], cfg["S"], cfg["C"], cfg["D"]
+    torch.cuda.set_device(0)
+    host, _ = make_lightfield(U, V, S, C, seed=cfg["seed"], dmin=cfg["dmin"], dmax=cfg["dmax"])
+    ctx = rs.default_context(0)
+    vol = rs.Volume.from_dense(torch.from_numpy(host).cuda(), 1.0, ctx)
+    comp = rs.Depth2DComputer(vol, cfg["dmin"], cfg["dmax"], D)
+    for _ in range(max(args.warmup, 1)):
+        comp.run(want_stats=True)
+    torch.cuda.synchronize()
+    units = int(comp.stats.units)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        comp.run(want_stats=False)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    print(json.dumps({
+        "metric": "Mpixel*disparity-hypotheses/s", "value": units / (elapsed / args.steps) / 1e6, "unit": "Mpixel*hyp/s",
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "2-D sweep (Depth2DComputer::run) over %s: %dx%d px x %d views x %d ch, %d hypotheses; %d visits, "
+                               "%d pixels scanned in total (%.2f views' worth)" % (
+                                   args.config if args.config != "c3" else "c2", U, V, S, C, D, S, units // D, units / D / (U * V)),
+                   "path": "sweep2d"},
+    }), flush=True)
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -77,7 +115,12 @@ def main() -> None:
     ap.add_argument("--config", default="c3", help="synthetic config of BASELINE.md section 4 (c2, c3, c5)")
     ap.add_argument("--rows", type=int, default=0, help="override the number of scanlines (developer runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--path", default="pile", choices=["pile", "sweep2d"],
+                    help="pile = Depth1DComputer_pile::run (the headline path); sweep2d = Depth2DComputer::run, the 'next' row "
+                         "(all views, centre outwards, with propagation), 1 GPU only")
     args = ap.parse_args()
+    if args.path == "sweep2d":
+        return bench_sweep2d(args)
 
     import torch
     import torch.distributed as dist
