@@ -77,6 +77,14 @@ def lib():
         L.oracle_depth2d_run.argtypes = [
             _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.POINTER(OracleParams), C.c_float,
             _f32p, _u8p, _f32p, _f32p, _f32p, _u8p]
+        L.oracle_edge_confidence_2d.argtypes = [_f32p, C.c_int, C.c_int, C.c_int, C.c_int, _f32p, _u8p, C.POINTER(OracleParams)]
+        L.oracle_depth_epi_2d.argtypes = [_f32p, C.c_int, C.c_int, C.c_int, C.c_int, _f32p, _f32p, C.c_int, _f32p, _u8p, _f32p,
+                                          _f32p, _f32p, C.POINTER(OracleParams), C.c_float, _u8p]
+        L.oracle_f2c_out_dims.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.oracle_downsample_epis.argtypes = [_f32p, C.c_int, C.c_int, C.c_int, C.c_int, _f32p]
+        L.oracle_f2c_tighten_bounds.argtypes = [_f32p, _u8p, C.c_int, C.c_int, C.c_int, _f32p, _f32p, C.c_int, C.c_int]
+        L.oracle_f2c_fuse.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                      C.c_int, _f32p, _u8p]
         L.oracle_num_threads.restype = C.c_int
         L.oracle_set_num_threads.argtypes = [C.c_int]
         _lib = L
@@ -231,6 +239,107 @@ def depth2d_run(vol, dmin, dmax, dim_d, params=None, propagation_epsilon=0.1) ->
     lib().oracle_depth2d_run(vol.reshape(-1), V, S, U, Cc, dmin, dmax, dim_d, C.byref(p), np.float32(propagation_epsilon),
                              Ce.reshape(-1), cm.reshape(-1), Cd.reshape(-1), depth.reshape(-1), rbar.reshape(-1), sm.reshape(-1))
     return SweepResult(Ce, cm, Cd, depth, rbar, sm)
+
+
+def depth2d_run_planes(vol, dmin_svu, dmax_svu, dim_d, params=None, propagation_epsilon=0.1) -> SweepResult:
+    """compute_2D_edge_confidence + compute_2D_depth_epi with per-pixel hypothesis ranges [S,V,U]
+    (what FineToCoarse hands to every level but the finest, rslf_fine_to_coarse.hpp:171-299)."""
+    vol = np.ascontiguousarray(vol, dtype=np.float32)
+    V, S, U, Cc = vol.shape
+    p = params or default_params()
+    Ce = np.zeros((S, V, U), np.float32); cm = np.zeros((S, V, U), np.uint8)
+    Cd = np.zeros((S, V, U), np.float32); depth = np.zeros((S, V, U), np.float32)
+    rbar = np.zeros((S, V, U, Cc), np.float32); sm = np.zeros((S, V, U), np.uint8)
+    L = lib()
+    L.oracle_edge_confidence_2d(vol.reshape(-1), V, S, U, Cc, Ce.reshape(-1), cm.reshape(-1), C.byref(p))
+    L.oracle_depth_epi_2d(vol.reshape(-1), V, S, U, Cc, np.ascontiguousarray(dmin_svu, np.float32).reshape(-1),
+                          np.ascontiguousarray(dmax_svu, np.float32).reshape(-1), dim_d, Ce.reshape(-1), cm.reshape(-1),
+                          Cd.reshape(-1), depth.reshape(-1), rbar.reshape(-1), C.byref(p), np.float32(propagation_epsilon),
+                          sm.reshape(-1))
+    return SweepResult(Ce, cm, Cd, depth, rbar, sm)
+
+
+def downsample_epis(raw_vsuc: np.ndarray) -> np.ndarray:
+    """rslf::downsample_EPIs (fine_to_coarse_core.cpp:14-60) on [V,S,U,C] float32."""
+    a = np.ascontiguousarray(raw_vsuc, np.float32)
+    V, S, U, Cc = a.shape
+    v2, u2 = C.c_int(), C.c_int()
+    lib().oracle_f2c_out_dims(V, U, C.byref(v2), C.byref(u2))
+    out = np.zeros((v2.value, S, u2.value, Cc), np.float32)
+    lib().oracle_downsample_epis(a.reshape(-1), V, S, U, Cc, out.reshape(-1))
+    return out
+
+
+def f2c_tighten_bounds(depth_up_svu, mask_up_svu, dmin_down_svu, dmax_down_svu):
+    """rslf_fine_to_coarse.hpp:171-299; returns new (dmin, dmax) for the coarser level."""
+    du = np.ascontiguousarray(depth_up_svu, np.float32); mu = np.ascontiguousarray(mask_up_svu, np.uint8)
+    S, Vu, Uu = du.shape
+    lo = np.array(dmin_down_svu, np.float32, copy=True); hi = np.array(dmax_down_svu, np.float32, copy=True)
+    _, Vd, Ud = lo.shape
+    lib().oracle_f2c_tighten_bounds(du.reshape(-1), mu.reshape(-1), S, Vu, Uu, lo.reshape(-1), hi.reshape(-1), Vd, Ud)
+    return lo, hi
+
+
+def f2c_fuse(disp_pyr, valid_pyr):
+    """rslf::fuse_disp_maps (fine_to_coarse_core.cpp:69-135) for one view: lists of [V_p,U_p] planes, finest first."""
+    P = len(disp_pyr)
+    d = [np.ascontiguousarray(x, np.float32) for x in disp_pyr]
+    m = [np.ascontiguousarray(x, np.uint8) for x in valid_pyr]
+    dp = (C.c_void_p * P)(*[x.ctypes.data for x in d]); mp = (C.c_void_p * P)(*[x.ctypes.data for x in m])
+    Vp = (C.c_int * P)(*[x.shape[0] for x in d]); Up = (C.c_int * P)(*[x.shape[1] for x in d])
+    out = np.zeros(d[0].shape, np.float32); ov = np.zeros(d[0].shape, np.uint8)
+    lib().oracle_f2c_fuse(dp, mp, Vp, Up, P, out.reshape(-1), ov.reshape(-1))
+    return out, ov
+
+
+def fine_to_coarse_run(raw_vsuc, dmin, dmax, dim_d, params=None, max_pyr_depth=-1, accept_all_last_scale=True,
+                       min_spatial_dim=10, propagation_epsilon=0.1):
+    """rslf::FineToCoarse (rslf_fine_to_coarse.hpp:103-299 + get_results :302-324) on a RAW float32 volume
+    [V,S,U,C]: every level normalises by its own max (epi_scale_factor = -1 in each Depth2DComputer), levels are
+    built while min(V,U) > _MIN_SPATIAL_DIM, slope_factor = U_p / U_0.
+    Returns dict(levels=[SweepResult...], dims=[(V_p,U_p)...], fused_map [S,V,U], fused_valid [S,V,U])."""
+    import copy
+    base = params or default_params()
+    raw = np.ascontiguousarray(raw_vsuc, np.float32)
+    U0 = raw.shape[2]
+    vols, pars = [], []
+    if max_pyr_depth < 1:
+        max_pyr_depth = 1 << 30
+    cur = raw
+    V, U = cur.shape[0], cur.shape[2]
+    count = 0
+    while V > min_spatial_dim and U > min_spatial_dim and count < max_pyr_depth:   # f2c.hpp:130
+        count += 1
+        p = copy.copy(base) if not isinstance(base, OracleParams) else OracleParams.from_buffer_copy(base)
+        p.slope_factor = np.float32((0.0 + U) / U0)                                # f2c.hpp:139
+        norm, _ = normalize_f32(cur, -1.0)                                         # Depth2DComputer ctor, dc.hpp:671-705
+        vols.append(norm); pars.append(p)
+        cur = downsample_epis(cur)                                                 # f2c.hpp:145-147 (the RAW EPIs go down)
+        V, U = cur.shape[0], cur.shape[2]
+    S = raw.shape[1]
+    thr = np.float32(base.edge_score_threshold)
+    levels, valids = [], []
+    dmin_p = dmax_p = None
+    for lvl, (vol, p) in enumerate(zip(vols, pars)):
+        Vp, Up = vol.shape[0], vol.shape[2]
+        if lvl == 0:
+            lo = np.full((S, Vp, Up), dmin, np.float32); hi = np.full((S, Vp, Up), dmax, np.float32)
+        else:
+            lo = np.full((S, Vp, Up), dmin, np.float32); hi = np.full((S, Vp, Up), dmax, np.float32)
+            lo, hi = f2c_tighten_bounds(levels[-1].depth, valids[-1], lo, hi)      # f2c.hpp:176-294
+        r = depth2d_run_planes(vol, lo, hi, dim_d, p, propagation_epsilon)
+        last = lvl == len(vols) - 1
+        if last and accept_all_last_scale:
+            valid = np.where(r.edge_confidence > -1, 255, 0).astype(np.uint8)      # dc.hpp:911
+        else:
+            valid = np.where(r.edge_confidence > thr, 255, 0).astype(np.uint8)     # dc.hpp:906
+        levels.append(r); valids.append(valid)
+    fused = np.zeros((S,) + levels[0].depth.shape[1:], np.float32)
+    fvalid = np.zeros(fused.shape, np.uint8)
+    for s in range(S):                                                             # fine_to_coarse_core.cpp:84
+        fused[s], fvalid[s] = f2c_fuse([lv.depth[s] for lv in levels], [vm[s] for vm in valids])
+    return dict(levels=levels, valids=valids, dims=[(v.shape[0], v.shape[2]) for v in vols], fused_map=fused, fused_valid=fvalid,
+                params=pars)
 
 
 def num_threads() -> int:

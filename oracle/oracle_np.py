@@ -254,3 +254,141 @@ def depth2d_run(vol, dmin, dmax, D, p=None, propagation_epsilon=F(0.1)):
                             mask[s, v, ri] = 0
                             Cd[s, v, ri] = Cd[s_hat, v, u]
     return dict(Ce=Ce, Ce_mask=cm, Cd=Cd, depth=depth, rbar=rbar, scan_mask=mask)
+
+
+# ---- "next" row: fine-to-coarse primitives (restated with array ops) -----------------------------
+
+_GK = np.array([0.03125, 0.109375, 0.21875, 0.28125, 0.21875, 0.109375, 0.03125], F)   # small_gaussian_tab[3]
+
+
+def _reflect(i, n):
+    """cv::BORDER_REFLECT index map."""
+    i = np.array(i, copy=True)
+    if n == 1:
+        return np.zeros_like(i)
+    while True:
+        lo, hi = i < 0, i >= n
+        if not (lo.any() or hi.any()):
+            return i
+        i[lo] = -i[lo] - 1
+        i[hi] = 2 * n - 1 - i[hi]
+
+
+def gaussian7_reflect(img):
+    """cv::GaussianBlur(7x7, sigma 0, BORDER_REFLECT) on [R,W,C] float32 (fine_to_coarse_core.cpp:38)."""
+    R, W, C = img.shape
+    xs = np.arange(W)
+    tmp = _GK[0] * img[:, _reflect(xs - 3, W)]
+    for j in range(1, 7):
+        tmp = tmp + _GK[j] * img[:, _reflect(xs + j - 3, W)]
+    ys = np.arange(R)
+    out = _GK[3] * tmp
+    for j in range(1, 4):
+        out = out + _GK[3 + j] * (tmp[_reflect(ys + j, R)] + tmp[_reflect(ys - j, R)])
+    return out.astype(F)
+
+
+def halve_area(img):
+    """cv::resize(0.5, 0.5, INTER_LINEAR) = OpenCV's 2x2 area-fast path (fine_to_coarse_core.cpp:42)."""
+    R, W, C = img.shape
+    R2, W2 = int(np.rint(R * 0.5)), int(np.rint(W * 0.5))      # cvRound: ties to even
+    out = np.zeros((R2, W2, C), F)
+    Rf, Wf = R // 2, W // 2
+    a = img[0:2 * Rf:2, 0:2 * Wf:2] + img[1:2 * Rf:2, 0:2 * Wf:2]
+    b = img[0:2 * Rf:2, 1:2 * Wf:2] + img[1:2 * Rf:2, 1:2 * Wf:2]
+    out[:Rf, :Wf] = (a + b) * F(0.25)
+    for y in range(R2):
+        for x in range(W2):
+            if y < Rf and x < Wf:
+                continue
+            vals = [img[2 * y + sy, 2 * x + sx] for sy in range(2) for sx in range(2) if 2 * y + sy < R and 2 * x + sx < W]
+            acc = np.zeros(C, F)
+            for vv in vals:
+                acc = acc + vv
+            out[y, x] = acc / F(len(vals)) if vals else 0
+    return out
+
+
+def downsample_epis(raw):
+    """rslf::downsample_EPIs: [V,S,U,C] -> [V2,S,U2,C]."""
+    V, S, U, C = raw.shape
+    outs = [halve_area(gaussian7_reflect(np.ascontiguousarray(raw[:, s]))) for s in range(S)]
+    return np.ascontiguousarray(np.stack(outs, axis=1))
+
+
+def tighten_bounds(depth_up, mask_up, dmin_down, dmax_down):
+    """rslf_fine_to_coarse.hpp:202-294."""
+    S, Vu, Uu = depth_up.shape
+    _, Vd, Ud = dmin_down.shape
+    lo, hi = dmin_down.copy(), dmax_down.copy()
+    for s in range(S):
+        for v in range(Vd):
+            for u in range(Ud):
+                cands = []
+                rows = [min(2 * v, Vu - 1)]
+                if rows[0] + 1 < Vu:
+                    rows.append(rows[0] + 1)
+                uu = min(2 * u, Uu - 1)
+                for r in rows:
+                    left = [c for c in range(uu - 1, 0, -1) if mask_up[s, r, c] > 0]
+                    right = [c for c in range(uu + 1, Uu) if mask_up[s, r, c] > 0]
+                    if left and right:
+                        cands += [depth_up[s, r, left[0]], depth_up[s, r, right[0]]]
+                if len(cands) > 1:
+                    lo[s, v, u], hi[s, v, u] = min(cands), max(cands)
+    return lo, hi
+
+
+def resize_linear(src, R2, W2):
+    """cv::resize(..., INTER_LINEAR) of a float plane (upscaling, fine_to_coarse_core.cpp:104)."""
+    R, W = src.shape
+    sx_scale, sy_scale = 1.0 / (W2 / W), 1.0 / (R2 / R)
+    fx = ((np.arange(W2) + 0.5) * sx_scale - 0.5).astype(F)
+    sx = np.floor(fx).astype(np.int64)
+    fx = (fx - sx.astype(F)).astype(F)
+    neg = sx < 0
+    fx[neg], sx[neg] = 0, 0
+    edge = sx + 1 >= W
+    xmax = int(np.flatnonzero(edge)[0]) if edge.any() else W2
+    far = sx >= W - 1
+    fx[far], sx[far] = 0, W - 1
+    fy = ((np.arange(R2) + 0.5) * sy_scale - 0.5).astype(F)
+    sy = np.floor(fy).astype(np.int64)
+    fy = (fy - sy.astype(F)).astype(F)
+    y0, y1 = np.clip(sy, 0, R - 1), np.clip(sy + 1, 0, R - 1)
+    a0, a1 = (F(1) - fx), fx
+    sx1 = np.minimum(sx + 1, W - 1)
+    def hrow(rows):
+        full = rows[:, sx] * a0 + rows[:, sx1] * a1
+        flat = rows[:, sx] * F(1)
+        return np.where(np.arange(W2)[None] < xmax, full, flat).astype(F)
+    r0, r1 = hrow(src[y0]), hrow(src[y1])
+    return (r0 * (F(1) - fy)[:, None] + r1 * fy[:, None]).astype(F)
+
+
+def resize_nearest(src, R2, W2):
+    R, W = src.shape
+    sy = np.minimum(np.floor(np.arange(R2) * (1.0 / (R2 / R))).astype(np.int64), R - 1)
+    sx = np.minimum(np.floor(np.arange(W2) * (1.0 / (W2 / W))).astype(np.int64), W - 1)
+    return src[sy][:, sx]
+
+
+def median3(src):
+    R, W = src.shape
+    p = np.pad(src, 1, mode="edge")
+    stack = np.stack([p[dy:dy + R, dx:dx + W] for dy in range(3) for dx in range(3)], axis=0)
+    return np.sort(stack, axis=0)[4].astype(F)
+
+
+def fuse(disp_pyr, valid_pyr):
+    """rslf::fuse_disp_maps for one view (fine_to_coarse_core.cpp:93-131)."""
+    P = len(disp_pyr)
+    md, mm = disp_pyr[P - 1].copy(), valid_pyr[P - 1].copy()
+    for p in range(P - 1, 0, -1):
+        R, W = disp_pyr[p - 1].shape
+        up = resize_linear(md, R, W)
+        upm = resize_nearest(mm, R, W)
+        inval = valid_pyr[p - 1] == 0
+        md = np.where(inval, F(0) + up, disp_pyr[p - 1]).astype(F)
+        mm = valid_pyr[p - 1] | upm
+    return median3(md), mm

@@ -736,3 +736,301 @@ void oracle_depth2d_run(const float* vol, int V, int S, int U, int C,
     free(dmin_svu);
     free(dmax_svu);
 }
+
+/* ======================================================================
+ * "next" row: fine-to-coarse (rslf_fine_to_coarse.hpp, rslf_fine_to_coarse_core.cpp)
+ * ====================================================================== */
+
+static int cv_round_half_even(double x)
+{
+    return (int)lrint(x); /* cvRound: the default rounding mode, ties to even */
+}
+
+void oracle_f2c_out_dims(int V, int U, int* V2, int* U2)
+{
+    /* cv::resize with dsize empty: Size(saturate_cast<int>(cols*fx), saturate_cast<int>(rows*fy)) */
+    *V2 = cv_round_half_even(V * 0.5);
+    *U2 = cv_round_half_even(U * 0.5);
+}
+
+static inline int reflect_border(int p, int len) /* cv::BORDER_REFLECT: fedcba|abcdefgh|hgfedcb */
+{
+    if (len == 1)
+        return 0;
+    while (p < 0 || p >= len)
+        p = (p < 0) ? -p - 1 : 2 * len - 1 - p;
+    return p;
+}
+
+/* cv::GaussianBlur(src, dst, Size(7,7), 0, 0, BORDER_REFLECT) on a float image [R][W][C]:
+ * getGaussianKernel(7, sigma<=0) returns the fixed small_gaussian_tab row; sepFilter2D runs the row
+ * filter (taps accumulated left to right) then the symmetric column filter
+ * (centre tap, then k[c+j] * (S[y+j] + S[y-j]), j = 1..3).  No FMA. */
+static void gaussian7_reflect(const float* src, float* dst, float* tmp, int R, int W, int C)
+{
+    static const float k[7] = {0.03125f, 0.109375f, 0.21875f, 0.28125f, 0.21875f, 0.109375f, 0.03125f};
+    for (int y = 0; y < R; y++)
+        for (int x = 0; x < W; x++)
+            for (int c = 0; c < C; c++) {
+                float s = k[0] * src[((size_t)y * W + reflect_border(x - 3, W)) * C + c];
+                for (int j = 1; j < 7; j++) {
+                    const float pr = k[j] * src[((size_t)y * W + reflect_border(x + j - 3, W)) * C + c];
+                    s = s + pr;
+                }
+                tmp[((size_t)y * W + x) * C + c] = s;
+            }
+    for (int y = 0; y < R; y++)
+        for (int x = 0; x < W; x++)
+            for (int c = 0; c < C; c++) {
+                float s = k[3] * tmp[((size_t)y * W + x) * C + c];
+                for (int j = 1; j <= 3; j++) {
+                    const float a = tmp[((size_t)reflect_border(y + j, R) * W + x) * C + c];
+                    const float b = tmp[((size_t)reflect_border(y - j, R) * W + x) * C + c];
+                    const float ab = a + b;
+                    const float pr = k[3 + j] * ab;
+                    s = s + pr;
+                }
+                dst[((size_t)y * W + x) * C + c] = s;
+            }
+}
+
+/* cv::resize(src, dst, Size(), 0.5, 0.5, INTER_LINEAR): with an exact factor 2 OpenCV takes the
+ * INTER_AREA fast path -- each output pixel is the mean of its 2x2 block, (S00 + S10) + (S01 + S11)
+ * times 0.25 (vertical pairs first, the SIMD form); where the block sticks out of an odd-sized source
+ * the mean runs over the pixels that exist, in row-major order, divided by their count. */
+static void halve_area(const float* src, int R, int W, int C, float* dst, int R2, int W2)
+{
+    for (int y = 0; y < R2; y++)
+        for (int x = 0; x < W2; x++)
+            for (int c = 0; c < C; c++) {
+                const int y0 = 2 * y, x0 = 2 * x;
+                float out;
+                if (y0 + 1 < R && x0 + 1 < W) {
+                    const float a = src[((size_t)y0 * W + x0) * C + c] + src[((size_t)(y0 + 1) * W + x0) * C + c];
+                    const float b = src[((size_t)y0 * W + x0 + 1) * C + c] + src[((size_t)(y0 + 1) * W + x0 + 1) * C + c];
+                    const float ab = a + b;
+                    out = ab * 0.25f;
+                } else {
+                    float sum = 0.0f;
+                    int cnt = 0;
+                    for (int sy = 0; sy < 2; sy++)
+                        for (int sx = 0; sx < 2; sx++)
+                            if (y0 + sy < R && x0 + sx < W) {
+                                sum = sum + src[((size_t)(y0 + sy) * W + x0 + sx) * C + c];
+                                cnt++;
+                            }
+                    out = cnt ? sum / (float)cnt : 0.0f;
+                }
+                dst[((size_t)y * W2 + x) * C + c] = out;
+            }
+}
+
+void oracle_downsample_epis(const float* in, int V, int S, int U, int C, float* out)
+{
+    int V2, U2;
+    oracle_f2c_out_dims(V, U, &V2, &U2);
+#pragma omp parallel
+    {
+        float* img = (float*)malloc(sizeof(float) * (size_t)V * U * C);
+        float* tmp = (float*)malloc(sizeof(float) * (size_t)V * U * C);
+        float* blur = (float*)malloc(sizeof(float) * (size_t)V * U * C);
+        float* half = (float*)malloc(sizeof(float) * (size_t)V2 * U2 * C);
+#pragma omp for schedule(static)
+        for (int s = 0; s < S; s++) { /* fine_to_coarse_core.cpp:28-46 */
+            for (int v = 0; v < V; v++)
+                memcpy(img + (size_t)v * U * C, in + (((size_t)v * S + s) * U) * C, sizeof(float) * (size_t)U * C);
+            gaussian7_reflect(img, blur, tmp, V, U, C);
+            halve_area(blur, V, U, C, half, V2, U2);
+            for (int v = 0; v < V2; v++) /* :49-59 */
+                memcpy(out + (((size_t)v * S + s) * U2) * C, half + (size_t)v * U2 * C, sizeof(float) * (size_t)U2 * C);
+        }
+        free(img); free(tmp); free(blur); free(half);
+    }
+}
+
+void oracle_f2c_tighten_bounds(const float* depth_up, const uint8_t* mask_up, int S, int V_up, int U_up,
+                               float* dmin_down, float* dmax_down, int V_down, int U_down)
+{
+    const size_t nu = (size_t)V_up * U_up, nd = (size_t)V_down * U_down;
+#pragma omp parallel for schedule(static)
+    for (int s = 0; s < S; s++) { /* rslf_fine_to_coarse.hpp:202 */
+        const float* dep = depth_up + (size_t)s * nu;
+        const uint8_t* msk = mask_up + (size_t)s * nu;
+        for (int v = 0; v < V_down; v++)
+            for (int u = 0; u < U_down; u++) {
+                float cand[4];
+                int nc = 0;
+                int v_up = (2 * v < V_up - 1) ? 2 * v : V_up - 1;   /* :212 */
+                const int u_up = (2 * u < U_up - 1) ? 2 * u : U_up - 1;
+                for (int line = 0; line < 2; line++) {
+                    if (line == 1) {
+                        if (v_up + 1 < V_up) /* :249 */
+                            v_up += 1;
+                        else
+                            break;
+                    }
+                    int found_l = 0, found_r = 0;
+                    float dl = 0, dr = 0;
+                    int ul = u_up;
+                    while (ul > 1) { /* :217-225: never looks at columns 0 */
+                        ul -= 1;
+                        if (msk[(size_t)v_up * U_up + ul] > 0) {
+                            dl = dep[(size_t)v_up * U_up + ul];
+                            found_l = 1;
+                            break;
+                        }
+                    }
+                    int ur = u_up;
+                    while (ur < U_up - 1) { /* :228-236 */
+                        ur += 1;
+                        if (msk[(size_t)v_up * U_up + ur] > 0) {
+                            dr = dep[(size_t)v_up * U_up + ur];
+                            found_r = 1;
+                            break;
+                        }
+                    }
+                    if (found_l && found_r) { /* :242-246 (NaN = "not found") */
+                        cand[nc++] = dl;
+                        cand[nc++] = dr;
+                    }
+                }
+                if (nc > 1) { /* :281-289: min and max of the candidates */
+                    float lo = cand[0], hi = cand[0];
+                    for (int i = 1; i < nc; i++) {
+                        if (cand[i] < lo) lo = cand[i];
+                        if (cand[i] > hi) hi = cand[i];
+                    }
+                    dmin_down[(size_t)s * nd + (size_t)v * U_down + u] = lo;
+                    dmax_down[(size_t)s * nd + (size_t)v * U_down + u] = hi;
+                }
+            }
+    }
+}
+
+/* cv::resize(..., dsize, 0, 0, INTER_LINEAR) of a float plane, upscaling (fine_to_coarse_core.cpp:104) */
+static void resize_linear_f32(const float* src, int R, int W, float* dst, int R2, int W2)
+{
+    const double scale_x = 1.0 / ((double)W2 / W), scale_y = 1.0 / ((double)R2 / R);
+    int* xofs = (int*)malloc(sizeof(int) * (size_t)W2);
+    float* xa = (float*)malloc(sizeof(float) * 2 * (size_t)W2);
+    int xmax = W2;
+    for (int dx = 0; dx < W2; dx++) {
+        float fx = (float)((dx + 0.5) * scale_x - 0.5);
+        int sx = (int)floor(fx);
+        fx -= sx;
+        if (sx < 0) {
+            fx = 0;
+            sx = 0;
+        }
+        if (sx + 1 >= W) {
+            if (dx < xmax)
+                xmax = dx;
+            if (sx >= W - 1) {
+                fx = 0;
+                sx = W - 1;
+            }
+        }
+        xofs[dx] = sx;
+        xa[2 * dx] = 1.f - fx;
+        xa[2 * dx + 1] = fx;
+    }
+    float* row0 = (float*)malloc(sizeof(float) * (size_t)W2);
+    float* row1 = (float*)malloc(sizeof(float) * (size_t)W2);
+    for (int dy = 0; dy < R2; dy++) {
+        float fy = (float)((dy + 0.5) * scale_y - 0.5);
+        int sy = (int)floor(fy);
+        fy -= sy;
+        const float b0 = 1.f - fy, b1 = fy;
+        int y0 = sy < 0 ? 0 : (sy > R - 1 ? R - 1 : sy);
+        int y1 = sy + 1 < 0 ? 0 : (sy + 1 > R - 1 ? R - 1 : sy + 1);
+        const float* S0 = src + (size_t)y0 * W;
+        const float* S1 = src + (size_t)y1 * W;
+        for (int dx = 0; dx < W2; dx++) { /* HResizeLinear */
+            const int sx = xofs[dx];
+            if (dx < xmax) {
+                const float a0 = S0[sx] * xa[2 * dx], a1 = S0[sx + 1] * xa[2 * dx + 1];
+                row0[dx] = a0 + a1;
+                const float c0 = S1[sx] * xa[2 * dx], c1 = S1[sx + 1] * xa[2 * dx + 1];
+                row1[dx] = c0 + c1;
+            } else {
+                row0[dx] = S0[sx] * 1.f;
+                row1[dx] = S1[sx] * 1.f;
+            }
+        }
+        for (int dx = 0; dx < W2; dx++) { /* VResizeLinear */
+            const float p0 = row0[dx] * b0, p1 = row1[dx] * b1;
+            dst[(size_t)dy * W2 + dx] = p0 + p1;
+        }
+    }
+    free(xofs); free(xa); free(row0); free(row1);
+}
+
+/* cv::resize(..., INTER_NEAREST) of a uchar plane (fine_to_coarse_core.cpp:106) */
+static void resize_nearest_u8(const uint8_t* src, int R, int W, uint8_t* dst, int R2, int W2)
+{
+    const double ifx = 1.0 / ((double)W2 / W), ify = 1.0 / ((double)R2 / R);
+    for (int y = 0; y < R2; y++) {
+        int sy = (int)floor(y * ify);
+        if (sy > R - 1)
+            sy = R - 1;
+        for (int x = 0; x < W2; x++) {
+            int sx = (int)floor(x * ifx);
+            if (sx > W - 1)
+                sx = W - 1;
+            dst[(size_t)y * W2 + x] = src[(size_t)sy * W + sx];
+        }
+    }
+}
+
+/* cv::medianBlur(src, dst, 3) on float: 3x3 window, BORDER_REPLICATE, exact median of 9 */
+static void median3_f32(const float* src, int R, int W, float* dst)
+{
+    for (int y = 0; y < R; y++)
+        for (int x = 0; x < W; x++) {
+            float w[9];
+            int n = 0;
+            for (int dy = -1; dy <= 1; dy++)
+                for (int dx = -1; dx <= 1; dx++) {
+                    int yy = y + dy, xx = x + dx;
+                    yy = yy < 0 ? 0 : (yy > R - 1 ? R - 1 : yy);
+                    xx = xx < 0 ? 0 : (xx > W - 1 ? W - 1 : xx);
+                    w[n++] = src[(size_t)yy * W + xx];
+                }
+            qsort(w, 9, sizeof(float), cmp_float);
+            dst[(size_t)y * W + x] = w[4];
+        }
+}
+
+void oracle_f2c_fuse(const float* const* disp, const uint8_t* const* valid, const int* Vp, const int* Up, int P,
+                     float* out_map, uint8_t* out_valid)
+{
+    /* fine_to_coarse_core.cpp:93-127 */
+    size_t n_last = (size_t)Vp[P - 1] * Up[P - 1];
+    float* map_down = (float*)malloc(sizeof(float) * n_last);
+    uint8_t* mask_down = (uint8_t*)malloc(n_last);
+    memcpy(map_down, disp[P - 1], sizeof(float) * n_last);
+    memcpy(mask_down, valid[P - 1], n_last);
+    for (int p = P - 1; p > 0; p--) {
+        const int R = Vp[p - 1], W = Up[p - 1];
+        const size_t n = (size_t)R * W;
+        float* map_up = (float*)malloc(sizeof(float) * n);
+        uint8_t* mask_up = (uint8_t*)malloc(n);
+        resize_linear_f32(map_down, Vp[p], Up[p], map_up, R, W);       /* :104 */
+        resize_nearest_u8(mask_down, Vp[p], Up[p], mask_up, R, W);     /* :106 */
+        float* nd = (float*)malloc(sizeof(float) * n);
+        uint8_t* nm = (uint8_t*)malloc(n);
+        for (size_t i = 0; i < n; i++) {
+            const int inval = valid[p - 1][i] == 0;                     /* :117 */
+            /* :119-120: setTo(0, invalid) then add(map, map_up, map, invalid) */
+            nd[i] = inval ? (0.0f + map_up[i]) : disp[p - 1][i];
+            nm[i] = valid[p - 1][i] | mask_up[i];                       /* :122 */
+        }
+        free(map_down); free(mask_down); free(map_up); free(mask_up);
+        map_down = nd;
+        mask_down = nm;
+    }
+    median3_f32(map_down, Vp[0], Up[0], out_map);                      /* :127 */
+    memcpy(out_valid, mask_down, (size_t)Vp[0] * Up[0]);
+    free(map_down);
+    free(mask_down);
+}

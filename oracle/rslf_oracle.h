@@ -151,6 +151,30 @@ void oracle_depth2d_run(const float* vol, int V, int S, int U, int C,
                         float* Ce_svu, uint8_t* Ce_mask_svu, float* Cd_svu,
                         float* depth_svu, float* rbar_svu, uint8_t* scan_mask_svu);
 
+/* ---- "next" row: fine-to-coarse -------------------- */
+/* The OpenCV 3.x primitives this row leans on are restated from their documented algorithms; the
+ * choices that affect the last bit (accumulation order) are listed in DESIGN.md.  All images here are
+ * dense float32, [rows][cols][C] interleaved. */
+
+/* rslf::downsample_EPIs (src/rslf_fine_to_coarse_core.cpp:14-60): per view s, the V x U image is
+ * smoothed with cv::GaussianBlur(7x7, sigma 0 => the fixed table {1,3.5,7,9,7,3.5,1}/32, BORDER_REFLECT)
+ * and halved with cv::resize(0.5, 0.5, INTER_LINEAR) (which OpenCV runs as its 2x2 "area fast" average).
+ * in [V][S][U][C] -> out [V2][S][U2][C]; V2 = cvRound(V/2), U2 = cvRound(U/2) (round half to even). */
+void oracle_f2c_out_dims(int V, int U, int* V2, int* U2);
+void oracle_downsample_epis(const float* in_vsuc, int V, int S, int U, int C, float* out_vsuc);
+
+/* FineToCoarse::run(), the bound tightening between two levels (include/rslf_fine_to_coarse.hpp:171-299):
+ * for every pixel of the coarser level, the nearest valid disparities left and right of column 2u on
+ * rows 2v and 2v+1 of the finer level bound its hypothesis range.  Planes [S][V][U]. */
+void oracle_f2c_tighten_bounds(const float* depth_up_svu, const uint8_t* mask_up_svu, int S, int V_up, int U_up,
+                               float* dmin_down_svu, float* dmax_down_svu, int V_down, int U_down);
+
+/* rslf::fuse_disp_maps (src/rslf_fine_to_coarse_core.cpp:69-135) for ONE view: coarse-to-fine fill of the
+ * invalid pixels (cv::resize INTER_LINEAR / INTER_NEAREST upscaling), then cv::medianBlur 3x3.
+ * disp[p] / valid[p]: level p planes [V_p][U_p], p = 0 finest.  out_map / out_valid: [V_0][U_0]. */
+void oracle_f2c_fuse(const float* const* disp, const uint8_t* const* valid, const int* Vp, const int* Up, int P,
+                     float* out_map, uint8_t* out_valid);
+
 int oracle_num_threads(void);
 void oracle_set_num_threads(int n);
 
