@@ -107,6 +107,46 @@ def bench_sweep2d(args) -> None:
     }), flush=True)
 
 
+def bench_f2c(args) -> None:
+    """FineToCoarse constructor + run() + get_results() (rslf_fine_to_coarse.hpp) on a synthetic field, raw
+    float input in [3, 203): a step = pyramid construction, every level's 2-D sweep, bound tightening and fusion."""
+    import torch
+    from remotesensingproject_amd import depth as rs
+    from remotesensingproject_amd.synth import CONFIGS, make_lightfield
+    cfg = dict(CONFIGS[args.config if args.config != "c3" else "c2"])
+    if args.rows:
+        cfg["V"] = args.rows
+    U, V, S, C, D = cfg["U"], cfg["V"], cfg["S"], cfg["C"], cfg["D"]
+    torch.cuda.set_device(0)
+    host, _ = make_lightfield(U, V, S, C, seed=cfg["seed"], dmin=cfg["dmin"], dmax=cfg["dmax"])
+    raw = (host * 200.0 + 3.0).astype(np.float32)
+
+    def once():
+        f = rs.FineToCoarse(raw, cfg["dmin"], cfg["dmax"], D)
+        f.run()
+        m, v = f.get_results()
+        torch.cuda.synchronize()
+        return f
+
+    f = None
+    for _ in range(max(args.warmup, 1)):
+        f = once()
+    units = sum(int(c.stats.units) for c in f.m_computers)
+    dims = [(c.m_epis.V, c.m_epis.U) for c in f.m_computers]
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        once()
+    elapsed = time.perf_counter() - t0
+    print(json.dumps({
+        "metric": "Mpixel*disparity-hypotheses/s", "value": units / (elapsed / args.steps) / 1e6, "unit": "Mpixel*hyp/s",
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "fine-to-coarse (FineToCoarse ctor + run + get_results, host upload included) over %s: %dx%d px x %d views "
+                               "x %d ch, %d hypotheses; pyramid %s" % (args.config if args.config != "c3" else "c2", U, V, S, C, D, dims),
+                   "path": "f2c", "pixels_scanned": units // D},
+    }), flush=True)
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -115,12 +155,14 @@ def main() -> None:
     ap.add_argument("--config", default="c3", help="synthetic config of BASELINE.md section 4 (c2, c3, c5)")
     ap.add_argument("--rows", type=int, default=0, help="override the number of scanlines (developer runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--path", default="pile", choices=["pile", "sweep2d"],
+    ap.add_argument("--path", default="pile", choices=["pile", "sweep2d", "f2c"],
                     help="pile = Depth1DComputer_pile::run (the headline path); sweep2d = Depth2DComputer::run, the 'next' row "
                          "(all views, centre outwards, with propagation), 1 GPU only")
     args = ap.parse_args()
     if args.path == "sweep2d":
         return bench_sweep2d(args)
+    if args.path == "f2c":
+        return bench_f2c(args)
 
     import torch
     import torch.distributed as dist

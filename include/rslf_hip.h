@@ -234,6 +234,30 @@ int rslf_depth2d_run(rslf_ctx* ctx, const rslf_volume* vol, float dmin, float dm
                      float* d_Ce_svu, uint8_t* d_Ce_mask_svu, float* d_Cd_svu, float* d_depth_svu,
                      float* d_rbar_svu, uint8_t* d_scan_mask_svu, rslf_stats* stats);
 
+/* ---- "next" row: fine-to-coarse ---------------------- */
+/* rslf::FineToCoarse<T> (include/rslf_fine_to_coarse.hpp:26-81) is a host-side loop over pyramid
+ * levels, each a Depth2DComputer (rslf_depth2d_run / rslf_depth_epi_2d above).  These are the pieces
+ * between the levels; the loop itself lives in the host wrapper (depth.py: FineToCoarse).  Raw
+ * (un-normalised) volumes here are dense float32 [V][S][U][C] on the device; the reference builds
+ * uchar pyramids in uchar arithmetic, this ABI builds every pyramid in float. */
+
+/* Level dimensions of cv::resize(0.5, 0.5): cvRound(V/2), cvRound(U/2) (ties to even). */
+int rslf_f2c_level_dims(int V, int U, int* V2, int* U2);
+/* rslf::downsample_EPIs -- src/rslf_fine_to_coarse_core.cpp:14-60: per view, cv::GaussianBlur(7x7,
+ * sigma 0, BORDER_REFLECT) then cv::resize(0.5, 0.5, INTER_LINEAR).  d_out_vsuc is [V2][S][U2][C]. */
+int rslf_downsample_epis_f32(rslf_ctx* ctx, const float* d_in_vsuc, int V, int S, int U, int C, float* d_out_vsuc);
+/* max over a device buffer: the per-level epi_scale_factor of Depth2DComputer's constructor
+ * (include/rslf_depth_computation.hpp:671-690).  Synchronises. */
+int rslf_device_max_f32(rslf_ctx* ctx, const float* d_values, size_t n, float* h_max);
+/* FineToCoarse::run(), bound tightening -- include/rslf_fine_to_coarse.hpp:171-299: d_dmin/d_dmax of
+ * the coarser level ([S][V_down][U_down], in/out) from the finer level's disparities and validity. */
+int rslf_f2c_tighten_bounds(rslf_ctx* ctx, const float* d_depth_up_svu, const uint8_t* d_valid_up_svu, int S, int V_up,
+                            int U_up, float* d_dmin_down_svu, float* d_dmax_down_svu, int V_down, int U_down);
+/* rslf::fuse_disp_maps -- src/rslf_fine_to_coarse_core.cpp:69-135, all views at once.
+ * d_disp[p] / d_valid[p]: level p planes [S][Vp[p]][Up[p]] (p = 0 finest); outputs [S][Vp[0]][Up[0]]. */
+int rslf_f2c_fuse(rslf_ctx* ctx, const float* const* d_disp, const uint8_t* const* d_valid, const int* Vp, const int* Up,
+                  int P, int S, float* d_out_map_svu, uint8_t* d_out_valid_svu);
+
 /* ---- measurement ------------------------------------------------------ */
 /* Duration in milliseconds of the last scan-kernel launch (K2) of this
  * context, from HIP events recorded on the context's stream around that

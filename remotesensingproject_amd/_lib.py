@@ -25,6 +25,7 @@ SYMBOLS = [
     "rslf_depth1d_pile_run", "rslf_depth1d_pile_run_host", "rslf_last_scan_kernel_ms",
     "rslf_edge_confidence_2d", "rslf_depth_epi_2d", "rslf_depth2d_run",
     "rslf_depth_epi_scan", "rslf_depth1d_run",
+    "rslf_f2c_level_dims", "rslf_downsample_epis_f32", "rslf_device_max_f32", "rslf_f2c_tighten_bounds", "rslf_f2c_fuse",
 ]
 
 
@@ -130,6 +131,11 @@ def lib():
                                         C.POINTER(RslfStats)]
     L.rslf_depth1d_pile_run_host.argtypes = L.rslf_depth1d_pile_run.argtypes
     L.rslf_last_scan_kernel_ms.argtypes = [vp, C.POINTER(cf)]
+    L.rslf_f2c_level_dims.argtypes = [ci, ci, C.POINTER(ci), C.POINTER(ci)]
+    L.rslf_downsample_epis_f32.argtypes = [vp, vp, ci, ci, ci, ci, vp]
+    L.rslf_device_max_f32.argtypes = [vp, vp, C.c_size_t, C.POINTER(cf)]
+    L.rslf_f2c_tighten_bounds.argtypes = [vp, vp, vp, ci, ci, ci, vp, vp, ci, ci]
+    L.rslf_f2c_fuse.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(ci), C.POINTER(ci), ci, ci, vp, vp]
     L.rslf_edge_confidence_2d.argtypes = [vp, vp, C.POINTER(RslfParams), vp, vp]
     L.rslf_depth_epi_2d.argtypes = [vp, vp, vp, vp, cf, cf, ci, vp, vp, vp, vp, vp, C.POINTER(RslfParams), vp, C.POINTER(RslfStats)]
     L.rslf_depth2d_run.argtypes = [vp, vp, cf, cf, ci, C.POINTER(RslfParams), vp, vp, vp, vp, vp, vp, C.POINTER(RslfStats)]

@@ -18,7 +18,7 @@ CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(CSRC, "librslf_hip.so")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 SOURCES = ["rslf_abi.hip"]
-DEPS = SOURCES + ["rslf_device.hpp", "k1_edge.hpp", "k2_scan.hpp", "k3_median.hpp", "k4_propagate.hpp", os.path.join(INCLUDE, "rslf_hip.h")]
+DEPS = SOURCES + ["rslf_device.hpp", "k1_edge.hpp", "k2_scan.hpp", "k3_median.hpp", "k4_propagate.hpp", "k5_f2c.hpp", os.path.join(INCLUDE, "rslf_hip.h")]
 
 HIPCC_FLAGS = [
     "--offload-arch=gfx950",

@@ -17,6 +17,7 @@
 #include "k2_scan.hpp"
 #include "k3_median.hpp"
 #include "k4_propagate.hpp"
+#include "k5_f2c.hpp"
 
 using namespace rslf;
 
@@ -1041,6 +1042,128 @@ extern "C" int rslf_depth2d_run(rslf_ctx* ctx, const rslf_volume* vol, float dmi
         return rc;
     return rslf_depth_epi_2d(ctx, vol, nullptr, nullptr, dmin, dmax, dim_d, d_Ce_svu, d_Ce_mask_svu, d_Cd_svu, d_depth_svu,   // dc.hpp:780
                              d_rbar_svu, p, d_scan_mask_svu, stats);
+}
+
+// ---- "next" row: fine-to-coarse ------------------------------------------------
+
+extern "C" int rslf_f2c_level_dims(int V, int U, int* V2, int* U2)
+{
+    if (!V2 || !U2 || V < 1 || U < 1)
+        return fail(RSLF_ERR_INVALID_ARG, "bad arguments");
+    *V2 = (int)std::lrint(V * 0.5);   // cvRound: ties to even
+    *U2 = (int)std::lrint(U * 0.5);
+    return RSLF_OK;
+}
+
+namespace {
+struct DevBuf {   // scoped device scratch for the once-per-level helpers
+    void* p = nullptr;
+    ~DevBuf() { (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
+};
+}  // namespace
+
+extern "C" int rslf_downsample_epis_f32(rslf_ctx* ctx, const float* d_in_vsuc, int V, int S, int U, int C, float* d_out_vsuc)
+{
+    if (!ctx || !d_in_vsuc || !d_out_vsuc || V < 1 || S < 1 || U < 1 || (C != 1 && C != 3))
+        return fail(RSLF_ERR_INVALID_ARG, "bad arguments");
+    HIP_TRY(hipSetDevice(ctx->device));
+    int V2, U2;
+    rslf_f2c_level_dims(V, U, &V2, &U2);
+    if (V2 < 1 || U2 < 1)
+        return fail(RSLF_ERR_INVALID_ARG, "level too small to halve");
+    DevBuf tmp;
+    HIP_TRY(tmp.alloc((size_t)V * S * U * C * sizeof(float)));
+    hipStream_t st = ctx->stream;
+    const long long row_blocks = (long long)V * S * ((U * C + 255) / 256);
+    if (row_blocks > (1ll << 31) - 1)
+        return fail(RSLF_ERR_UNSUPPORTED, "volume too large for one downsampling launch");
+    hipLaunchKernelGGL(k5_gauss_rows, dim3((unsigned)row_blocks), dim3(256), 0, st, d_in_vsuc, (float*)tmp.p, (long long)V * S, U, C);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(k5_gauss_cols_halve, dim3((U2 * C + 255) / 256, S, V2), dim3(256), 0, st, (const float*)tmp.p, d_out_vsuc,
+                       V, S, U, C, V2, U2);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(st));   // tmp is released on return
+    return RSLF_OK;
+}
+
+extern "C" int rslf_device_max_f32(rslf_ctx* ctx, const float* d_values, size_t n, float* h_max)
+{
+    if (!ctx || !d_values || !h_max || n == 0)
+        return fail(RSLF_ERR_INVALID_ARG, "bad arguments");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const int blocks = (int)std::min<size_t>((n + 255) / 256, 2048);
+    DevBuf part;
+    HIP_TRY(part.alloc((size_t)blocks * sizeof(float)));
+    hipLaunchKernelGGL(k5_max_partial, dim3(blocks), dim3(256), 0, ctx->stream, d_values, (long long)n, (float*)part.p);
+    HIP_TRY(hipGetLastError());
+    std::vector<float> h(blocks);
+    HIP_TRY(hipMemcpyAsync(h.data(), part.p, (size_t)blocks * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    float m = h[0];
+    for (int i = 1; i < blocks; i++)
+        m = std::max(m, h[i]);
+    *h_max = m;
+    return RSLF_OK;
+}
+
+extern "C" int rslf_f2c_tighten_bounds(rslf_ctx* ctx, const float* d_depth_up_svu, const uint8_t* d_valid_up_svu, int S, int V_up,
+                                       int U_up, float* d_dmin_down_svu, float* d_dmax_down_svu, int V_down, int U_down)
+{
+    if (!ctx || !d_depth_up_svu || !d_valid_up_svu || !d_dmin_down_svu || !d_dmax_down_svu || S < 1 || V_up < 1 || U_up < 1 ||
+        V_down < 1 || U_down < 1)
+        return fail(RSLF_ERR_INVALID_ARG, "bad arguments");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t n_up = (size_t)S * V_up * U_up;
+    DevBuf left, right;
+    HIP_TRY(left.alloc(n_up * sizeof(int)));
+    HIP_TRY(right.alloc(n_up * sizeof(int)));
+    hipStream_t st = ctx->stream;
+    const long long rows = (long long)S * V_up;
+    hipLaunchKernelGGL(k5_nearest_valid, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, st, d_valid_up_svu, rows, U_up,
+                       (int*)left.p, (int*)right.p);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(k5_tighten, dim3((U_down + 255) / 256, V_down, S), dim3(256), 0, st, d_depth_up_svu, (const int*)left.p,
+                       (const int*)right.p, S, V_up, U_up, d_dmin_down_svu, d_dmax_down_svu, V_down, U_down);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(st));
+    return RSLF_OK;
+}
+
+extern "C" int rslf_f2c_fuse(rslf_ctx* ctx, const float* const* d_disp, const uint8_t* const* d_valid, const int* Vp, const int* Up,
+                             int P, int S, float* d_out_map_svu, uint8_t* d_out_valid_svu)
+{
+    if (!ctx || !d_disp || !d_valid || !Vp || !Up || P < 1 || S < 1 || !d_out_map_svu || !d_out_valid_svu)
+        return fail(RSLF_ERR_INVALID_ARG, "bad arguments");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const size_t n0 = (size_t)S * Vp[0] * Up[0];
+    // two ping-pong buffers at the finest size hold the running map / mask of every step
+    DevBuf mapA, mapB, mskA, mskB;
+    HIP_TRY(mapA.alloc(n0 * sizeof(float)));
+    HIP_TRY(mapB.alloc(n0 * sizeof(float)));
+    HIP_TRY(mskA.alloc(n0));
+    HIP_TRY(mskB.alloc(n0));
+    float* map_down = (float*)mapA.p;
+    float* map_next = (float*)mapB.p;
+    uint8_t* msk_down = (uint8_t*)mskA.p;
+    uint8_t* msk_next = (uint8_t*)mskB.p;
+    const size_t nl = (size_t)S * Vp[P - 1] * Up[P - 1];
+    HIP_TRY(hipMemcpyAsync(map_down, d_disp[P - 1], nl * sizeof(float), hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(msk_down, d_valid[P - 1], nl, hipMemcpyDeviceToDevice, st));
+    for (int p = P - 1; p > 0; p--) {   // fine_to_coarse_core.cpp:98-123
+        const int R = Vp[p], W = Up[p], R2 = Vp[p - 1], W2 = Up[p - 1];
+        hipLaunchKernelGGL(k5_fuse_step, dim3((W2 + 255) / 256, R2, S), dim3(256), 0, st, map_down, msk_down, R, W, d_disp[p - 1],
+                           d_valid[p - 1], map_next, msk_next, R2, W2);
+        HIP_TRY(hipGetLastError());
+        std::swap(map_down, map_next);
+        std::swap(msk_down, msk_next);
+    }
+    hipLaunchKernelGGL(k5_median3, dim3((Up[0] + 255) / 256, Vp[0], S), dim3(256), 0, st, map_down, d_out_map_svu, Vp[0], Up[0]);   // :127
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(d_out_valid_svu, msk_down, n0, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return RSLF_OK;
 }
 
 extern "C" int rslf_last_scan_kernel_ms(rslf_ctx* ctx, float* ms)

@@ -497,3 +497,121 @@ class Depth1DComputer:
                     disp_confidence=self.m_disp_confidence_u[0].cpu().numpy(), depth=self.m_best_depth_u[0].cpu().numpy(),
                     rbar=self.m_rbar_u[0].cpu().numpy(), depth_idx=self.m_depth_idx_u[0].cpu().numpy(),
                     score=self.m_score_u[0].cpu().numpy())
+
+
+# ---- "next" row: fine-to-coarse ---------------------------
+
+_MIN_SPATIAL_DIM = 10   # rslf_fine_to_coarse.hpp:8
+
+
+def downsample_EPIs(raw_vsuc: torch.Tensor, ctx: Context | None = None) -> torch.Tensor:
+    """rslf::downsample_EPIs (src/rslf_fine_to_coarse_core.cpp:14-60) on a dense RAW float32 CUDA volume
+    [V,S,U,C] -> [V2,S,U2,C]."""
+    ctx = ctx or default_context(raw_vsuc.device)
+    t = raw_vsuc.contiguous()
+    V, S, U, C_ = t.shape
+    v2, u2 = C.c_int(), C.c_int()
+    check(_lib.lib().rslf_f2c_level_dims(V, U, C.byref(v2), C.byref(u2)), "rslf_f2c_level_dims")
+    out = torch.empty((v2.value, S, u2.value, C_), dtype=torch.float32, device=t.device)
+    ctx.use_current_stream()
+    check(_lib.lib().rslf_downsample_epis_f32(ctx._h, _ptr(t), V, S, U, C_, _ptr(out)), "rslf_downsample_epis_f32")
+    return out
+
+
+class FineToCoarse:
+    """rslf::FineToCoarse<T> (include/rslf_fine_to_coarse.hpp:26-81, :103-324): a pyramid of Depth2DComputers,
+    each level halving (v, u) -- never s --, with slope_factor = U_p / U_0, per-pixel hypothesis ranges
+    tightened from the finer level, and a coarse-to-fine fusion of the disparity maps.
+
+    `epis`: the reference's Vec<Mat> (list of V arrays [S,U] / [S,U,3]) or a dense array [V,S,U(,C)],
+    float32 or uint8.  Every pyramid is built in float (the reference blurs uchar input in uchar)."""
+
+    def __init__(self, epis, d_min: float, d_max: float, dim_d: int, epi_scale_factor: float = -1.0,
+                 parameters: Depth1DParameters | None = None, max_pyr_depth: int = -1, accept_all_last_scale: bool = True,
+                 ctx: Context | None = None):
+        import copy
+        self.m_parameters = parameters or Depth1DParameters.get_default()
+        ctx = ctx or default_context()
+        dev = ctx.device
+        a = np.stack([np.asarray(e) for e in epis]) if isinstance(epis, (list, tuple)) else np.asarray(epis)
+        if a.ndim == 3:
+            a = a[..., None]
+        self._is_u8 = a.dtype == np.uint8
+        raw = torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dev)
+        start_dim_u = raw.shape[2]
+        if max_pyr_depth < 1:
+            max_pyr_depth = 1 << 30
+        self.m_computers: list[Depth2DComputer] = []
+        self.m_parameter_instances: list[Depth1DParameters] = []
+        dim_v, dim_u, counter = raw.shape[0], raw.shape[2], 0
+        L = _lib.lib()
+        while dim_v > _MIN_SPATIAL_DIM and dim_u > _MIN_SPATIAL_DIM and counter < max_pyr_depth:   # f2c.hpp:130
+            counter += 1
+            new_parameters = copy.copy(self.m_parameters)
+            new_parameters.par_slope_factor = float(np.float32((0.0 + dim_u) / start_dim_u))       # f2c.hpp:139
+            # Depth2DComputer's constructor normalises ITS input: uchar by 1/255, float by the level's own max
+            # unless a scale factor was given (dc.hpp:671-705)
+            if self._is_u8:
+                scale = 255.0
+            elif epi_scale_factor < 0:
+                mx = C.c_float()
+                ctx.use_current_stream()
+                check(L.rslf_device_max_f32(ctx._h, _ptr(raw), raw.numel(), C.byref(mx)), "rslf_device_max_f32")
+                scale = float(mx.value)
+            else:
+                scale = float(epi_scale_factor)
+            vol = Volume.from_dense(raw, scale, ctx)
+            self.m_computers.append(Depth2DComputer(vol, d_min, d_max, dim_d, parameters=new_parameters))
+            self.m_parameter_instances.append(new_parameters)
+            raw = downsample_EPIs(raw, ctx)                                                        # f2c.hpp:145-147
+            dim_v, dim_u = raw.shape[0], raw.shape[2]
+        if not self.m_computers:
+            raise ValueError("light field smaller than _MIN_SPATIAL_DIM: no pyramid level")
+        if accept_all_last_scale:
+            self.m_computers[-1].set_accept_all(True)                                              # f2c.hpp:157-158
+        self._dmin, self._dmax = float(d_min), float(d_max)
+
+    def run(self) -> None:
+        """f2c.hpp:171-299."""
+        L = _lib.lib()
+        for p, comp in enumerate(self.m_computers):
+            vol = comp.m_epis
+            S, V, U = vol.S, vol.V, vol.U
+            if p == 0:
+                comp.run(want_stats=True)
+            else:
+                up = self.m_computers[p - 1]
+                dev = vol.ctx.device
+                dmin = torch.full((S, V, U), self._dmin, dtype=torch.float32, device=dev)
+                dmax = torch.full((S, V, U), self._dmax, dtype=torch.float32, device=dev)
+                mask_up = up.get_valid_depths_mask_s_v_u()
+                vol.ctx.use_current_stream()
+                check(L.rslf_f2c_tighten_bounds(vol.ctx._h, _ptr(up.m_best_depth_s_v_u), _ptr(mask_up), S, up.m_epis.V, up.m_epis.U,
+                                                _ptr(dmin), _ptr(dmax), V, U), "rslf_f2c_tighten_bounds")
+                comp.m_dmin_s_v_u, comp.m_dmax_s_v_u = dmin, dmax
+                # Depth2DComputer::run with per-pixel ranges (edit_dmin / edit_dmax, dc.hpp:201-203)
+                for t in (comp.m_edge_confidence_s_v_u, comp.m_disp_confidence_s_v_u, comp.m_best_depth_s_v_u, comp.m_rbar_s_v_u):
+                    t.zero_()
+                comp.m_edge_confidence_mask_s_v_u = compute_2D_edge_confidence(vol, comp.m_edge_confidence_s_v_u, comp.m_parameters)
+                comp.stats = compute_2D_depth_epi(vol, dmin, dmax, comp.m_dim_d, comp.m_edge_confidence_s_v_u,
+                                                  comp.m_edge_confidence_mask_s_v_u, comp.m_disp_confidence_s_v_u,
+                                                  comp.m_best_depth_s_v_u, comp.m_rbar_s_v_u, comp.m_parameters,
+                                                  scan_mask_s_v_u=comp.m_scan_mask_s_v_u, want_stats=True)
+
+    def get_results(self):
+        """f2c.hpp:302-324 -> (out_map_s_v_u [S,V,U] f32, out_validity_s_v_u [S,V,U] u8) at the finest scale."""
+        comps = self.m_computers
+        P, S = len(comps), comps[0].m_epis.S
+        disp = [c.m_best_depth_s_v_u.contiguous() for c in comps]
+        valid = [c.get_valid_depths_mask_s_v_u().contiguous() for c in comps]
+        dp = (C.c_void_p * P)(*[t.data_ptr() for t in disp])
+        vp = (C.c_void_p * P)(*[t.data_ptr() for t in valid])
+        Vp = (C.c_int * P)(*[c.m_epis.V for c in comps])
+        Up = (C.c_int * P)(*[c.m_epis.U for c in comps])
+        dev = comps[0].m_epis.ctx.device
+        out_map = torch.empty((S, comps[0].m_epis.V, comps[0].m_epis.U), dtype=torch.float32, device=dev)
+        out_valid = torch.empty((S, comps[0].m_epis.V, comps[0].m_epis.U), dtype=torch.uint8, device=dev)
+        ctx = comps[0].m_epis.ctx
+        ctx.use_current_stream()
+        check(_lib.lib().rslf_f2c_fuse(ctx._h, dp, vp, Vp, Up, P, S, _ptr(out_map), _ptr(out_valid)), "rslf_f2c_fuse")
+        return out_map, out_valid

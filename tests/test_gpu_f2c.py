@@ -1,0 +1,82 @@
+"""Fine-to-coarse (rslf_fine_to_coarse.hpp / rslf_fine_to_coarse_core.cpp) on the GPU vs the oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("V,S,U,C_", [(17, 3, 23, 1), (16, 2, 30, 3), (11, 2, 13, 1), (135, 2, 67, 1), (64, 5, 96, 1)])
+def test_downsample_epis(oracle_mod, V, S, U, C_):
+    import torch
+    from remotesensingproject_amd import depth as rs
+    rng = np.random.default_rng(V + U)
+    raw = rng.uniform(0, 250, size=(V, S, U, C_)).astype(np.float32)
+    want = oracle_mod.downsample_epis(raw)
+    got = rs.downsample_EPIs(torch.from_numpy(raw).cuda()).cpu().numpy()
+    assert got.shape == want.shape
+    assert np.array_equal(got, want)
+
+
+def test_tighten_bounds_and_fuse(oracle_mod):
+    import ctypes as C
+    import torch
+    from remotesensingproject_amd import _lib
+    from remotesensingproject_amd import depth as rs
+    rng = np.random.default_rng(4)
+    ctx = rs.default_context()
+    L = _lib.lib()
+    for (S, Vu, Uu, dens) in ((2, 17, 23, 0.3), (3, 16, 30, 0.7), (1, 40, 51, 0.02)):
+        dep = rng.uniform(-2, 2, size=(S, Vu, Uu)).astype(np.float32)
+        m = (rng.uniform(size=(S, Vu, Uu)) < dens).astype(np.uint8) * 255
+        Vd, Ud = int(np.rint(Vu * .5)), int(np.rint(Uu * .5))
+        lo = np.full((S, Vd, Ud), -3, np.float32); hi = np.full((S, Vd, Ud), 3, np.float32)
+        wlo, whi = oracle_mod.f2c_tighten_bounds(dep, m, lo, hi)
+        tlo, thi = torch.from_numpy(lo).cuda(), torch.from_numpy(hi).cuda()
+        tdep, tmsk = torch.from_numpy(dep).cuda(), torch.from_numpy(m).cuda()   # keep alive across the call
+        ctx.use_current_stream()
+        rc = L.rslf_f2c_tighten_bounds(ctx._h, C.c_void_p(tdep.data_ptr()), C.c_void_p(tmsk.data_ptr()), S, Vu, Uu,
+                                       C.c_void_p(tlo.data_ptr()), C.c_void_p(thi.data_ptr()), Vd, Ud)
+        assert rc == 0
+        assert np.array_equal(tlo.cpu().numpy(), wlo) and np.array_equal(thi.cpu().numpy(), whi)
+    for dims in (((17, 23), (8, 12), (4, 6)), ((16, 30), (8, 15)), ((135, 67), (68, 34), (34, 17), (17, 8)), ((20, 20),)):
+        S = 3
+        d = [rng.uniform(-2, 2, size=(S,) + x).astype(np.float32) for x in dims]
+        m = [(rng.uniform(size=(S,) + x) > 0.5).astype(np.uint8) * 255 for x in dims]
+        P = len(dims)
+        td = [torch.from_numpy(x).cuda() for x in d]; tm = [torch.from_numpy(x).cuda() for x in m]
+        dp = (C.c_void_p * P)(*[t.data_ptr() for t in td]); mp = (C.c_void_p * P)(*[t.data_ptr() for t in tm])
+        Vp = (C.c_int * P)(*[x[0] for x in dims]); Up = (C.c_int * P)(*[x[1] for x in dims])
+        om = torch.empty((S,) + dims[0], dtype=torch.float32, device="cuda"); ov = torch.empty((S,) + dims[0], dtype=torch.uint8, device="cuda")
+        assert L.rslf_f2c_fuse(ctx._h, dp, mp, Vp, Up, P, S, C.c_void_p(om.data_ptr()), C.c_void_p(ov.data_ptr())) == 0
+        for s in range(S):
+            wm, wv = oracle_mod.f2c_fuse([x[s] for x in d], [x[s] for x in m])
+            assert np.array_equal(om[s].cpu().numpy(), wm), (dims, s)
+            assert np.array_equal(ov[s].cpu().numpy(), wv), (dims, s)
+
+
+@pytest.mark.parametrize("C_,dtype", [(1, np.float32), (3, np.float32)])
+def test_fine_to_coarse_end_to_end(oracle_mod, C_, dtype):
+    """rslf::FineToCoarse constructor + run() + get_results() against the oracle's orchestration of the same
+    steps: every level's planes and the fused map, raw float input normalised per level by its own max."""
+    from remotesensingproject_amd import depth as rs
+    from remotesensingproject_amd.synth import make_lightfield
+    vol, _ = make_lightfield(64, 44, 5, C_, seed=2, dmin=-1, dmax=1, band=8)
+    raw = (vol * 200 + 3).astype(np.float32)
+    ref = oracle_mod.fine_to_coarse_run(raw, -1.0, 1.0, 9)
+    f2c = rs.FineToCoarse(raw, -1.0, 1.0, 9)
+    assert [(c.m_epis.V, c.m_epis.U) for c in f2c.m_computers] == ref["dims"]
+    f2c.run()
+    for p, (comp, lv) in enumerate(zip(f2c.m_computers, ref["levels"])):
+        got = comp.results()
+        assert abs(comp.m_parameters.par_slope_factor - float(ref["params"][p].slope_factor)) == 0
+        assert np.array_equal(got["edge_mask"], lv.edge_mask), p
+        assert np.array_equal(got["edge_confidence"], lv.edge_confidence), p
+        assert np.array_equal(got["depth"], lv.depth), p
+        assert np.array_equal(got["scan_mask"], lv.scan_mask), p
+        assert np.array_equal(got["rbar"], lv.rbar), p
+        assert np.abs(got["disp_confidence"] - lv.disp_confidence).max() <= 1e-5, p
+        valid = comp.get_valid_depths_mask_s_v_u().cpu().numpy()
+        assert np.array_equal(valid, ref["valids"][p]), p
+    out_map, out_valid = f2c.get_results()
+    assert np.array_equal(out_map.cpu().numpy(), ref["fused_map"])
+    assert np.array_equal(out_valid.cpu().numpy(), ref["fused_valid"])
