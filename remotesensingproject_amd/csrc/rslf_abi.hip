@@ -292,6 +292,11 @@ extern "C" int rslf_volume_create(rslf_ctx* ctx, int V, int S, int U, int C, rsl
         return fail(RSLF_ERR_INVALID_ARG, "bad dimensions V=%d S=%d U=%d", V, S, U);
     if (C != 1 && C != 3)
         return fail(RSLF_ERR_UNSUPPORTED, "C=%d: the reference instantiates float and cv::Vec3f only (dc.hpp:149-154)", C);
+    if (V > 65535 || S > 65535)
+        return fail(RSLF_ERR_UNSUPPORTED, "V=%d / S=%d: the per-scanline kernels index scanlines and views with grid.y / grid.z "
+                                          "(at most 65535)", V, S);
+    if ((long long)S * C * (((long long)U + 1 + 63) / 64 * 64) > ((long long)1 << 29))
+        return fail(RSLF_ERR_UNSUPPORTED, "one EPI (S*C*pitch floats) must stay below 2 GiB: the scan addresses it with 32-bit byte offsets");
     HIP_TRY(hipSetDevice(ctx->device));
     rslf_volume* vol = new (std::nothrow) rslf_volume();
     if (!vol)
