@@ -630,13 +630,25 @@ __device__ __forceinline__ void scan_reg_body(const ScanArgs& a, int v, int u, i
                 A[c] = 0.0f;
             B = 0.0f;
             if (C == 1) {
-                // hand-scheduled, four samples per block (rslf_device.hpp)
+                // hand-scheduled, four samples per block (rslf_device.hpp).  Only the last kPadSlack slots can
+                // be padding: there a wave-uniform test skips what lies beyond S (a padded slot would add +0
+                // to both sums, so skipping it changes nothing but the instruction count).
 #pragma unroll
-                for (int s0 = 0; s0 < SPAD; s0 += 4)
-                    mean_shift_group4(R[0][s0], R[0][s0 + 1], R[0][s0 + 2], R[0][s0 + 3], rbar[0], kq, A[0], B);
+                for (int s0 = 0; s0 < SPAD; s0 += 4) {
+                    if (s0 + 4 <= SPAD - kPadSlack || s0 + 4 <= S) {
+                        mean_shift_group4(R[0][s0], R[0][s0 + 1], R[0][s0 + 2], R[0][s0 + 3], rbar[0], kq, A[0], B);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 3; j++)
+                            if (s0 + j < S)
+                                mean_shift_group1(R[0][s0 + j], rbar[0], kq, A[0], B);
+                    }
+                }
             } else {
 #pragma unroll
                 for (int s = 0; s < SPAD; s++) {
+                    if (!(s < SPAD - kPadSlack || s < S))   // wave-uniform: padding slot
+                        continue;
                     float q[C];
 #pragma unroll
                     for (int c = 0; c < C; c++) {

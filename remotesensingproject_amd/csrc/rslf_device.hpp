@@ -113,6 +113,21 @@ __device__ __forceinline__ void mean_shift_group4(float r0, float r1, float r2, 
         : "v"(r0), "v"(r1), "v"(r2), "v"(r3), "v"(rbar), "s"(k1));
 }
 
+// One sample of the same pass (the tail of a view count that is not a multiple of four).
+__device__ __forceinline__ void mean_shift_group1(float r0, float rbar, float k1, float& A, float& B)
+{
+    float t0, u0;
+    asm("v_sub_f32 %2, %4, %5\n\t"
+        "v_mul_f32 %3, %6, %2\n\t"
+        "v_mul_f32 %2, %2, %3\n\t"
+        "v_sub_f32_e64 %2, 1.0, %2 clamp\n\t"
+        "v_mul_f32 %3, %4, %2\n\t"
+        "v_add_f32 %0, %0, %3\n\t"
+        "v_add_f32 %1, %1, %2"
+        : "+v"(A), "+v"(B), "=&v"(t0), "=&v"(u0)
+        : "v"(r0), "v"(rbar), "s"(k1));
+}
+
 // cv::BORDER_REFLECT_101
 __device__ __forceinline__ int reflect101(int p, int len)
 {
