@@ -258,6 +258,23 @@ int rslf_f2c_tighten_bounds(rslf_ctx* ctx, const float* d_depth_up_svu, const ui
 int rslf_f2c_fuse(rslf_ctx* ctx, const float* const* d_disp, const uint8_t* const* d_valid, const int* Vp, const int* Up,
                   int P, int S, float* d_out_map_svu, uint8_t* d_out_valid_svu);
 
+/* ---- the rows around the path, host pointers --------------------------- */
+/* rslf::Depth2DComputer<T>::run() with host result planes ([S][V][U], rbar [S][V][U][C]; any may be NULL). */
+int rslf_depth2d_run_host(rslf_ctx* ctx, const rslf_volume* vol, float dmin, float dmax, int dim_d, const rslf_params* p,
+                          float* h_Ce_svu, uint8_t* h_Ce_mask_svu, float* h_Cd_svu, float* h_depth_svu,
+                          float* h_rbar_svu, rslf_stats* stats);
+
+/* rslf::FineToCoarse<T>: constructor + run() + get_results() -- include/rslf_fine_to_coarse.hpp:103-324 --
+ * from the reference's Vec<Mat> (h_epis[v] -> S rows of U*C values, row_stride_bytes apart; is_u8
+ * selects uchar input).  The whole pyramid loop runs inside the library.
+ *   h_out_map_svu / h_out_valid_svu  [S][V][U] fused disparity map and validity at the finest scale
+ *   n_levels (nullable)              pyramid depth that was built
+ *   stats->units                     sums every visit of every level */
+int rslf_fine_to_coarse_run_host(rslf_ctx* ctx, const void* const* h_epis, int is_u8, int V, int S, int U, int C,
+                                 size_t row_stride_bytes, float d_min, float d_max, int dim_d, float epi_scale_factor,
+                                 const rslf_params* p, int max_pyr_depth, int accept_all_last_scale,
+                                 float* h_out_map_svu, uint8_t* h_out_valid_svu, int* n_levels, rslf_stats* stats);
+
 /* ---- measurement ------------------------------------------------------ */
 /* Duration in milliseconds of the last scan-kernel launch (K2) of this
  * context, from HIP events recorded on the context's stream around that

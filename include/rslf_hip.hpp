@@ -249,6 +249,111 @@ private:
     const Depth1DParameters m_parameters;
 };
 
+// rslf::Depth2DComputer<DataType> (dc.hpp:166-225, :651-805): disparities for every view, centre outwards,
+// with propagation along EPI lines.  Results are dense [S][V][U] host vectors after run().
+template <int CHANNELS>
+class Depth2DComputer {
+public:
+    Depth2DComputer(Context& ctx, const void* const* epis, bool is_u8, int dim_v, int dim_s, int dim_u, size_t row_stride_bytes,
+                    float dmin, float dmax, int dim_d, float epi_scale_factor = -1,
+                    const Depth1DParameters& parameters = Depth1DParameters::get_default())
+        : ctx_(ctx), vol_(nullptr), dim_v_(dim_v), dim_s_(dim_s), dim_u_(dim_u), m_dim_d(dim_d), m_dmin(dmin), m_dmax(dmax),
+          m_parameters(parameters)
+    {
+        stats = rslf_stats();
+        check(rslf_volume_create(ctx_.get(), dim_v, dim_s, dim_u, CHANNELS, &vol_), "rslf_volume_create");
+        if (is_u8)
+            check(rslf_volume_upload_epis_u8(vol_, (const uint8_t* const*)epis, row_stride_bytes), "rslf_volume_upload_epis_u8");
+        else
+            check(rslf_volume_upload_epis_f32(vol_, (const float* const*)epis, row_stride_bytes, epi_scale_factor, nullptr),
+                  "rslf_volume_upload_epis_f32");
+    }
+    ~Depth2DComputer() { rslf_volume_destroy(vol_); }
+    Depth2DComputer(const Depth2DComputer&) = delete;
+    Depth2DComputer& operator=(const Depth2DComputer&) = delete;
+
+    void run()   // dc.hpp:748-805
+    {
+        const size_t n = (size_t)dim_s_ * dim_v_ * dim_u_;
+        m_edge_confidence_s_v_u.assign(n, 0.f);
+        m_edge_confidence_mask_s_v_u.assign(n, 0);
+        m_disp_confidence_s_v_u.assign(n, 0.f);
+        m_best_depth_s_v_u.assign(n, 0.f);
+        m_rbar_s_v_u.assign(n * CHANNELS, 0.f);
+        const rslf_params p = m_parameters.to_c();
+        check(rslf_depth2d_run_host(ctx_.get(), vol_, m_dmin, m_dmax, m_dim_d, &p, m_edge_confidence_s_v_u.data(),
+                                    m_edge_confidence_mask_s_v_u.data(), m_disp_confidence_s_v_u.data(),
+                                    m_best_depth_s_v_u.data(), m_rbar_s_v_u.data(), &stats),
+              "rslf_depth2d_run_host");
+    }
+    const std::vector<float>& get_depths_s_v_u() const { return m_best_depth_s_v_u; }
+
+    std::vector<float> m_edge_confidence_s_v_u;
+    std::vector<uint8_t> m_edge_confidence_mask_s_v_u;
+    std::vector<float> m_disp_confidence_s_v_u;
+    std::vector<float> m_rbar_s_v_u;
+    std::vector<float> m_best_depth_s_v_u;
+    rslf_stats stats;
+
+private:
+    Context& ctx_;
+    rslf_volume* vol_;
+    int dim_v_, dim_s_, dim_u_, m_dim_d;
+    float m_dmin, m_dmax;
+    const Depth1DParameters m_parameters;
+};
+
+// rslf::FineToCoarse<DataType> (include/rslf_fine_to_coarse.hpp:26-81): constructor arguments as in the
+// reference; run() builds the pyramid, sweeps every level and fuses; get_results() hands out the fused maps.
+template <int CHANNELS>
+class FineToCoarse {
+public:
+    FineToCoarse(Context& ctx, const void* const* epis, bool is_u8, int dim_v, int dim_s, int dim_u, size_t row_stride_bytes,
+                 float d_min, float d_max, int dim_d, float epi_scale_factor = -1,
+                 const Depth1DParameters& parameters = Depth1DParameters::get_default(), int max_pyr_depth = -1,
+                 bool accept_all_last_scale = true)
+        : ctx_(ctx), epis_(epis, epis + dim_v), is_u8_(is_u8), dim_v_(dim_v), dim_s_(dim_s), dim_u_(dim_u),
+          stride_(row_stride_bytes), d_min_(d_min), d_max_(d_max), dim_d_(dim_d), scale_(epi_scale_factor),
+          m_parameters(parameters), max_pyr_depth_(max_pyr_depth), accept_all_(accept_all_last_scale), n_levels_(0)
+    {
+        stats = rslf_stats();
+    }
+    void run()
+    {
+        const size_t n = (size_t)dim_s_ * dim_v_ * dim_u_;
+        out_map_s_v_u_.assign(n, 0.f);
+        out_validity_s_v_u_.assign(n, 0);
+        const rslf_params p = m_parameters.to_c();
+        check(rslf_fine_to_coarse_run_host(ctx_.get(), epis_.data(), is_u8_ ? 1 : 0, dim_v_, dim_s_, dim_u_, CHANNELS, stride_,
+                                           d_min_, d_max_, dim_d_, scale_, &p, max_pyr_depth_, accept_all_ ? 1 : 0,
+                                           out_map_s_v_u_.data(), out_validity_s_v_u_.data(), &n_levels_, &stats),
+              "rslf_fine_to_coarse_run_host");
+    }
+    void get_results(std::vector<float>& out_map_s_v_u, std::vector<uint8_t>& out_validity_s_v_u) const
+    {
+        out_map_s_v_u = out_map_s_v_u_;
+        out_validity_s_v_u = out_validity_s_v_u_;
+    }
+    int pyramid_depth() const { return n_levels_; }
+    rslf_stats stats;
+
+private:
+    Context& ctx_;
+    std::vector<const void*> epis_;
+    bool is_u8_;
+    int dim_v_, dim_s_, dim_u_;
+    size_t stride_;
+    float d_min_, d_max_;
+    int dim_d_;
+    float scale_;
+    const Depth1DParameters m_parameters;
+    int max_pyr_depth_;
+    bool accept_all_;
+    int n_levels_;
+    std::vector<float> out_map_s_v_u_;
+    std::vector<uint8_t> out_validity_s_v_u_;
+};
+
 typedef Depth1DComputer_pile<1> Depth1DComputer_pile_1ch;   // dc.hpp:149
 typedef Depth1DComputer_pile<3> Depth1DComputer_pile_3ch;   // dc.hpp:154
 

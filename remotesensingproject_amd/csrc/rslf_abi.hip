@@ -1171,6 +1171,239 @@ extern "C" int rslf_f2c_fuse(rslf_ctx* ctx, const float* const* d_disp, const ui
     return RSLF_OK;
 }
 
+// ---- host-pointer forms of the rows around the path -----------------------------
+
+extern "C" int rslf_depth2d_run_host(rslf_ctx* ctx, const rslf_volume* vol, float dmin, float dmax, int dim_d, const rslf_params* p,
+                                     float* h_Ce_svu, uint8_t* h_Ce_mask_svu, float* h_Cd_svu, float* h_depth_svu,
+                                     float* h_rbar_svu, rslf_stats* stats)
+{
+    if (!ctx || !vol)
+        return fail(RSLF_ERR_INVALID_ARG, "NULL argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t n = (size_t)vol->S * vol->V * vol->U;
+    DevBuf Ce, Cd, depth, rbar, mask;
+    HIP_TRY(Ce.alloc(n * 4));
+    HIP_TRY(Cd.alloc(n * 4));
+    HIP_TRY(depth.alloc(n * 4));
+    HIP_TRY(rbar.alloc(n * 4 * vol->C));
+    HIP_TRY(mask.alloc(n));
+    int rc = rslf_depth2d_run(ctx, vol, dmin, dmax, dim_d, p, (float*)Ce.p, (uint8_t*)mask.p, (float*)Cd.p, (float*)depth.p,
+                              (float*)rbar.p, nullptr, stats);
+    if (rc)
+        return rc;
+    hipStream_t st = ctx->stream;
+    if (h_Ce_svu) HIP_TRY(hipMemcpyAsync(h_Ce_svu, Ce.p, n * 4, hipMemcpyDeviceToHost, st));
+    if (h_Ce_mask_svu) HIP_TRY(hipMemcpyAsync(h_Ce_mask_svu, mask.p, n, hipMemcpyDeviceToHost, st));
+    if (h_Cd_svu) HIP_TRY(hipMemcpyAsync(h_Cd_svu, Cd.p, n * 4, hipMemcpyDeviceToHost, st));
+    if (h_depth_svu) HIP_TRY(hipMemcpyAsync(h_depth_svu, depth.p, n * 4, hipMemcpyDeviceToHost, st));
+    if (h_rbar_svu) HIP_TRY(hipMemcpyAsync(h_rbar_svu, rbar.p, n * 4 * vol->C, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return RSLF_OK;
+}
+
+namespace {
+// One pyramid level of rslf::FineToCoarse: its Depth2DComputer's volume and result planes.
+struct F2cLevel {
+    rslf_volume* vol = nullptr;
+    int V = 0, U = 0;
+    DevBuf Ce, Cd, depth, rbar, mask, valid, dmin, dmax;
+    rslf_params params;
+    ~F2cLevel() { rslf_volume_destroy(vol); }
+};
+
+__global__ __launch_bounds__(256) void k_u8_to_f32(const uint8_t* __restrict__ in, float* __restrict__ out, long long n)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        out[i] = (float)in[i];
+}
+__global__ __launch_bounds__(256) void k_fill_f32(float* __restrict__ out, long long n, float value)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        out[i] = value;
+}
+// get_valid_depths_mask_s_v_u (dc.hpp:893-915, default build): C_e > thr, or everything with accept_all
+__global__ __launch_bounds__(256) void k_valid_mask(const float* __restrict__ Ce, uint8_t* __restrict__ out, long long n, float thr)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        out[i] = (Ce[i] > thr) ? 255 : 0;
+}
+inline unsigned stream_blocks(size_t n) { return (unsigned)std::min<size_t>((n + 255) / 256, 8192); }
+}  // namespace
+
+extern "C" int rslf_fine_to_coarse_run_host(rslf_ctx* ctx, const void* const* h_epis, int is_u8, int V, int S, int U, int C,
+                                            size_t row_stride_bytes, float d_min, float d_max, int dim_d, float epi_scale_factor,
+                                            const rslf_params* p, int max_pyr_depth, int accept_all_last_scale,
+                                            float* h_out_map_svu, uint8_t* h_out_valid_svu, int* n_levels, rslf_stats* stats)
+{
+    if (!ctx || !h_epis || !h_out_map_svu || !h_out_valid_svu || V < 1 || S < 1 || U < 1 || (C != 1 && C != 3))
+        return fail(RSLF_ERR_INVALID_ARG, "bad arguments");
+    int rc = check_params(p);
+    if (rc)
+        return rc;
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const size_t elem = is_u8 ? 1 : 4;
+    const size_t row_bytes = (size_t)U * C * elem;
+    if (row_stride_bytes == 0)
+        row_stride_bytes = row_bytes;
+
+    // the raw (un-normalised) finest level as a dense float volume [V][S][U][C]
+    DevBuf raw;
+    HIP_TRY(raw.alloc((size_t)V * S * U * C * sizeof(float)));
+    {
+        DevBuf stage;
+        void* dst = raw.p;
+        if (is_u8) {
+            HIP_TRY(stage.alloc((size_t)V * S * row_bytes));
+            dst = stage.p;
+        }
+        for (int v = 0; v < V; v++) {
+            if (!h_epis[v])
+                return fail(RSLF_ERR_INVALID_ARG, "h_epis[%d] is NULL", v);
+            HIP_TRY(hipMemcpy2DAsync((char*)dst + (size_t)v * S * row_bytes, row_bytes, h_epis[v], row_stride_bytes, row_bytes, S,
+                                     hipMemcpyHostToDevice, st));
+        }
+        if (is_u8) {
+            const size_t n = (size_t)V * S * U * C;
+            hipLaunchKernelGGL(k_u8_to_f32, dim3(stream_blocks(n)), dim3(256), 0, st, (const uint8_t*)stage.p, (float*)raw.p,
+                               (long long)n);
+            HIP_TRY(hipGetLastError());
+        }
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+
+    // constructor: rslf_fine_to_coarse.hpp:103-159
+    if (max_pyr_depth < 1)
+        max_pyr_depth = 1 << 30;
+    std::vector<F2cLevel*> levels;
+    struct Cleanup {
+        std::vector<F2cLevel*>& l;
+        ~Cleanup() { for (F2cLevel* x : l) delete x; }
+    } cleanup{levels};
+    const int start_dim_u = U;
+    int dim_v = V, dim_u = U, counter = 0;
+    DevBuf cur;           // raw volume of the level being built (level 0 borrows `raw`)
+    float* cur_p = (float*)raw.p;
+    while (dim_v > 10 && dim_u > 10 && counter < max_pyr_depth) {   // _MIN_SPATIAL_DIM, f2c.hpp:8, :130
+        counter++;
+        F2cLevel* lv = new (std::nothrow) F2cLevel();
+        if (!lv)
+            return fail(RSLF_ERR_ALLOC, "out of host memory");
+        levels.push_back(lv);
+        lv->V = dim_v;
+        lv->U = dim_u;
+        lv->params = *p;
+        lv->params.slope_factor = (float)((0.0 + dim_u) / start_dim_u);   // f2c.hpp:139
+        float scale = 255.0f;                                              // dc.hpp:696-699 (uchar)
+        if (!is_u8) {
+            scale = epi_scale_factor;
+            if (scale < 0) {                                               // dc.hpp:671-690: this level's own max
+                rc = rslf_device_max_f32(ctx, cur_p, (size_t)dim_v * S * dim_u * C, &scale);
+                if (rc)
+                    return rc;
+            }
+        }
+        rc = rslf_volume_create(ctx, dim_v, S, dim_u, C, &lv->vol);
+        if (rc)
+            return rc;
+        rc = rslf_volume_pack_device_f32(lv->vol, cur_p, scale, nullptr);
+        if (rc)
+            return rc;
+        int v2, u2;
+        rslf_f2c_level_dims(dim_v, dim_u, &v2, &u2);
+        if (v2 < 1 || u2 < 1)
+            break;
+        DevBuf next;                                                       // f2c.hpp:145-147: the RAW EPIs go down
+        HIP_TRY(next.alloc((size_t)v2 * S * u2 * C * sizeof(float)));
+        rc = rslf_downsample_epis_f32(ctx, cur_p, dim_v, S, dim_u, C, (float*)next.p);
+        if (rc)
+            return rc;
+        std::swap(cur.p, next.p);   // `next` now frees the previous level's raw copy
+        cur_p = (float*)cur.p;
+        dim_v = v2;
+        dim_u = u2;
+    }
+    if (levels.empty())
+        return fail(RSLF_ERR_INVALID_ARG, "light field %dx%d is not larger than _MIN_SPATIAL_DIM: no pyramid level", V, U);
+    const int P = (int)levels.size();
+
+    // run(): rslf_fine_to_coarse.hpp:171-299
+    int64_t pixels = 0;
+    rslf_stats st1;
+    for (int l = 0; l < P; l++) {
+        F2cLevel& lv = *levels[l];
+        const size_t n = (size_t)S * lv.V * lv.U;
+        HIP_TRY(lv.Ce.alloc(n * 4));
+        HIP_TRY(lv.Cd.alloc(n * 4));
+        HIP_TRY(lv.depth.alloc(n * 4));
+        HIP_TRY(lv.rbar.alloc(n * 4 * C));
+        HIP_TRY(lv.mask.alloc(n));
+        HIP_TRY(lv.valid.alloc(n));
+        if (l == 0) {
+            rc = rslf_depth2d_run(ctx, lv.vol, d_min, d_max, dim_d, &lv.params, (float*)lv.Ce.p, (uint8_t*)lv.mask.p, (float*)lv.Cd.p,
+                                  (float*)lv.depth.p, (float*)lv.rbar.p, nullptr, &st1);
+        } else {
+            F2cLevel& up = *levels[l - 1];
+            HIP_TRY(lv.dmin.alloc(n * 4));
+            HIP_TRY(lv.dmax.alloc(n * 4));
+            hipLaunchKernelGGL(k_fill_f32, dim3(stream_blocks(n)), dim3(256), 0, st, (float*)lv.dmin.p, (long long)n, d_min);
+            hipLaunchKernelGGL(k_fill_f32, dim3(stream_blocks(n)), dim3(256), 0, st, (float*)lv.dmax.p, (long long)n, d_max);
+            HIP_TRY(hipGetLastError());
+            rc = rslf_f2c_tighten_bounds(ctx, (const float*)up.depth.p, (const uint8_t*)up.valid.p, S, up.V, up.U, (float*)lv.dmin.p,
+                                         (float*)lv.dmax.p, lv.V, lv.U);
+            if (rc)
+                return rc;
+            HIP_TRY(hipMemsetAsync(lv.Ce.p, 0, n * 4, st));
+            HIP_TRY(hipMemsetAsync(lv.Cd.p, 0, n * 4, st));
+            HIP_TRY(hipMemsetAsync(lv.depth.p, 0, n * 4, st));
+            HIP_TRY(hipMemsetAsync(lv.rbar.p, 0, n * 4 * C, st));
+            rc = rslf_edge_confidence_2d(ctx, lv.vol, &lv.params, (float*)lv.Ce.p, (uint8_t*)lv.mask.p);
+            if (rc)
+                return rc;
+            rc = rslf_depth_epi_2d(ctx, lv.vol, (const float*)lv.dmin.p, (const float*)lv.dmax.p, d_min, d_max, dim_d,
+                                   (float*)lv.Ce.p, (uint8_t*)lv.mask.p, (float*)lv.Cd.p, (float*)lv.depth.p, (float*)lv.rbar.p,
+                                   &lv.params, nullptr, &st1);
+        }
+        if (rc)
+            return rc;
+        pixels += st1.pixels_scanned;
+        // get_valid_depths_mask_s_v_u: the last level accepts everything when asked to (f2c.hpp:157-158)
+        const bool all = accept_all_last_scale && l == P - 1;
+        hipLaunchKernelGGL(k_valid_mask, dim3(stream_blocks(n)), dim3(256), 0, st, (const float*)lv.Ce.p, (uint8_t*)lv.valid.p,
+                           (long long)n, all ? -1.0f : p->edge_score_threshold);
+        HIP_TRY(hipGetLastError());
+    }
+
+    // get_results(): rslf_fine_to_coarse.hpp:302-324
+    std::vector<const float*> dp(P);
+    std::vector<const uint8_t*> vp(P);
+    std::vector<int> Vp(P), Up(P);
+    for (int l = 0; l < P; l++) {
+        dp[l] = (const float*)levels[l]->depth.p;
+        vp[l] = (const uint8_t*)levels[l]->valid.p;
+        Vp[l] = levels[l]->V;
+        Up[l] = levels[l]->U;
+    }
+    const size_t n0 = (size_t)S * V * U;
+    DevBuf omap, ovalid;
+    HIP_TRY(omap.alloc(n0 * 4));
+    HIP_TRY(ovalid.alloc(n0));
+    rc = rslf_f2c_fuse(ctx, dp.data(), vp.data(), Vp.data(), Up.data(), P, S, (float*)omap.p, (uint8_t*)ovalid.p);
+    if (rc)
+        return rc;
+    HIP_TRY(hipMemcpyAsync(h_out_map_svu, omap.p, n0 * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(h_out_valid_svu, ovalid.p, n0, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (n_levels)
+        *n_levels = P;
+    if (stats) {
+        *stats = st1;
+        stats->pixels_scanned = pixels;
+        stats->units = pixels * dim_d;
+    }
+    return RSLF_OK;
+}
+
 extern "C" int rslf_last_scan_kernel_ms(rslf_ctx* ctx, float* ms)
 {
     if (!ctx || !ms)

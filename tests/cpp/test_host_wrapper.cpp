@@ -65,6 +65,46 @@ static int run_case(rslfx::Context& ctx, const std::string& dir, const std::stri
     return 0;
 }
 
+// The rows around the path through the same header: Depth2DComputer and FineToCoarse on plain buffers.
+static int run_sweeps(rslfx::Context& ctx, const std::string& dir)
+{
+    const int V = 44, S = 5, U = 64, D = 9;
+    std::vector<std::vector<float> > epis(V);
+    std::vector<const void*> ptrs(V);
+    std::vector<float> flat;
+    unsigned state = 777u;
+    for (int v = 0; v < V; v++) {
+        epis[v].resize((size_t)S * U);
+        // a little structure: the same texture in every view, shifted by one column per view on the lower half
+        std::vector<float> tex(U + 2 * S);
+        for (size_t i = 0; i < tex.size(); i++) {
+            state = state * 1664525u + 1013904223u;
+            tex[i] = 3.0f + 200.0f * (float)((state >> 8) & 0xffffu) / 65535.0f;
+        }
+        for (int s = 0; s < S; s++)
+            for (int u = 0; u < U; u++)
+                epis[v][(size_t)s * U + u] = tex[u + S + ((v >= V / 2) ? (s - S / 2) : 0)];
+        ptrs[v] = epis[v].data();
+        flat.insert(flat.end(), epis[v].begin(), epis[v].end());
+    }
+    dump(dir + "/sweep_input.f32", flat);
+    rslfx::Depth2DComputer<1> d2(ctx, ptrs.data(), false, V, S, U, 0, -1.0f, 1.0f, D);
+    d2.run();
+    dump(dir + "/d2_depth.f32", d2.get_depths_s_v_u());
+    dump(dir + "/d2_mask.u8", d2.m_edge_confidence_mask_s_v_u);
+    dump(dir + "/d2_Ce.f32", d2.m_edge_confidence_s_v_u);
+    rslfx::FineToCoarse<1> f2c(ctx, ptrs.data(), false, V, S, U, 0, -1.0f, 1.0f, D);
+    f2c.run();
+    std::vector<float> map;
+    std::vector<uint8_t> valid;
+    f2c.get_results(map, valid);
+    dump(dir + "/f2c_map.f32", map);
+    dump(dir + "/f2c_valid.u8", valid);
+    std::printf("sweeps: Depth2DComputer scanned %lld px, FineToCoarse %d levels, %lld px\n", (long long)d2.stats.pixels_scanned,
+                f2c.pyramid_depth(), (long long)f2c.stats.pixels_scanned);
+    return f2c.pyramid_depth() == 3 ? 0 : 8;   // 44x64 -> 22x32 -> 11x16, then 6x8 stops the pyramid
+}
+
 int main(int argc, char** argv)
 {
     const std::string dir = argc > 1 ? argv[1] : ".";
@@ -74,6 +114,7 @@ int main(int argc, char** argv)
         rc |= run_case<1>(ctx, dir, "f32_1ch", false);
         rc |= run_case<3>(ctx, dir, "f32_3ch", false);
         rc |= run_case<3>(ctx, dir, "u8_3ch", true);
+        rc |= run_sweeps(ctx, dir);
         // error convention: the C-ABI never throws; the C++ wrapper turns its status into rslfx::Error
         bool threw = false;
         try {

@@ -35,3 +35,15 @@ def test_cpp_wrapper_matches_oracle(tmp_path, oracle_mod):
         assert np.array_equal(rd("depth.f32", np.float32).reshape(V, U), ref.depth), tag
         assert np.array_equal(rd("rbar.f32", np.float32).reshape(V, U, C_), ref.rbar), tag
         assert np.abs(rd("Cd.f32", np.float32).reshape(V, U) - ref.disp_confidence).max() <= 1e-5, tag
+    # Depth2DComputer and FineToCoarse through the C++ classes (host pointers in, host planes out)
+    V, S, U, D = 44, 5, 64, 9
+    raw = np.fromfile(tmp_path / "sweep_input.f32", np.float32).reshape(V, S, U, 1)
+    norm, _ = oracle_mod.normalize_f32(raw, -1.0)
+    ref2 = oracle_mod.depth2d_run(norm, -1.0, 1.0, D)
+    assert np.array_equal(np.fromfile(tmp_path / "d2_mask.u8", np.uint8).reshape(S, V, U), ref2.edge_mask)
+    assert np.array_equal(np.fromfile(tmp_path / "d2_Ce.f32", np.float32).reshape(S, V, U), ref2.edge_confidence)
+    assert np.array_equal(np.fromfile(tmp_path / "d2_depth.f32", np.float32).reshape(S, V, U), ref2.depth)
+    reff = oracle_mod.fine_to_coarse_run(raw, -1.0, 1.0, D)
+    assert reff["dims"] == [(44, 64), (22, 32), (11, 16)]
+    assert np.array_equal(np.fromfile(tmp_path / "f2c_map.f32", np.float32).reshape(S, V, U), reff["fused_map"])
+    assert np.array_equal(np.fromfile(tmp_path / "f2c_valid.u8", np.uint8).reshape(S, V, U), reff["fused_valid"])
