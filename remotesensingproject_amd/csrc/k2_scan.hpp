@@ -46,8 +46,22 @@ struct ScanArgs {
     int32_t* idx;           // nullable
     float* score;           // nullable
     int tiles_per_row;      // ceil(U / 64)
-    int logical_blocks;     // V * tiles_per_row
+    int logical_blocks;     // V * tiles_per_row * groups
     int per_xcd;            // ceil(logical_blocks / 8)
+    // Hypothesis groups: `groups` workgroups share one tile, each taking a contiguous slice of the
+    // hypothesis range (its 4 waves a quarter of the slice each).  groups == 1: the workgroup writes the
+    // pixel itself.  groups > 1 (launches expected to be sparse, where the launch lasts as long as ONE
+    // wave's walk over its hypotheses): each workgroup leaves a partial record and k2_scan_combine merges
+    // them in hypothesis order.
+    int groups;
+    struct Partial* partial;   // [tile][group][64]
+};
+
+struct Partial {   // one lane's merged result over one group's hypotheses
+    float score, D;
+    int d;
+    float rbar[3];
+    double sum;
 };
 
 // One lane's running result over the hypotheses it has scored (core.hpp:630-644).
@@ -90,8 +104,9 @@ __device__ __forceinline__ bool scan_tile(const ScanArgs& a, int& v, int& u, boo
     const int lb = xcd_logical_block(blockIdx.x, a.per_xcd);
     if (lb >= a.logical_blocks)
         return false;
-    v = lb / a.tiles_per_row;
-    const int j = lb - v * a.tiles_per_row;
+    const int tile = lb / a.groups;
+    v = tile / a.tiles_per_row;
+    const int j = tile - v * a.tiles_per_row;
     const int n = a.count[v];
     if (j * 64 >= n)
         return false;
@@ -107,8 +122,10 @@ __device__ __forceinline__ void scan_chunk(const ScanArgs& a, int& d0, int& d1)
 {
     // wave-uniform by construction; readfirstlane lets the compiler keep it in an SGPR
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int chunk = (a.dim_d + kScanWaves - 1) / kScanWaves;
-    d0 = min(wave * chunk, a.dim_d);
+    const int group = xcd_logical_block(blockIdx.x, a.per_xcd) % a.groups;
+    const int slices = kScanWaves * a.groups;
+    const int chunk = (a.dim_d + slices - 1) / slices;
+    d0 = min((group * kScanWaves + wave) * chunk, a.dim_d);
     d1 = min(d0 + chunk, a.dim_d);
 }
 
@@ -120,7 +137,30 @@ __device__ __forceinline__ float hypothesis(float dmin, float range, float denom
     return dmin + quo;
 }
 
-// Merge the waves' partial results in hypothesis order and write the pixel (core.hpp:630-657).
+// core.hpp:636-657 for one pixel once every hypothesis is scored.
+template <int C>
+__device__ __forceinline__ void write_pixel(const ScanArgs& a, long long o, float best, int best_d, float best_D,
+                                            const float (&best_rbar)[C], double sum)
+{
+    if ((double)best > (double)a.k.raw_thr) {   // core.hpp:636
+        a.depth[o] = best_D;
+        const double mean = sum / (double)a.dim_d;
+        a.Cd[o] = (float)((double)a.Ce[o] * fabs((double)best - mean));   // core.hpp:641
+#pragma unroll
+        for (int c = 0; c < C; c++)
+            a.rbar[o * C + c] = best_rbar[c];
+        if (a.idx)
+            a.idx[o] = best_d;
+        if (a.score)
+            a.score[o] = best;
+    } else {   // core.hpp:653-657
+        a.Ce[o] = 0.0f;
+        a.Ce_mask[o] = 0;
+    }
+}
+
+// Merge the waves' partial results in hypothesis order (first maximum wins, cv::minMaxLoc) and either
+// write the pixel (groups == 1) or leave this group's record for k2_scan_combine.
 template <int C>
 __device__ __forceinline__ void scan_epilogue(const ScanArgs& a, int v, int u, bool active, const Best<C>& mine)
 {
@@ -138,7 +178,7 @@ __device__ __forceinline__ void scan_epilogue(const ScanArgs& a, int v, int u, b
     for (int c = 0; c < C; c++)
         s_rbar[wave][c][lane] = mine.rbar[c];
     __syncthreads();
-    if (wave != 0 || !active)
+    if (wave != 0)
         return;
 
     float best = mine.score, best_D = mine.D;
@@ -161,23 +201,55 @@ __device__ __forceinline__ void scan_epilogue(const ScanArgs& a, int v, int u, b
                 best_rbar[c] = s_rbar[w][c][lane];
         }
     }
-
-    const long long o = (long long)v * a.vol.U + u;
-    if ((double)best > (double)a.k.raw_thr) {   // core.hpp:636
-        a.depth[o] = best_D;
-        const double mean = sum / (double)a.dim_d;
-        a.Cd[o] = (float)((double)a.Ce[o] * fabs((double)best - mean));   // core.hpp:641
+    if (a.groups > 1) {
+        const int lb = xcd_logical_block(blockIdx.x, a.per_xcd);   // = tile * groups + group
+        Partial& pr = a.partial[(long long)lb * 64 + lane];
+        pr.score = best;
+        pr.D = best_D;
+        pr.d = best_d;
+        pr.sum = sum;
 #pragma unroll
         for (int c = 0; c < C; c++)
-            a.rbar[o * C + c] = best_rbar[c];
-        if (a.idx)
-            a.idx[o] = best_d;
-        if (a.score)
-            a.score[o] = best;
-    } else {   // core.hpp:653-657
-        a.Ce[o] = 0.0f;
-        a.Ce_mask[o] = 0;
+            pr.rbar[c] = best_rbar[c];
+        return;
     }
+    if (active)
+        write_pixel<C>(a, (long long)v * a.vol.U + u, best, best_d, best_D, best_rbar, sum);
+}
+
+// groups > 1: one wave per tile merges the groups' records in hypothesis order and writes the pixels.
+template <int C>
+__global__ __launch_bounds__(64) void k2_scan_combine(ScanArgs a)
+{
+    const int tile = blockIdx.x;
+    const int v = tile / a.tiles_per_row;
+    const int j = tile - v * a.tiles_per_row;
+    const int n = a.count[v];
+    const int e = j * 64 + (int)threadIdx.x;
+    if (e >= n)
+        return;
+    const int u = a.list[(long long)v * a.vol.U + e];
+    const Partial* pr = a.partial + (long long)tile * a.groups * 64 + threadIdx.x;
+    float best = pr[0].score, best_D = pr[0].D;
+    int best_d = pr[0].d;
+    float best_rbar[C];
+#pragma unroll
+    for (int c = 0; c < C; c++)
+        best_rbar[c] = pr[0].rbar[c];
+    double sum = pr[0].sum;
+    for (int g = 1; g < a.groups; g++) {
+        const Partial& q = pr[(long long)g * 64];
+        sum += q.sum;
+        if (q.score > best) {
+            best = q.score;
+            best_d = q.d;
+            best_D = q.D;
+#pragma unroll
+            for (int c = 0; c < C; c++)
+                best_rbar[c] = q.rbar[c];
+        }
+    }
+    write_pixel<C>(a, (long long)v * a.vol.U + u, best, best_d, best_D, best_rbar, sum);
 }
 
 // ---------------------------------------------------------------------------

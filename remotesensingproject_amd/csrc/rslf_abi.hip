@@ -63,6 +63,9 @@ struct rslf_ctx {
     int last_spad = 0;   // register-scan slot count of the last K2 launch, 0 = none
     int last_kernel = 0; // RSLF_SCAN_* of the last K2 launch
     bool keep_total = false;   // the 2-D sweep sums the scanned pixels of all its visits
+    int scan_groups = 1;       // hypothesis groups per tile for the next scan launches (the 2-D sweep raises it)
+    Partial* scan_partial = nullptr;   // [tile][group][64] records of grouped scan launches
+    size_t partial_rec_cap = 0;
     // 2-D sweep scratch
     int* winner = nullptr;        // [S][V][U]
     uint8_t* sweep_mask = nullptr;
@@ -252,6 +255,7 @@ extern "C" int rslf_ctx_destroy(rslf_ctx* ctx)
     (void)hipFree(ctx->partial);
     (void)hipFree(ctx->minmax);
     (void)hipFree(ctx->staging);
+    (void)hipFree(ctx->scan_partial);
     (void)hipFree(ctx->winner);
     (void)hipFree(ctx->sweep_mask);
     (void)hipFree(ctx->filtered);
@@ -713,9 +717,29 @@ extern "C" int rslf_depth_epi_scan(rslf_ctx* ctx, const rslf_volume* vol, const 
     a.score = d_score_vu;
     a.tiles_per_row = (vol->U + 63) / 64;
     const long long tiles = (long long)vol->V * a.tiles_per_row;
-    if (tiles > (long long)1 << 30)
+    // hypothesis groups per tile: 1 unless the caller expects a sparse launch (ctx->scan_groups) and there
+    // are enough hypotheses to share out
+    int groups = std::max(1, ctx->scan_groups);
+    if (const char* fg = getenv("RSLF_FORCE_GROUPS"))   // parity tests: grouped launches on the pile path too
+        groups = std::min(64, std::max(1, atoi(fg)));
+    while (groups > 1 && dim_d < 2 * kScanWaves * groups)
+        groups /= 2;
+    if (tiles * groups > (long long)1 << 30)
         return fail(RSLF_ERR_UNSUPPORTED, "V * ceil(U/64) = %lld tiles exceeds the grid limit", tiles);
-    a.logical_blocks = (int)tiles;   // one workgroup per tile, its waves split the hypotheses
+    a.groups = groups;
+    a.partial = nullptr;
+    if (groups > 1) {
+        const size_t recs = (size_t)tiles * groups * 64;
+        if (recs > ctx->partial_rec_cap) {
+            HIP_TRY(hipFree(ctx->scan_partial));
+            ctx->scan_partial = nullptr;
+            ctx->partial_rec_cap = 0;
+            HIP_TRY(hipMalloc(&ctx->scan_partial, recs * sizeof(Partial)));
+            ctx->partial_rec_cap = recs;
+        }
+        a.partial = ctx->scan_partial;
+    }
+    a.logical_blocks = (int)(tiles * groups);   // `groups` workgroups per tile, their waves split the hypotheses
     a.per_xcd = (a.logical_blocks + 7) / 8;
     const dim3 grid((unsigned)(a.per_xcd * 8));
 
@@ -735,6 +759,7 @@ extern "C" int rslf_depth_epi_scan(rslf_ctx* ctx, const rslf_volume* vol, const 
         spad = 0;
     }
 
+    HIP_TRY(hipGetLastError());   // anything an earlier enqueue left behind is not this launch's fault
     ctx->last_spad = spad;
     ctx->last_kernel = spad ? RSLF_SCAN_REG : (stream_ok ? RSLF_SCAN_STREAM : RSLF_SCAN_GENERIC);
     HIP_TRY(hipEventRecord(ctx->ev0, st));
@@ -755,6 +780,13 @@ extern "C" int rslf_depth_epi_scan(rslf_ctx* ctx, const rslf_volume* vol, const 
         hipLaunchKernelGGL(k2_scan_generic<3>, grid, dim3(64 * kScanWaves), 0, st, a);
     }
     HIP_TRY(hipGetLastError());
+    if (groups > 1) {
+        if (vol->C == 1)
+            hipLaunchKernelGGL(k2_scan_combine<1>, dim3((unsigned)tiles), dim3(64), 0, st, a);
+        else
+            hipLaunchKernelGGL(k2_scan_combine<3>, dim3((unsigned)tiles), dim3(64), 0, st, a);
+        HIP_TRY(hipGetLastError());
+    }
     HIP_TRY(hipEventRecord(ctx->ev1, st));
     ctx->ev_valid = true;
 
@@ -985,7 +1017,12 @@ extern "C" int rslf_depth_epi_2d(rslf_ctx* ctx, const rslf_volume* vol, const fl
     const dim3 grid_vu((U + 255) / 256, V);
     const unsigned apply_blocks = (unsigned)std::min<size_t>(((size_t)S * n + 255) / 256, 256 * 8 * 4);
     ctx->keep_total = true;
+    bool first_visit = true;
     for (int s_hat : order) {
+        // After the centre view, propagation has explained most pixels: a visit scans a few per scanline
+        // and lasts as long as one wave's walk over its hypotheses -- share them out over 4x the waves.
+        ctx->scan_groups = first_visit ? 1 : 8;
+        first_visit = false;
         float* depth = d_depth_svu + (size_t)s_hat * n;
         float* Cd = d_Cd_svu + (size_t)s_hat * n;
         float* rbar = d_rbar_svu + (size_t)s_hat * n * C;
@@ -997,6 +1034,7 @@ extern "C" int rslf_depth_epi_2d(rslf_ctx* ctx, const rslf_volume* vol, const fl
                                  nullptr, ctx->raw, nullptr);
         if (rc) {
             ctx->keep_total = false;
+            ctx->scan_groups = 1;
             return rc;
         }
         // ... while in the reference the stored plane keeps the RAW depths and only the local header is
@@ -1016,6 +1054,7 @@ extern "C" int rslf_depth_epi_2d(rslf_ctx* ctx, const rslf_volume* vol, const fl
         HIP_TRY(hipGetLastError());
     }
     ctx->keep_total = false;
+    ctx->scan_groups = 1;
     if (stats) {
         unsigned long long tot = 0;
         HIP_TRY(hipMemcpyAsync(&tot, ctx->total, sizeof(tot), hipMemcpyDeviceToHost, st));

@@ -150,6 +150,29 @@ def test_stream_kernel_per_pixel_ranges(rs, oracle_mod, monkeypatch):
     assert np.array_equal(trbar.cpu().numpy(), ref.rbar)
 
 
+@pytest.mark.parametrize("groups,force,C_,S,U,D", [
+    (2, None, 1, 17, 130, 16),       # the smallest D a pair of groups accepts
+    (4, None, 1, 33, 200, 47),       # ragged chunks: 47 hypotheses over 16 slices
+    (8, None, 1, 9, 70, 64),
+    (8, None, 3, 13, 150, 100),
+    (4, "stream", 1, 21, 90, 40),
+    (4, "stream", 3, 11, 90, 33),
+    (2, "generic", 1, 15, 100, 24),
+    (16, None, 1, 12, 64, 31),       # more groups than D allows: halved until every slice has work
+])
+def test_hypothesis_groups(rs, oracle_mod, monkeypatch, groups, force, C_, S, U, D):
+    """Sparse launches of the 2-D sweep split each tile's hypotheses over several workgroups and merge
+    their records in k2_scan_combine: first-max arg-max, mean and r-bar must not depend on the split."""
+    monkeypatch.setenv("RSLF_FORCE_GROUPS", str(groups))
+    if force:
+        monkeypatch.setenv("RSLF_FORCE_SCAN", force)
+    vol = _vol("noise" if C_ == 1 else "struct", U, 3, S, C_, 900 + D, -1.5, 2.5)
+    ref = oracle_mod.depth1d_pile_run(vol, -1.5, 2.5, D)
+    comp, got = _run(rs, vol, -1.5, 2.5, D)
+    assert comp.stats.scan_kernel == {None: 1, "stream": 2, "generic": 0}[force]
+    assert_pile_parity(got, ref, label="groups%d_%s_C%d_D%d" % (groups, force, C_, D))
+
+
 def test_negative_radiances_take_generic_path(rs, oracle_mod):
     """max(R,0) != R when the input goes negative (core.hpp:580): register scan must not run."""
     rng = np.random.default_rng(11)

@@ -17,7 +17,9 @@ def _check(got, ref, label):
 
 
 @pytest.mark.parametrize("C,S,U,V,D,kind", [(1, 7, 80, 5, 12, "struct"), (1, 9, 140, 4, 10, "noise"), (3, 5, 70, 4, 8, "struct"),
-                                            (1, 6, 64, 3, 9, "struct"), (1, 13, 200, 3, 16, "mixed")])
+                                            (1, 6, 64, 3, 9, "struct"), (1, 13, 200, 3, 16, "mixed"),
+                                            # D >= 32: the later visits run as grouped launches (k2_scan_combine)
+                                            (1, 7, 100, 4, 40, "mixed"), (3, 5, 70, 3, 70, "struct"), (1, 9, 90, 3, 64, "noise")])
 def test_depth2d_matches_oracle(oracle_mod, C, S, U, V, D, kind):
     from remotesensingproject_amd import depth as rs
     from remotesensingproject_amd.synth import make_lightfield
