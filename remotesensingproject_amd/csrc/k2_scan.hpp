@@ -55,6 +55,12 @@ struct ScanArgs {
     // them in hypothesis order.
     int groups;
     struct Partial* partial;   // [tile][group][64]
+    // Packed tiles (sparse launches): `list` is ONE list of pixel indices v*U + u over all scanlines,
+    // *packed_n long, and a tile is 64 consecutive entries of it -- lanes of a wave then sit on different
+    // scanlines.  The grid is fixed and every workgroup strides over the (tile, group) items, because only
+    // the device knows how many there are.
+    int packed;
+    const int* packed_n;
 };
 
 struct Partial {   // one lane's merged result over one group's hypotheses
@@ -98,10 +104,10 @@ struct Best {
 
 // Which tile does this workgroup own, which pixel this lane?  Block-uniform result
 // (every wave of the block takes the same branch, so the later barrier is safe).
-__device__ __forceinline__ bool scan_tile(const ScanArgs& a, int& v, int& u, bool& active)
+// `lb` = tile * groups + group.
+__device__ __forceinline__ bool scan_tile(const ScanArgs& a, int lb, int& v, int& u, bool& active)
 {
     const int lane = threadIdx.x & 63;
-    const int lb = xcd_logical_block(blockIdx.x, a.per_xcd);
     if (lb >= a.logical_blocks)
         return false;
     const int tile = lb / a.groups;
@@ -117,12 +123,22 @@ __device__ __forceinline__ bool scan_tile(const ScanArgs& a, int& v, int& u, boo
     return true;
 }
 
+// Packed tiles: entry e of the flat list is pixel index v*U + u; `n` = *packed_n > tile * 64.
+__device__ __forceinline__ void scan_tile_packed(const ScanArgs& a, int item, int n, int& v, int& u, bool& active)
+{
+    const int lane = threadIdx.x & 63;
+    const int e = (item / a.groups) * 64 + lane;
+    active = e < n;
+    const unsigned o = (unsigned)a.list[active ? e : n - 1];
+    v = (int)(o / (unsigned)a.vol.U);
+    u = (int)(o - (unsigned)v * (unsigned)a.vol.U);
+}
+
 // This wave's hypotheses [d0, d1): contiguous quarters, so "first maximum" = lowest wave first.
-__device__ __forceinline__ void scan_chunk(const ScanArgs& a, int& d0, int& d1)
+__device__ __forceinline__ void scan_chunk(const ScanArgs& a, int group, int& d0, int& d1)
 {
     // wave-uniform by construction; readfirstlane lets the compiler keep it in an SGPR
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int group = xcd_logical_block(blockIdx.x, a.per_xcd) % a.groups;
     const int slices = kScanWaves * a.groups;
     const int chunk = (a.dim_d + slices - 1) / slices;
     d0 = min((group * kScanWaves + wave) * chunk, a.dim_d);
@@ -162,7 +178,7 @@ __device__ __forceinline__ void write_pixel(const ScanArgs& a, long long o, floa
 // Merge the waves' partial results in hypothesis order (first maximum wins, cv::minMaxLoc) and either
 // write the pixel (groups == 1) or leave this group's record for k2_scan_combine.
 template <int C>
-__device__ __forceinline__ void scan_epilogue(const ScanArgs& a, int v, int u, bool active, const Best<C>& mine)
+__device__ __forceinline__ void scan_epilogue(const ScanArgs& a, int lb, int v, int u, bool active, const Best<C>& mine)
 {
     __shared__ float s_score[kScanWaves][64];
     __shared__ float s_D[kScanWaves][64];
@@ -202,7 +218,6 @@ __device__ __forceinline__ void scan_epilogue(const ScanArgs& a, int v, int u, b
         }
     }
     if (a.groups > 1) {
-        const int lb = xcd_logical_block(blockIdx.x, a.per_xcd);   // = tile * groups + group
         Partial& pr = a.partial[(long long)lb * 64 + lane];
         pr.score = best;
         pr.D = best_D;
@@ -219,16 +234,8 @@ __device__ __forceinline__ void scan_epilogue(const ScanArgs& a, int v, int u, b
 
 // groups > 1: one wave per tile merges the groups' records in hypothesis order and writes the pixels.
 template <int C>
-__global__ __launch_bounds__(64) void k2_scan_combine(ScanArgs a)
+__device__ __forceinline__ void combine_tile(const ScanArgs& a, int tile, int v, int u)
 {
-    const int tile = blockIdx.x;
-    const int v = tile / a.tiles_per_row;
-    const int j = tile - v * a.tiles_per_row;
-    const int n = a.count[v];
-    const int e = j * 64 + (int)threadIdx.x;
-    if (e >= n)
-        return;
-    const int u = a.list[(long long)v * a.vol.U + e];
     const Partial* pr = a.partial + (long long)tile * a.groups * 64 + threadIdx.x;
     float best = pr[0].score, best_D = pr[0].D;
     int best_d = pr[0].d;
@@ -252,21 +259,39 @@ __global__ __launch_bounds__(64) void k2_scan_combine(ScanArgs a)
     write_pixel<C>(a, (long long)v * a.vol.U + u, best, best_d, best_D, best_rbar, sum);
 }
 
+template <int C>
+__global__ __launch_bounds__(64) void k2_scan_combine(ScanArgs a)
+{
+    if (a.packed) {
+        const int n = *a.packed_n;
+        for (int tile = blockIdx.x; tile * 64 < n; tile += gridDim.x) {
+            const int e = tile * 64 + (int)threadIdx.x;
+            if (e < n) {
+                const unsigned o = (unsigned)a.list[e];
+                const int v = (int)(o / (unsigned)a.vol.U);
+                combine_tile<C>(a, tile, v, (int)(o - (unsigned)v * (unsigned)a.vol.U));
+            }
+        }
+        return;
+    }
+    const int tile = blockIdx.x;
+    const int v = tile / a.tiles_per_row;
+    const int j = tile - v * a.tiles_per_row;
+    const int n = a.count[v];
+    const int e = j * 64 + (int)threadIdx.x;
+    if (e >= n)
+        return;
+    combine_tile<C>(a, tile, v, a.list[(long long)v * a.vol.U + e]);
+}
+
 // ---------------------------------------------------------------------------
 // Generic variant: any S, C in {1,3}, negative radiances allowed.  Nothing is
 // kept between mean-shift passes: every pass re-gathers its samples from the
 // slab (L1/L2 hits).  ~3x the instructions of the register variant.
 // ---------------------------------------------------------------------------
 template <int C>
-__global__ __launch_bounds__(64 * kScanWaves) void k2_scan_generic(ScanArgs a)
+__device__ __forceinline__ void scan_generic_body(const ScanArgs& a, int v, int u, int d0, int d1, Best<C>& best)
 {
-    int v, u;
-    bool active;
-    if (!scan_tile(a, v, u, active))
-        return;
-    int d0, d1;
-    scan_chunk(a, d0, d1);
-
     const VolView& vol = a.vol;
     const float* epi = vol.row(v, 0, 0);
     const float uf = (float)u;
@@ -276,9 +301,6 @@ __global__ __launch_bounds__(64 * kScanWaves) void k2_scan_generic(ScanArgs a)
     const float dmax = a.dmax_vu ? a.dmax_vu[o] : a.dmax;
     const float range = dmax - dmin;
     const float denom = (float)(a.dim_d - 1);
-
-    Best<C> best;
-    best.init();
 
     for (int d = d0; d < d1; d++) {
         const float Dd = hypothesis(dmin, range, denom, d);
@@ -351,7 +373,52 @@ __global__ __launch_bounds__(64 * kScanWaves) void k2_scan_generic(ScanArgs a)
         sc = (sc > 0.0f) ? sc : 0.0f;
         best.offer(sc, d, Dd, rbar);
     }
-    scan_epilogue<C>(a, v, u, active, best);
+}
+
+// The launch shapes every variant shares.  Row tiles: one (tile, group) item per workgroup, dealt to XCDs
+// in scanline order.  Packed tiles: a fixed grid strides over the items the device-side count yields;
+// every wave of a workgroup makes the same trips, and the barrier separates one item's merge in LDS
+// from the next item's.
+#define RSLF_SCAN_PACKED_LOOP(PACKED_CALL)                                               \
+    {                                                                                   \
+        Best<C> best;                                                                   \
+        int v, u, d0, d1;                                                               \
+        bool active;                                                                    \
+        const int n = *a.packed_n;                                                      \
+        const int items = ((n + 63) >> 6) * a.groups;                                   \
+        for (int item = blockIdx.x; item < items; item += gridDim.x) {                  \
+            scan_tile_packed(a, item, n, v, u, active);                                 \
+            scan_chunk(a, item % a.groups, d0, d1);                                     \
+            best.init();                                                                \
+            PACKED_CALL;                                                                \
+            scan_epilogue<C>(a, item, v, u, active, best);                              \
+            __syncthreads();                                                            \
+        }                                                                               \
+    }
+#define RSLF_SCAN_ROW_TILE(ROWS_CALL)                                                   \
+    {                                                                                   \
+        Best<C> best;                                                                   \
+        int v, u, d0, d1;                                                               \
+        bool active;                                                                    \
+        const int lb = xcd_logical_block(blockIdx.x, a.per_xcd);                        \
+        if (!scan_tile(a, lb, v, u, active))                                            \
+            return;                                                                     \
+        scan_chunk(a, lb % a.groups, d0, d1);                                           \
+        best.init();                                                                    \
+        ROWS_CALL;                                                                      \
+        scan_epilogue<C>(a, lb, v, u, active, best);                                    \
+    }
+#define RSLF_SCAN_KERNEL_BODY(ROWS_CALL, PACKED_CALL)                                   \
+    if (a.packed) {                                                                     \
+        RSLF_SCAN_PACKED_LOOP(PACKED_CALL)                                              \
+        return;                                                                         \
+    }                                                                                   \
+    RSLF_SCAN_ROW_TILE(ROWS_CALL)
+
+template <int C>
+__global__ __launch_bounds__(64 * kScanWaves) void k2_scan_generic(ScanArgs a)
+{
+    RSLF_SCAN_KERNEL_BODY((scan_generic_body<C>(a, v, u, d0, d1, best)), (scan_generic_body<C>(a, v, u, d0, d1, best)))
 }
 
 // ---------------------------------------------------------------------------
@@ -495,34 +562,38 @@ __device__ __forceinline__ void scan_stream_body(const ScanArgs& a, int v, int u
     }
 }
 
-template <int C>
-__global__ __launch_bounds__(64 * kScanWaves) void k2_scan_stream(ScanArgs a)
+// A wave whose every sample line stays inside [0, U-1] for every hypothesis
+// needs no validity test: |x - u| <= max|s_hat - s| * max|d| * slope.
+__device__ __forceinline__ bool wave_is_interior(const ScanArgs& a, int u)
 {
-    extern __shared__ __attribute__((aligned(16))) float s_stream_otab[];   // [kScanWaves][S]
-    int v, u;
-    bool active;
-    if (!scan_tile(a, v, u, active))
-        return;
-    int d0, d1;
-    scan_chunk(a, d0, d1);
-    bool interior = false;
-    if (!a.dmin_vu) {
-        const float max_ds = (float)max(a.s_hat, a.vol.S - 1 - a.s_hat);
-        const float max_d = fmaxf(fabsf(a.dmin), fabsf(a.dmax));
-        const float reach = max_ds * max_d * fabsf(a.k.slope) + 2.0f;
-        const float uf = (float)u;
-        interior = __all((uf - reach >= 0.0f) && (uf + reach <= (float)(a.vol.U - 1)));
-    }
-    float* otab = s_stream_otab + (size_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * a.vol.S;
-    Best<C> best;
-    best.init();
-    if (interior)
+    if (a.dmin_vu)
+        return false;
+    const float max_ds = (float)max(a.s_hat, a.vol.S - 1 - a.s_hat);
+    const float max_d = fmaxf(fabsf(a.dmin), fabsf(a.dmax));
+    const float reach = max_ds * max_d * fabsf(a.k.slope) + 2.0f;
+    const float uf = (float)u;
+    return __all((uf - reach >= 0.0f) && (uf + reach <= (float)(a.vol.U - 1)));
+}
+
+template <int C>
+__device__ __forceinline__ void scan_stream_rows(const ScanArgs& a, int v, int u, int d0, int d1, Best<C>& best, float* otab)
+{
+    if (wave_is_interior(a, u))
         scan_stream_body<C, false, true>(a, v, u, d0, d1, best, otab);
     else if (!a.dmin_vu)
         scan_stream_body<C, true, true>(a, v, u, d0, d1, best, otab);
     else
         scan_stream_body<C, true, false>(a, v, u, d0, d1, best, otab);
-    scan_epilogue<C>(a, v, u, active, best);
+}
+
+template <int C>
+__global__ __launch_bounds__(64 * kScanWaves) void k2_scan_stream(ScanArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float s_stream_otab[];   // [kScanWaves][S]
+    float* otab = s_stream_otab + (size_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * a.vol.S;
+    // packed tiles: lanes sit on different scanlines, offsets are per lane (the <true, false> body)
+    RSLF_SCAN_KERNEL_BODY((scan_stream_rows<C>(a, v, u, d0, d1, best, otab)),
+                          (scan_stream_body<C, true, false>(a, v, u, d0, d1, best, otab)))
 }
 
 // ---------------------------------------------------------------------------
@@ -766,36 +837,32 @@ constexpr int scan_reg_waves(int spad, int c)
 }
 
 template <int SPAD, int C>
-__global__ __launch_bounds__(64 * kScanWaves) __attribute__((amdgpu_waves_per_eu(scan_reg_waves(SPAD, C), scan_reg_waves(SPAD, C))))
-void k2_scan_reg(ScanArgs a)
+__device__ __forceinline__ void scan_reg_rows(const ScanArgs& a, int v, int u, int d0, int d1, Best<C>& best, float* otab)
 {
-    int v, u;
-    bool active;
-    if (!scan_tile(a, v, u, active))
-        return;
-    int d0, d1;
-    scan_chunk(a, d0, d1);
-    // A wave whose every sample line stays inside [0, U-1] for every hypothesis
-    // needs no validity test: |x - u| <= max|s_hat - s| * max|d| * slope.
-    bool interior = false;
-    if (!a.dmin_vu) {
-        const float max_ds = (float)max(a.s_hat, a.vol.S - 1 - a.s_hat);
-        const float max_d = fmaxf(fabsf(a.dmin), fabsf(a.dmax));
-        const float reach = max_ds * max_d * fabsf(a.k.slope) + 2.0f;
-        const float uf = (float)u;
-        interior = __all((uf - reach >= 0.0f) && (uf + reach <= (float)(a.vol.U - 1)));
-    }
-    __shared__ float s_otab[kScanWaves][SPAD];
-    float* otab = s_otab[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)];
-    Best<C> best;
-    best.init();
-    if (interior)
+    if (wave_is_interior(a, u))
         scan_reg_body<SPAD, C, false, true>(a, v, u, d0, d1, best, otab);
     else if (!a.dmin_vu)
         scan_reg_body<SPAD, C, true, true>(a, v, u, d0, d1, best, otab);
     else
         scan_reg_body<SPAD, C, true, false>(a, v, u, d0, d1, best, otab);
-    scan_epilogue<C>(a, v, u, active, best);
+}
+
+template <int SPAD, int C>
+__global__ __launch_bounds__(64 * kScanWaves) __attribute__((amdgpu_waves_per_eu(scan_reg_waves(SPAD, C), scan_reg_waves(SPAD, C))))
+void k2_scan_reg(ScanArgs a)
+{
+    __shared__ float s_otab[kScanWaves][SPAD];
+    float* otab = s_otab[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)];
+    RSLF_SCAN_ROW_TILE((scan_reg_rows<SPAD, C>(a, v, u, d0, d1, best, otab)))
+}
+
+// Packed tiles: its own kernel, because per-lane EPI bases cost address registers the row kernel's
+// budget does not have (and must not pay for).
+template <int SPAD, int C>
+__global__ __launch_bounds__(64 * kScanWaves) __attribute__((amdgpu_waves_per_eu(scan_reg_waves(SPAD + 24, C), scan_reg_waves(SPAD + 24, C))))
+void k2_scan_reg_packed(ScanArgs a)
+{
+    RSLF_SCAN_PACKED_LOOP((scan_reg_body<SPAD, C, true, false>(a, v, u, d0, d1, best, nullptr)))
 }
 
 }  // namespace rslf

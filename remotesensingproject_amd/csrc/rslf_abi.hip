@@ -64,6 +64,7 @@ struct rslf_ctx {
     int last_kernel = 0; // RSLF_SCAN_* of the last K2 launch
     bool keep_total = false;   // the 2-D sweep sums the scanned pixels of all its visits
     int scan_groups = 1;       // hypothesis groups per tile for the next scan launches (the 2-D sweep raises it)
+    bool scan_packed = false;  // next scan launches use one packed pixel list (sparse visits of the 2-D sweep)
     Partial* scan_partial = nullptr;   // [tile][group][64] records of grouped scan launches
     size_t partial_rec_cap = 0;
     // 2-D sweep scratch
@@ -227,7 +228,7 @@ extern "C" int rslf_ctx_create(int device, rslf_ctx** out)
     if (!ctx)
         return fail(RSLF_ERR_ALLOC, "out of host memory");
     ctx->device = device;
-    hipError_t e = hipMalloc(&ctx->total, sizeof(unsigned long long));
+    hipError_t e = hipMalloc(&ctx->total, 2 * sizeof(unsigned long long));   // [0] scanned pixels, [1] packed-list length (int)
     if (e == hipSuccess)
         e = hipMalloc(&ctx->minmax, 2 * sizeof(float));
     if (e == hipSuccess)
@@ -612,29 +613,31 @@ extern "C" int rslf_selective_median(rslf_ctx* ctx, const rslf_volume* vol, cons
 
 static int launch_scan_reg(int spad, int C, const ScanArgs& a, dim3 grid, hipStream_t stream)
 {
+#define RSLF_CASE(N)                                                                                        \
+    case N:                                                                                                 \
+        if (a.packed)                                                                                       \
+            hipLaunchKernelGGL((k2_scan_reg_packed<N, RSLF_C>), grid, dim3(64 * kScanWaves), 0, stream, a); \
+        else                                                                                                \
+            hipLaunchKernelGGL((k2_scan_reg<N, RSLF_C>), grid, dim3(64 * kScanWaves), 0, stream, a);        \
+        return RSLF_OK;
     if (C == 1) {
         switch (spad) {
-#define RSLF_CASE(N)                                                                            \
-    case N:                                                                                     \
-        hipLaunchKernelGGL((k2_scan_reg<N, 1>), grid, dim3(64 * kScanWaves), 0, stream, a);     \
-        return RSLF_OK;
+#define RSLF_C 1
             RSLF_SPAD_LIST_1CH(RSLF_CASE)
-#undef RSLF_CASE
+#undef RSLF_C
         default:
             break;
         }
     } else if (C == 3) {
         switch (spad) {
-#define RSLF_CASE(N)                                                                            \
-    case N:                                                                                     \
-        hipLaunchKernelGGL((k2_scan_reg<N, 3>), grid, dim3(64 * kScanWaves), 0, stream, a);     \
-        return RSLF_OK;
+#define RSLF_C 3
             RSLF_SPAD_LIST_3CH(RSLF_CASE)
-#undef RSLF_CASE
+#undef RSLF_C
         default:
             break;
         }
     }
+#undef RSLF_CASE
     return fail(RSLF_ERR_UNSUPPORTED, "no register scan kernel with %d slots x %d channels", spad, C);
 }
 
@@ -693,8 +696,27 @@ extern "C" int rslf_depth_epi_scan(rslf_ctx* ctx, const rslf_volume* vol, const 
     if (!ctx->keep_total)
         HIP_TRY(hipMemsetAsync(ctx->total, 0, sizeof(unsigned long long), st));
 
-    hipLaunchKernelGGL(k_compact_mask, dim3(vol->V), dim3(256), 0, st, d_Ce_mask_vu, d_mask_vu, vol->U, ctx->list, ctx->count,
-                       ctx->total);
+    // hypothesis groups per tile and packed tiles: 1 / off unless the caller expects a sparse launch
+    int groups = std::max(1, ctx->scan_groups);
+    bool packed = ctx->scan_packed;
+    if (const char* fg = getenv("RSLF_FORCE_GROUPS"))   // parity tests: sparse-launch shapes on the pile path too
+        groups = std::min(64, std::max(1, atoi(fg)));
+    if (const char* fp = getenv("RSLF_FORCE_PACKED"))
+        packed = atoi(fp) != 0;
+    while (groups > 1 && dim_d < 2 * kScanWaves * groups)   // enough hypotheses to share out?
+        groups /= 2;
+    if (n > (size_t)INT32_MAX)
+        packed = false;   // entry counts are ints
+
+    int* packed_n = reinterpret_cast<int*>(ctx->total + 1);
+    if (packed) {
+        HIP_TRY(hipMemsetAsync(packed_n, 0, sizeof(int), st));
+        hipLaunchKernelGGL(k_compact_mask_packed, dim3(vol->V), dim3(256), 0, st, d_Ce_mask_vu, d_mask_vu, vol->U, ctx->list,
+                           ctx->count, ctx->total, packed_n);
+    } else {
+        hipLaunchKernelGGL(k_compact_mask, dim3(vol->V), dim3(256), 0, st, d_Ce_mask_vu, d_mask_vu, vol->U, ctx->list,
+                           ctx->count, ctx->total);
+    }
     HIP_TRY(hipGetLastError());
 
     ScanArgs a;
@@ -716,17 +738,13 @@ extern "C" int rslf_depth_epi_scan(rslf_ctx* ctx, const rslf_volume* vol, const 
     a.idx = d_idx_vu;
     a.score = d_score_vu;
     a.tiles_per_row = (vol->U + 63) / 64;
-    const long long tiles = (long long)vol->V * a.tiles_per_row;
-    // hypothesis groups per tile: 1 unless the caller expects a sparse launch (ctx->scan_groups) and there
-    // are enough hypotheses to share out
-    int groups = std::max(1, ctx->scan_groups);
-    if (const char* fg = getenv("RSLF_FORCE_GROUPS"))   // parity tests: grouped launches on the pile path too
-        groups = std::min(64, std::max(1, atoi(fg)));
-    while (groups > 1 && dim_d < 2 * kScanWaves * groups)
-        groups /= 2;
+    // row tiles: ceil(U/64) per scanline; packed tiles: at most ceil(V*U/64), the device knows how many
+    const long long tiles = packed ? (long long)((n + 63) / 64) : (long long)vol->V * a.tiles_per_row;
     if (tiles * groups > (long long)1 << 30)
-        return fail(RSLF_ERR_UNSUPPORTED, "V * ceil(U/64) = %lld tiles exceeds the grid limit", tiles);
+        return fail(RSLF_ERR_UNSUPPORTED, "%lld tiles x %d groups exceeds the grid limit", tiles, groups);
     a.groups = groups;
+    a.packed = packed ? 1 : 0;
+    a.packed_n = packed_n;
     a.partial = nullptr;
     if (groups > 1) {
         const size_t recs = (size_t)tiles * groups * 64;
@@ -741,7 +759,9 @@ extern "C" int rslf_depth_epi_scan(rslf_ctx* ctx, const rslf_volume* vol, const 
     }
     a.logical_blocks = (int)(tiles * groups);   // `groups` workgroups per tile, their waves split the hypotheses
     a.per_xcd = (a.logical_blocks + 7) / 8;
-    const dim3 grid((unsigned)(a.per_xcd * 8));
+    // packed: a fixed grid strides over the items (k2_scan.hpp); ~4 workgroups per CU cover any occupancy
+    const dim3 grid(packed ? (unsigned)std::min<long long>(tiles * groups, 1024) : (unsigned)(a.per_xcd * 8));
+    const dim3 combine_grid(packed ? (unsigned)std::min<long long>(tiles, 1024) : (unsigned)tiles);
 
     // Register variant: one channel, S within the compiled slot counts, and
     // radiances in [0, 1e6] so that max(R,0) == R and the 1e30 sentinel dwarfs them.
@@ -782,9 +802,9 @@ extern "C" int rslf_depth_epi_scan(rslf_ctx* ctx, const rslf_volume* vol, const 
     HIP_TRY(hipGetLastError());
     if (groups > 1) {
         if (vol->C == 1)
-            hipLaunchKernelGGL(k2_scan_combine<1>, dim3((unsigned)tiles), dim3(64), 0, st, a);
+            hipLaunchKernelGGL(k2_scan_combine<1>, combine_grid, dim3(64), 0, st, a);
         else
-            hipLaunchKernelGGL(k2_scan_combine<3>, dim3((unsigned)tiles), dim3(64), 0, st, a);
+            hipLaunchKernelGGL(k2_scan_combine<3>, combine_grid, dim3(64), 0, st, a);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(ctx->ev1, st));
@@ -1022,6 +1042,7 @@ extern "C" int rslf_depth_epi_2d(rslf_ctx* ctx, const rslf_volume* vol, const fl
         // After the centre view, propagation has explained most pixels: a visit scans a few per scanline
         // and lasts as long as one wave's walk over its hypotheses -- share them out over 4x the waves.
         ctx->scan_groups = first_visit ? 1 : 8;
+        ctx->scan_packed = !first_visit;
         first_visit = false;
         float* depth = d_depth_svu + (size_t)s_hat * n;
         float* Cd = d_Cd_svu + (size_t)s_hat * n;
@@ -1035,6 +1056,7 @@ extern "C" int rslf_depth_epi_2d(rslf_ctx* ctx, const rslf_volume* vol, const fl
         if (rc) {
             ctx->keep_total = false;
             ctx->scan_groups = 1;
+            ctx->scan_packed = false;
             return rc;
         }
         // ... while in the reference the stored plane keeps the RAW depths and only the local header is
@@ -1055,6 +1077,7 @@ extern "C" int rslf_depth_epi_2d(rslf_ctx* ctx, const rslf_volume* vol, const fl
     }
     ctx->keep_total = false;
     ctx->scan_groups = 1;
+    ctx->scan_packed = false;
     if (stats) {
         unsigned long long tot = 0;
         HIP_TRY(hipMemcpyAsync(&tot, ctx->total, sizeof(tot), hipMemcpyDeviceToHost, st));

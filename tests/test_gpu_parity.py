@@ -150,7 +150,9 @@ def test_stream_kernel_per_pixel_ranges(rs, oracle_mod, monkeypatch):
     assert np.array_equal(trbar.cpu().numpy(), ref.rbar)
 
 
+@pytest.mark.parametrize("packed", [0, 1])
 @pytest.mark.parametrize("groups,force,C_,S,U,D", [
+    (1, None, 1, 17, 130, 12),       # packed tiles alone
     (2, None, 1, 17, 130, 16),       # the smallest D a pair of groups accepts
     (4, None, 1, 33, 200, 47),       # ragged chunks: 47 hypotheses over 16 slices
     (8, None, 1, 9, 70, 64),
@@ -160,17 +162,54 @@ def test_stream_kernel_per_pixel_ranges(rs, oracle_mod, monkeypatch):
     (2, "generic", 1, 15, 100, 24),
     (16, None, 1, 12, 64, 31),       # more groups than D allows: halved until every slice has work
 ])
-def test_hypothesis_groups(rs, oracle_mod, monkeypatch, groups, force, C_, S, U, D):
-    """Sparse launches of the 2-D sweep split each tile's hypotheses over several workgroups and merge
-    their records in k2_scan_combine: first-max arg-max, mean and r-bar must not depend on the split."""
+def test_sparse_launch_shapes(rs, oracle_mod, monkeypatch, packed, groups, force, C_, S, U, D):
+    """Sparse visits of the 2-D sweep split each tile's hypotheses over several workgroups (records merged
+    by k2_scan_combine) and pack the pixels of all scanlines into one list, so that a wave's lanes sit on
+    different scanlines: arg-max (first maximum), mean and r-bar must not depend on either."""
     monkeypatch.setenv("RSLF_FORCE_GROUPS", str(groups))
+    monkeypatch.setenv("RSLF_FORCE_PACKED", str(packed))
     if force:
         monkeypatch.setenv("RSLF_FORCE_SCAN", force)
-    vol = _vol("noise" if C_ == 1 else "struct", U, 3, S, C_, 900 + D, -1.5, 2.5)
+    vol = _vol("noise" if C_ == 1 else "struct", U, 5, S, C_, 900 + D, -1.5, 2.5)
     ref = oracle_mod.depth1d_pile_run(vol, -1.5, 2.5, D)
     comp, got = _run(rs, vol, -1.5, 2.5, D)
     assert comp.stats.scan_kernel == {None: 1, "stream": 2, "generic": 0}[force]
-    assert_pile_parity(got, ref, label="groups%d_%s_C%d_D%d" % (groups, force, C_, D))
+    assert_pile_parity(got, ref, label="groups%d_packed%d_%s_C%d_D%d" % (groups, packed, force, C_, D))
+
+
+def test_packed_tiles_with_per_pixel_ranges_and_sparse_mask(rs, oracle_mod, monkeypatch):
+    """The fine-to-coarse shape of a sparse visit: per-pixel [dmin, dmax] planes, a caller mask that leaves
+    a few pixels per scanline (some scanlines none), packed tiles x 4 groups."""
+    import torch
+    monkeypatch.setenv("RSLF_FORCE_GROUPS", "4")
+    monkeypatch.setenv("RSLF_FORCE_PACKED", "1")
+    rng = np.random.default_rng(77)
+    V, S, U, D = 9, 13, 150, 37
+    vol = rng.uniform(0.0, 1.0, size=(V, S, U, 1)).astype(np.float32)
+    dmin = rng.uniform(-2.0, 0.0, size=(V, U)).astype(np.float32)
+    dmax = (dmin + rng.uniform(0.0, 3.0, size=(V, U))).astype(np.float32)
+    Ce, cm = oracle_mod.edge_confidence_pile(vol, 6)
+    mask = (rng.uniform(size=(V, U)) < 0.03).astype(np.uint8) * 255
+    mask[2] = 0
+    mask[5] = 0
+    ref = oracle_mod.depth_epi_pile(vol, dmin, dmax, D, 6, Ce, cm, mask_vu=mask)
+    v = rs.Volume.from_dense(vol)
+    dev = "cuda"
+    t = lambda a: torch.from_numpy(a.copy()).to(dev)
+    tCe, tcm, tmask = t(Ce), t(cm), t(mask)
+    tCd = torch.zeros((V, U), device=dev); tdepth = torch.zeros((V, U), device=dev); trbar = torch.zeros((V, U, 1), device=dev)
+    tidx = torch.empty((V, U), dtype=torch.int32, device=dev); tsc = torch.empty((V, U), device=dev)
+    st = rs.compute_1D_depth_epi_pile(v, t(dmin), t(dmax), D, 6, tCe, tcm, tCd, tdepth, trbar, None, tmask, idx_v_u=tidx,
+                                      score_v_u=tsc, want_stats=True)
+    torch.cuda.synchronize()
+    assert st.scan_kernel == 1
+    assert st.pixels_scanned == int(np.count_nonzero(cm & mask))
+    assert np.array_equal(tidx.cpu().numpy(), ref.depth_idx)
+    assert np.array_equal(tsc.cpu().numpy(), ref.score)
+    assert np.array_equal(tdepth.cpu().numpy(), ref.depth)
+    assert np.array_equal(tcm.cpu().numpy(), ref.edge_mask)
+    assert np.array_equal(tCe.cpu().numpy(), ref.edge_confidence)
+    np.testing.assert_allclose(tCd.cpu().numpy(), ref.disp_confidence, rtol=1e-5, atol=1e-7)
 
 
 def test_negative_radiances_take_generic_path(rs, oracle_mod):
