@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define RSLF_ABI_VERSION 1
+#define RSLF_ABI_VERSION 2
 
 typedef enum rslf_status {
     RSLF_OK = 0,
@@ -48,9 +48,9 @@ typedef enum rslf_status {
 
 /* Mirrors rslf::Depth1DParameters<T> -- include/rslf_depth_computation_core.hpp:66-142
  * (defaults :16-31, :74-99).  Same member meaning, par_ prefix dropped.  The two
- * polymorphic plug-ins (:108-109) are fixed to the reference's defaults:
- * Interpolation1DLinear (include/rslf_interpolation.hpp:155-193) and
- * BandwidthKernel(h) (src/rslf_kernels.cpp:16-54), h = kernel_bandwidth. */
+ * polymorphic plug-ins (:108-109) become plain members: `interpolation` selects
+ * between the reference's two interpolation classes (include/rslf_interpolation.hpp),
+ * and the kernel is BandwidthKernel(h) (src/rslf_kernels.cpp:16-54), h = kernel_bandwidth. */
 typedef struct rslf_params {
     float edge_score_threshold;         /* 0.02 */
     float line_score_threshold;         /* 0.02  (unused by this path, kept for 1:1 layout) */
@@ -67,7 +67,21 @@ typedef struct rslf_params {
     int   cut_shadows;                  /* 1 */
     float shadow_level;                 /* 0.05 * 1.73205080757 */
     float kernel_bandwidth;             /* 0.2 (_BANDWIDTH_KERNEL_PARAMETER, :26) */
+    int   interpolation;                /* par_interpolation_class (:76-77, :108): RSLF_INTERP_*, default LINEAR */
 } rslf_params;
+
+/* par_interpolation_class.
+ * LINEAR            Interpolation1DLinear (include/rslf_interpolation.hpp:155-193), the reference default.
+ * NEAREST           Interpolation1DNearestNeighbour as its scalar interpolate() states it (:80-92):
+ *                   index (int)std::round(x), NaN outside [0, U-1].
+ * NEAREST_AS_BUILT  what its interpolate_mat() -- the method the scan calls (core.hpp:561) -- executes:
+ *                   the float index matrix is read through `indices.ptr<int>` (:118), so the "index" is
+ *                   the BIT PATTERN of x, in range only for x = +0.  Kept so that a caller who selects
+ *                   the reference's commented-out line (core.hpp:77) gets the reference's result bit for bit.
+ * The two nearest modes run on the generic scan kernel only. */
+#define RSLF_INTERP_LINEAR            0
+#define RSLF_INTERP_NEAREST           1
+#define RSLF_INTERP_NEAREST_AS_BUILT  2
 
 typedef struct rslf_ctx rslf_ctx;       /* device, stream, scratch */
 typedef struct rslf_volume rslf_volume; /* light-field slab resident in HBM */

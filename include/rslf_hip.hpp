@@ -60,6 +60,7 @@ struct Depth1DParameters {
     bool par_cut_shadows;
     float par_shadow_level;
     float par_kernel_bandwidth;   // BandwidthKernel(_BANDWIDTH_KERNEL_PARAMETER), core.hpp:78
+    int par_interpolation_class;  // RSLF_INTERP_*: stands for the Interpolation1DClass* of core.hpp:108 (default Linear, :76)
 
     Depth1DParameters()
     {
@@ -80,6 +81,7 @@ struct Depth1DParameters {
         par_cut_shadows = p.cut_shadows != 0;
         par_shadow_level = p.shadow_level;
         par_kernel_bandwidth = p.kernel_bandwidth;
+        par_interpolation_class = p.interpolation;
     }
 
     static Depth1DParameters& get_default()
@@ -106,6 +108,7 @@ struct Depth1DParameters {
         p.cut_shadows = par_cut_shadows ? 1 : 0;
         p.shadow_level = par_shadow_level;
         p.kernel_bandwidth = par_kernel_bandwidth;
+        p.interpolation = par_interpolation_class;
         return p;
     }
 };

@@ -34,6 +34,7 @@ class OracleParams(C.Structure):
         ("cut_shadows", C.c_int),
         ("shadow_level", C.c_float),
         ("kernel_bandwidth", C.c_float),
+        ("interpolation", C.c_int),     # 0 linear, 1 nearest (interp.hpp:80-92), 2 nearest as built (interp.hpp:118)
     ]
 
 

@@ -33,6 +33,7 @@ def default_params() -> dict:
         cut_shadows=True,
         shadow_level=F(0.05 * SQRT3),
         kernel_bandwidth=F(0.2),
+        interpolation=0,             # core.hpp:76: Interpolation1DLinear; 1 / 2 = nearest (see rslf_oracle.h)
     )
 
 
@@ -102,14 +103,25 @@ def scan_pixel(epi: np.ndarray, u: int, dmin: F, dmax: F, D: int, s_hat: int, p:
     I = I * F(p["slope_factor"])               # core.hpp:551
     I = I + F(u)                               # core.hpp:552
 
-    i0 = np.floor(I).astype(np.int64)          # interp.hpp:179-181
-    i1 = np.ceil(I).astype(np.int64)
-    t = I - i0.astype(F)
-    valid = ~((i0 < 0) | (i1 > U - 1))         # interp.hpp:182
-    i0c, i1c = np.clip(i0, 0, U - 1), np.clip(i1, 0, U - 1)
     rows = np.arange(S)[:, None]
-    R = (F(1) - t)[..., None] * epi[rows, i0c] + t[..., None] * epi[rows, i1c]   # interp.hpp:184
-    R = np.where(valid[..., None], R, F(np.nan)).astype(F)
+    mode = int(p.get("interpolation", 0))
+    if mode == 0:
+        i0 = np.floor(I).astype(np.int64)          # interp.hpp:179-181
+        i1 = np.ceil(I).astype(np.int64)
+        t = I - i0.astype(F)
+        valid = ~((i0 < 0) | (i1 > U - 1))         # interp.hpp:182
+        i0c, i1c = np.clip(i0, 0, U - 1), np.clip(i1, 0, U - 1)
+        R = (F(1) - t)[..., None] * epi[rows, i0c] + t[..., None] * epi[rows, i1c]   # interp.hpp:184
+    else:
+        if mode == 2:                              # interp.hpp:118: the float matrix read through an int pointer
+            r = np.ascontiguousarray(I, F).view(np.int32).astype(np.int64)
+        else:                                      # interp.hpp:121: std::round, halves away from zero
+            with np.errstate(invalid="ignore", over="ignore"):
+                r = (np.sign(I) * np.floor(np.abs(I.astype(np.float64)) + 0.5)).astype(np.int64)
+            r = np.where(np.abs(I) < 2.0e9, r, -1)
+        valid = (r > -1) & (r < U)                 # interp.hpp:122
+        R = epi[rows, np.clip(r, 0, U - 1)]        # interp.hpp:124
+    R = np.where(valid[..., None], R, F(np.nan)).astype(F)   # interp.hpp:129 / :189
     card = np.zeros(D, F)
     for s in range(S):
         card = card + valid[s].astype(F)       # interp.hpp:185

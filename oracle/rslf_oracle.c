@@ -35,6 +35,22 @@ void oracle_default_params(oracle_params* p)
     p->cut_shadows = 1;
     p->shadow_level = (float)(0.05 * SQRT3_D);
     p->kernel_bandwidth = (float)0.2;
+    p->interpolation = ORACLE_INTERP_LINEAR;   /* core.hpp:76 */
+}
+
+/* Interpolation1DNearestNeighbour::interpolate_mat (interp.hpp:94-131): the sample index for position x,
+ * or -1 when the reference stores NaN. */
+static int nearest_index(float x, int U, int mode)
+{
+    int r;
+    if (mode == ORACLE_INTERP_NEAREST_AS_BUILT) {
+        memcpy(&r, &x, sizeof r);               /* interp.hpp:118: const int* ind_ptr = indices.ptr<int>(r) */
+    } else {
+        if (!(fabsf(x) < 2.0e9f))               /* (int) of an out-of-range float is undefined: never a valid index */
+            return -1;
+        r = (int)roundf(x);                     /* interp.hpp:121 / :86: std::round, halves away from zero */
+    }
+    return (r > -1 && r < U) ? r : -1;          /* interp.hpp:122 */
 }
 
 void oracle_set_num_threads(int n)
@@ -267,6 +283,22 @@ static void scan_pixel(const float* epi, int S, int U, int C, int u,
         for (int s = 0; s < S; s++) {
             const float Ss = (float)(s_hat - s); /* core.hpp:542 */
             const float* erow = epi + (size_t)s * U * C;
+            if (p->interpolation != ORACLE_INTERP_LINEAR) {
+                for (int d = 0; d < nb; d++) {
+                    float xi = Ss * Dv[d];          /* I = S * D (gemm, K=1)    */
+                    xi = xi * p->slope_factor;      /* I *= par_slope_factor    */
+                    xi = xi + uf;                   /* I += u                   */
+                    const int r = nearest_index(xi, U, p->interpolation);
+                    for (int c = 0; c < C; c++) {
+                        const float val = (r >= 0) ? erow[(size_t)r * C + c] : NAN;   /* interp.hpp:124 / :129 */
+                        w->R[c * SD + (size_t)s * ORACLE_DBLOCK + d] = val;
+                        w->R0[c * SD + (size_t)s * ORACLE_DBLOCK + d] = (r >= 0 && val > 0.0f) ? val : 0.0f; /* core.hpp:580 */
+                    }
+                    if (r >= 0)
+                        card[d] = card[d] + 1.0f;   /* interp.hpp:125 */
+                }
+                continue;
+            }
             if (C == 1) {
                 /* branch-free so the compiler can vectorise it (gathers); same values */
                 float* restrict Rr = w->R + (size_t)s * ORACLE_DBLOCK;

@@ -52,7 +52,18 @@ typedef struct oracle_params {
     int   cut_shadows;               /* true                            core.hpp:97  */
     float shadow_level;              /* 0.05*sqrt(3)                    core.hpp:31  */
     float kernel_bandwidth;          /* h = 0.2                         core.hpp:26  */
+    int   interpolation;             /* par_interpolation_class (core.hpp:76-77, :108): ORACLE_INTERP_* */
 } oracle_params;
+
+/* par_interpolation_class.  LINEAR = Interpolation1DLinear (interp.hpp:155-193), the default.
+ * NEAREST = Interpolation1DNearestNeighbour as its scalar interpolate() states it (interp.hpp:80-92):
+ * index (int)std::round(x), NaN outside [0, U-1].  NEAREST_AS_BUILT = what its interpolate_mat(), the
+ * method the scan calls (core.hpp:561), really executes: it reads the FLOAT index matrix through
+ * `indices.ptr<int>` (interp.hpp:118), so the "index" is the bit pattern of x -- in range only for
+ * x = +0 (and denormals). */
+#define ORACLE_INTERP_LINEAR            0
+#define ORACLE_INTERP_NEAREST           1
+#define ORACLE_INTERP_NEAREST_AS_BUILT  2
 
 void oracle_default_params(oracle_params* p);
 

@@ -12,7 +12,7 @@ from . import build as _build
 
 _LIB = None
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # every symbol include/rslf_hip.h declares
 SYMBOLS = [
@@ -49,6 +49,7 @@ class RslfParams(C.Structure):
         ("cut_shadows", C.c_int),
         ("shadow_level", C.c_float),
         ("kernel_bandwidth", C.c_float),
+        ("interpolation", C.c_int),
     ]
 
 

@@ -306,8 +306,11 @@ __device__ __forceinline__ void scan_generic_body(const ScanArgs& a, int v, int 
         const float Dd = hypothesis(dmin, range, denom, d);
         float rbar[C];
 #pragma unroll
-        for (int c = 0; c < C; c++)   // core.hpp:577: R[s_hat] is E[s_hat][u] exactly
+        for (int c = 0; c < C; c++) {   // core.hpp:577: R[s_hat] is E[s_hat][u] exactly (position u + 0*d) ...
             rbar[c] = epi[(long long)a.s_hat * vol.stride_s + (long long)c * vol.pitch + u];
+            if (a.k.interp == 2 && u != 0)   // ... except as built (interp.hpp:118): bits(float(u)) is no column unless u = 0
+                rbar[c] = NAN;
+        }
         float B = 0.0f, card = 0.0f;
         for (int it = 0; it < a.k.n_iter; it++) {
             float A[C];
@@ -321,10 +324,24 @@ __device__ __forceinline__ void scan_generic_body(const ScanArgs& a, int v, int 
                 x = x * a.k.slope;                     // I *= slope_factor  core.hpp:551
                 x = x + uf;                            // I += u             core.hpp:552
                 const float fl = floorf(x);
-                const int i0 = (int)fl;                // interp.hpp:179-181
-                const int i1 = (int)ceilf(x);
-                const float t = x - fl;
-                const bool valid = !(i0 < 0 || i1 > Um1);   // interp.hpp:182
+                int i0 = (int)fl;                      // interp.hpp:179-181
+                int i1 = (int)ceilf(x);
+                float t = x - fl;
+                bool valid = !(i0 < 0 || i1 > Um1);    // interp.hpp:182
+                if (a.k.interp != 0) {
+                    // Interpolation1DNearestNeighbour::interpolate_mat (interp.hpp:94-131): one tap.  Both taps
+                    // below read E[r] with weights 1 and 0, and 1*E + 0*E == E exactly for every finite E.
+                    int r;
+                    if (a.k.interp == 2) {
+                        r = __float_as_int(x);         // interp.hpp:118: the float index read through an int pointer
+                        valid = r > -1 && r < vol.U;   // interp.hpp:122
+                    } else {
+                        r = (int)roundf(x);            // interp.hpp:121: std::round, halves away from zero
+                        valid = fabsf(x) < 2.0e9f && r > -1 && r < vol.U;
+                    }
+                    i0 = i1 = r;
+                    t = 0.0f;
+                }
                 const int j0 = min(max(i0, 0), Um1), j1 = min(max(i1, 0), Um1);
                 const float* row = epi + (long long)s * vol.stride_s;
                 const float omt = 1.0f - t;

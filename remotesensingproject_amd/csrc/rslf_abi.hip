@@ -171,6 +171,7 @@ extern "C" void rslf_default_params(rslf_params* p)
     p->cut_shadows = 1;
     p->shadow_level = (float)(0.05 * 1.73205080757);
     p->kernel_bandwidth = (float)0.2;
+    p->interpolation = RSLF_INTERP_LINEAR;   // core.hpp:76
 }
 
 static ScanConsts make_scan_consts(const rslf_params* p)
@@ -186,6 +187,7 @@ static ScanConsts make_scan_consts(const rslf_params* p)
     while ((float)n < p->mean_shift_max_iter && n < (1 << 20))   // core.hpp:584, float bound
         n++;
     k.n_iter = n;
+    k.interp = p->interpolation;
     return k;
 }
 
@@ -204,6 +206,8 @@ static int check_params(const rslf_params* p)
         return fail(RSLF_ERR_INVALID_ARG, "kernel_bandwidth must be > 0");
     if (!(p->mean_shift_max_iter > 0.0f))
         return fail(RSLF_ERR_INVALID_ARG, "mean_shift_max_iter must be > 0");
+    if (p->interpolation < RSLF_INTERP_LINEAR || p->interpolation > RSLF_INTERP_NEAREST_AS_BUILT)
+        return fail(RSLF_ERR_INVALID_ARG, "interpolation=%d is not one of RSLF_INTERP_*", p->interpolation);
     return RSLF_OK;
 }
 
@@ -772,7 +776,10 @@ extern "C" int rslf_depth_epi_scan(rslf_ctx* ctx, const rslf_volume* vol, const 
     bool stream_ok = vol->min_value >= 0.0f && vol->max_value <= 1.0e6f &&
                      (size_t)kScanWaves * vol->S * sizeof(float) <= (size_t)48 << 10;
     const char* force = getenv("RSLF_FORCE_SCAN");   // parity tests exercise every variant on small cases
-    if (force && strcmp(force, "generic") == 0) {
+    if (p->interpolation != RSLF_INTERP_LINEAR) {      // nearest-neighbour sampling: generic kernel only
+        spad = 0;
+        stream_ok = false;
+    } else if (force && strcmp(force, "generic") == 0) {
         spad = 0;
         stream_ok = false;
     } else if (force && strcmp(force, "stream") == 0) {

@@ -34,6 +34,7 @@ struct ScanConsts {
     float k1;             // 3.0f * inv_h2                  kernels.cpp:21
     float raw_thr;        // par_raw_score_threshold
     int   n_iter;         // #{i >= 0 : float(i) < par_mean_shift_max_iter}   core.hpp:584
+    int   interp;         // RSLF_INTERP_*: the generic kernel alone handles the nearest modes
 };
 
 struct EdgeConsts {

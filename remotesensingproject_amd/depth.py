@@ -26,6 +26,20 @@ from . import _lib
 from ._lib import RslfParams, RslfStats, RslfVolumeDesc, check
 
 
+class Interpolation1DLinear:
+    """include/rslf_interpolation.hpp:59-67, :155-193 (RSLF_INTERP_LINEAR)."""
+    mode = 0
+
+
+class Interpolation1DNearestNeighbour:
+    """include/rslf_interpolation.hpp:46-54.  `as_built=False`: the class as its scalar interpolate() states it
+    (:80-92, RSLF_INTERP_NEAREST).  `as_built=True`: what interpolate_mat() executes in the reference, the float
+    index matrix read through an int pointer (:118, RSLF_INTERP_NEAREST_AS_BUILT)."""
+
+    def __init__(self, as_built: bool = False):
+        self.mode = 2 if as_built else 1
+
+
 @dataclass
 class Depth1DParameters:
     """rslf::Depth1DParameters<T> with the reference's member names and defaults."""
@@ -45,6 +59,9 @@ class Depth1DParameters:
     par_cut_shadows: bool = True
     par_shadow_level: float = 0.05 * 1.73205080757
     par_kernel_bandwidth: float = 0.2   # BandwidthKernel(_BANDWIDTH_KERNEL_PARAMETER), core.hpp:78
+    # par_interpolation_class (core.hpp:76-77, :108): an Interpolation1DLinear / Interpolation1DNearestNeighbour
+    # instance, or the RSLF_INTERP_* integer itself
+    par_interpolation_class: object = 0
 
     @staticmethod
     def get_default() -> "Depth1DParameters":
@@ -53,6 +70,9 @@ class Depth1DParameters:
     def to_c(self) -> RslfParams:
         p = RslfParams()
         for f, _ in RslfParams._fields_:
+            if f == "interpolation":
+                p.interpolation = int(getattr(self.par_interpolation_class, "mode", self.par_interpolation_class))
+                continue
             v = getattr(self, "par_" + f)
             setattr(p, f, int(v) if isinstance(getattr(p, f), int) else float(v))
         return p

@@ -33,7 +33,8 @@ def test_every_declared_symbol_is_exported(L):
 
 
 def test_abi_version_and_strings(L):
-    assert L.rslf_abi_version() == 1
+    from remotesensingproject_amd import _lib
+    assert L.rslf_abi_version() == _lib.ABI_VERSION == 2
     assert L.rslf_status_string(0) == b"ok"
     assert b"invalid" in L.rslf_status_string(-1)
 
@@ -52,6 +53,7 @@ def test_default_params_match_reference_defaults(L, oracle_mod):
     assert p.slope_factor == 1.0 and p.cut_shadows == 1
     assert p.shadow_level == C.c_float(0.05 * 1.73205080757).value
     assert p.kernel_bandwidth == C.c_float(0.2).value
+    assert p.interpolation == 0 == o.interpolation   # Interpolation1DLinear, core.hpp:76
     for f in ("edge_score_threshold", "raw_score_threshold", "mean_shift_max_iter", "edge_confidence_filter_size",
               "median_filter_size", "median_filter_epsilon", "slope_factor", "cut_shadows", "shadow_level", "kernel_bandwidth"):
         assert getattr(p, f) == getattr(o, f), f

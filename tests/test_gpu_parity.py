@@ -212,6 +212,22 @@ def test_packed_tiles_with_per_pixel_ranges_and_sparse_mask(rs, oracle_mod, monk
     np.testing.assert_allclose(tCd.cpu().numpy(), ref.disp_confidence, rtol=1e-5, atol=1e-7)
 
 
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("C_,S,U,D,kind", [(1, 11, 130, 14, "noise"), (3, 9, 100, 12, "struct"), (1, 7, 70, 9, "struct")])
+def test_nearest_neighbour_interpolation(rs, oracle_mod, mode, C_, S, U, D, kind):
+    """par_interpolation_class = Interpolation1DNearestNeighbour (core.hpp:77; interp.hpp:94-131), as stated
+    (std::round) and as built (index = bit pattern of the float position, interp.hpp:118)."""
+    vol = _vol(kind, U, 4, S, C_, 40 + S, -1.5, 2.0)
+    po = oracle_mod.default_params()
+    po.interpolation = mode
+    ref = oracle_mod.depth1d_pile_run(vol, -1.5, 2.0, D, params=po)
+    par = rs.Depth1DParameters()
+    par.par_interpolation_class = rs.Interpolation1DNearestNeighbour(as_built=(mode == 2))
+    comp, got = _run(rs, vol, -1.5, 2.0, D, params=par)
+    assert comp.stats.scan_kernel == 0
+    assert_pile_parity(got, ref, label="nearest%d_C%d_S%d" % (mode, C_, S))
+
+
 def test_negative_radiances_take_generic_path(rs, oracle_mod):
     """max(R,0) != R when the input goes negative (core.hpp:580): register scan must not run."""
     rng = np.random.default_rng(11)

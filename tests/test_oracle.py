@@ -49,6 +49,50 @@ def test_numpy_restatement_agrees_bitwise(oracle_mod, name, rows):
         assert np.array_equal(getattr(r, ko), n[kn]), (name, ko)
 
 
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("name,rows", [("rand1", slice(4, 7)), ("rgb", slice(2, 5)), ("edge", slice(0, 4))])
+def test_nearest_interpolation_restatements_agree(oracle_mod, name, rows, mode):
+    """par_interpolation_class = Interpolation1DNearestNeighbour (core.hpp:77, interp.hpp:94-131): the C and numpy
+    restatements agree bit for bit, for the class as stated (std::round) and as built (index = bits of x)."""
+    from oracle import oracle_np as onp
+    vol, meta, _ = load_case(name)
+    sub = np.ascontiguousarray(vol[rows])
+    pc = oracle_mod.default_params()
+    pc.interpolation = mode
+    pn = onp.default_params()
+    pn["interpolation"] = mode
+    r = oracle_mod.depth1d_pile_run(sub, meta["dmin"], meta["dmax"], meta["D"], meta["s_hat"], params=pc)
+    n = onp.depth1d_pile_run(sub, np.float32(meta["dmin"]), np.float32(meta["dmax"]), meta["D"], meta["s_hat"], p=pn)
+    for ko, kn in (("edge_confidence", "Ce"), ("edge_mask", "Ce_mask"), ("depth_idx", "idx"), ("score", "score"),
+                   ("depth_raw", "depth_raw"), ("rbar", "rbar"), ("disp_confidence", "Cd"), ("depth", "depth")):
+        assert np.array_equal(getattr(r, ko), n[kn]), (name, mode, ko)
+    if mode == 2:
+        # as built, a sample exists only where the position is exactly +0 (its bit pattern is column 0): R[s_hat][u]
+        # is NaN for every u != 0, and a pixel survives only if some view's line passes through x = 0 exactly
+        assert (r.edge_mask > 0).mean() < 0.05
+        assert set(np.unique(r.score)) <= {np.float32(0.0), np.float32(1.0)}
+
+
+def test_nearest_interpolation_known_answer(oracle_mod):
+    """Integer disparities and integer view offsets: nearest and linear sampling read the same columns, so
+    the stated nearest mode must reproduce the linear result wherever the whole line is in range."""
+    from remotesensingproject_amd.synth import make_lightfield
+    U, V, S, D = 96, 4, 9, 9
+    deltas = np.array([-1, 0, 1, 2], np.float32)
+    vol, _ = make_lightfield(U, V, S, 1, seed=9, deltas=deltas)
+    lin = oracle_mod.depth1d_pile_run(vol, -2.0, 2.0, D)            # grid step 0.5
+    p = oracle_mod.default_params()
+    p.interpolation = 1
+    nn = oracle_mod.depth1d_pile_run(vol, -2.0, 2.0, D, params=p)
+    inner = slice(12, U - 12)
+    m = lin.edge_mask[:, inner] > 0
+    assert m.mean() > 0.9
+    want = ((deltas + 2.0) / 0.5).astype(np.int32)
+    for v in range(V):
+        assert (nn.depth_idx[v, inner][m[v]] == want[v]).all()
+        assert (nn.score[v, inner][m[v]] == 1.0).all()
+
+
 def test_analytic_known_answer(oracle_mod):
     """Independent of every OpenCV-semantics assumption: integer true disparity on the grid =>
     all samples of the true line are identical => K == 1, score == 1.0 exactly, argmax known."""
