@@ -228,6 +228,29 @@ def test_nearest_neighbour_interpolation(rs, oracle_mod, mode, C_, S, U, D, kind
     assert_pile_parity(got, ref, label="nearest%d_C%d_S%d" % (mode, C_, S))
 
 
+@pytest.mark.parametrize("force", [None, "stream", "generic"])
+def test_degenerate_shapes(rs, oracle_mod, monkeypatch, force):
+    """One pixel / one view / two hypotheses / dmin == dmax / U below the edge filter's width."""
+    from tests.test_oracle import DEGENERATE
+    if force:
+        monkeypatch.setenv("RSLF_FORCE_SCAN", force)
+    for V, S, U, C_, D, dmin, dmax in DEGENERATE:
+        vol = np.random.default_rng(3 + U).uniform(0.0, 1.0, size=(V, S, U, C_)).astype(np.float32)
+        ref = oracle_mod.depth1d_pile_run(vol, dmin, dmax, D)
+        comp, got = _run(rs, vol, dmin, dmax, D)
+        assert_pile_parity(got, ref, label="degenerate_%dx%dx%dx%d_%s" % (V, S, U, C_, force))
+
+
+def test_nothing_to_scan(rs, oracle_mod):
+    """A flat field has C_e = 0 everywhere: no pixel is scanned, every output stays zero, idx stays -1."""
+    vol = np.full((3, 7, 50, 1), 0.5, np.float32)
+    ref = oracle_mod.depth1d_pile_run(vol, -1.0, 1.0, 8)
+    comp, got = _run(rs, vol, -1.0, 1.0, 8)
+    assert comp.stats.pixels_scanned == 0
+    assert_pile_parity(got, ref, label="flat")
+    assert not got["edge_mask"].any() and (got["depth_idx"] == -1).all()
+
+
 def test_negative_radiances_take_generic_path(rs, oracle_mod):
     """max(R,0) != R when the input goes negative (core.hpp:580): register scan must not run."""
     rng = np.random.default_rng(11)

@@ -93,6 +93,29 @@ def test_nearest_interpolation_known_answer(oracle_mod):
         assert (nn.score[v, inner][m[v]] == 1.0).all()
 
 
+DEGENERATE = [(1, 1, 1, 1, 2, -1.0, 1.0),     # one pixel, one view, the smallest hypothesis grid (core.hpp:548 divides by D-1)
+              (1, 2, 2, 1, 2, -1.0, 1.0),
+              (2, 3, 3, 3, 3, 0.0, 0.0),      # dmin == dmax: every hypothesis the same line, first index wins
+              (1, 9, 5, 1, 4, -1.0, 1.0),     # U below the 9-tap edge filter: BORDER_REFLECT_101 folds more than once
+              (3, 1, 40, 1, 5, -2.0, 2.0),    # a single view: R = r-bar, score 1 for every hypothesis
+              (1, 5, 9, 1, 2, -1.0, 1.0),
+              (2, 4, 17, 3, 7, 1.0, 1.0)]
+
+
+@pytest.mark.parametrize("shape", DEGENERATE, ids=["%dx%dx%dx%d_D%d" % s[:5] for s in DEGENERATE])
+def test_degenerate_shapes_restatements_agree(oracle_mod, shape):
+    from oracle import oracle_np as onp
+    V, S, U, C_, D, dmin, dmax = shape
+    vol = np.random.default_rng(3 + U).uniform(0.0, 1.0, size=(V, S, U, C_)).astype(np.float32)
+    r = oracle_mod.depth1d_pile_run(vol, dmin, dmax, D)
+    n = onp.depth1d_pile_run(vol, np.float32(dmin), np.float32(dmax), D)
+    for ko, kn in (("edge_confidence", "Ce"), ("edge_mask", "Ce_mask"), ("depth_idx", "idx"), ("score", "score"),
+                   ("depth_raw", "depth_raw"), ("rbar", "rbar"), ("disp_confidence", "Cd"), ("depth", "depth")):
+        assert np.array_equal(getattr(r, ko), n[kn]), (shape, ko)
+    if dmin == dmax:
+        assert set(np.unique(r.depth_idx)) <= {-1, 0}     # ties: cv::minMaxLoc keeps the first maximum
+
+
 def test_analytic_known_answer(oracle_mod):
     """Independent of every OpenCV-semantics assumption: integer true disparity on the grid =>
     all samples of the true line are identical => K == 1, score == 1.0 exactly, argmax known."""
