@@ -516,9 +516,8 @@ __device__ __forceinline__ void scan_stream_body(const ScanArgs& a, int v, int u
                         x = x * slope;
                     }
                     x = x + uf;                          // core.hpp:552
-                    const float fl = floorf(x);          // interp.hpp:179
-                    tt[j] = x - fl;                      // interp.hpp:181
-                    int i0 = (int)fl;
+                    tt[j] = lerp_weight(x);              // interp.hpp:181
+                    int i0 = floor_to_int(x);            // interp.hpp:179
                     ok[j] = live;
                     if (BORDER) {
                         ok[j] = live && (__float_as_uint(x) <= Um1_bits);   // interp.hpp:182 (x is never -0)
@@ -717,9 +716,8 @@ __device__ __forceinline__ void scan_reg_body(const ScanArgs& a, int v, int u, i
                         x = x * slope;                 // core.hpp:551
                     }
                     x = x + uf;                        // core.hpp:552
-                    const float fl = floorf(x);        // interp.hpp:179
-                    tt[j] = x - fl;                    // interp.hpp:181
-                    int i0 = (int)fl;
+                    tt[j] = lerp_weight(x);            // interp.hpp:181
+                    int i0 = floor_to_int(x);          // interp.hpp:179
                     ok[j] = true;
                     if (BORDER) {
                         // interp.hpp:182: floor(x) >= 0 <=> x >= 0 and ceil(x) <= U-1 <=> x <= U-1.

@@ -72,6 +72,21 @@ __device__ __forceinline__ float kernel_weight(float q)
     return k;
 }
 
+// interp.hpp:179-181 for a position x >= 0: i0 = (int)floor(x) and t = x - floor(x), one instruction each
+// instead of floor + convert + subtract.  v_fract_f32 is x - floor(x) exactly for x >= 0 (for x < 0 close
+// to an integer it stays below 1 where the subtraction rounds to 1 -- callers only use t where x is valid,
+// i.e. non-negative); v_cvt_flr_i32_f32 converts with round toward -inf.
+__device__ __forceinline__ float lerp_weight(float x)
+{
+    return __builtin_amdgcn_fractf(x);
+}
+__device__ __forceinline__ int floor_to_int(float x)
+{
+    int i;
+    asm("v_cvt_flr_i32_f32_e32 %0, %1" : "=v"(i) : "v"(x));
+    return i;
+}
+
 // Four samples of one mean-shift pass (1 channel), hand-scheduled: 28 VALU instructions issued
 // stage by stage so that no instruction reads the result of the one before it (hipcc, left to
 // itself, allocates two temporaries and emits the 7-instruction chain of each sample back to
