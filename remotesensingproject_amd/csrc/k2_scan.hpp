@@ -638,7 +638,10 @@ constexpr int kPadSlack = 16;     // compiled slot counts step by at most this: 
 //            the wave computes the S offsets of a hypothesis once (2-4 lane-parallel rounds),
 //            parks them in LDS and every sample starts from one broadcast ds_read -- 3 VALU
 //            instructions fewer per sample than recomputing them per lane.
-template <int SPAD, int C, bool BORDER, bool UNIFORM_D>
+// PK:        the samples live in register PAIRS (s, s+1) and the mean-shift pass uses packed fp32
+//            instructions on them; the sums still take one sample at a time, in ascending s.  For the
+//            variants that run at one wave per SIMD (rslf_device.hpp, f2).
+template <int SPAD, int C, bool BORDER, bool UNIFORM_D, bool PK>
 __device__ __forceinline__ void scan_reg_body(const ScanArgs& a, int v, int u, int d0, int d1, Best<C>& best,
                                               float* __restrict__ otab)
 {
@@ -669,7 +672,8 @@ __device__ __forceinline__ void scan_reg_body(const ScanArgs& a, int v, int u, i
 #pragma unroll 1
     for (int d = d0; d < d1; d++) {
         const float Dd = hypothesis(dmin, range, denom, d);
-        float R[C][SPAD];
+        float R[PK ? 1 : C][PK ? 1 : SPAD];
+        f2 R2[PK ? C : 1][PK ? SPAD / 2 : 1];
         int card = BORDER ? 0 : S;
         // The gather is fully unrolled (R[] must be register-indexed).  Everything in it that
         // does not depend on d would otherwise be hoisted out of the d loop -- SPAD row
@@ -748,10 +752,19 @@ __device__ __forceinline__ void scan_reg_body(const ScanArgs& a, int v, int u, i
                     const float m0 = omt * e0[c][j];   // interp.hpp:184
                     const float m1 = tt[j] * e1[c][j];
                     const float r = m0 + m1;
+                    float val;
                     if (BORDER)
-                        R[c][s] = ok[j] ? r : kSentinel;
+                        val = ok[j] ? r : kSentinel;
                     else
-                        R[c][s] = (s < SPAD - kPadSlack || s < S) ? r : kSentinel;
+                        val = (s < SPAD - kPadSlack || s < S) ? r : kSentinel;
+                    if constexpr (PK) {
+                        if (s & 1)
+                            R2[c][s >> 1].y = val;
+                        else
+                            R2[c][s >> 1].x = val;
+                    } else {
+                        R[c][s] = val;
+                    }
                 }
                 if (BORDER)
                     card += ok[j] ? 1 : 0;
@@ -763,10 +776,16 @@ __device__ __forceinline__ void scan_reg_body(const ScanArgs& a, int v, int u, i
                 const int b = g * kGatherBatch;
 #pragma unroll
                 for (int c = 0; c < C; c++) {
-                    asm volatile("" : "+v"(R[c][b + 0]), "+v"(R[c][b + 1]), "+v"(R[c][b + 2]), "+v"(R[c][b + 3]));
-                    if (kGatherBatch == 8)
-                        asm volatile("" : "+v"(R[c][b + kGatherBatch - 4]), "+v"(R[c][b + kGatherBatch - 3]),
-                                          "+v"(R[c][b + kGatherBatch - 2]), "+v"(R[c][b + kGatherBatch - 1]));
+                    if constexpr (PK) {
+                        asm volatile("" : "+v"(R2[c][b / 2]), "+v"(R2[c][b / 2 + 1]));
+                        if (kGatherBatch == 8)
+                            asm volatile("" : "+v"(R2[c][b / 2 + 2]), "+v"(R2[c][b / 2 + 3]));
+                    } else {
+                        asm volatile("" : "+v"(R[c][b + 0]), "+v"(R[c][b + 1]), "+v"(R[c][b + 2]), "+v"(R[c][b + 3]));
+                        if (kGatherBatch == 8)
+                            asm volatile("" : "+v"(R[c][b + kGatherBatch - 4]), "+v"(R[c][b + kGatherBatch - 3]),
+                                              "+v"(R[c][b + kGatherBatch - 2]), "+v"(R[c][b + kGatherBatch - 1]));
+                    }
                 }
                 if (BORDER)
                     asm volatile("" : "+s"(rowoff), "+v"(Ss0), "+v"(card));
@@ -787,7 +806,57 @@ __device__ __forceinline__ void scan_reg_body(const ScanArgs& a, int v, int u, i
             for (int c = 0; c < C; c++)
                 A[c] = 0.0f;
             B = 0.0f;
-            if (C == 1) {
+            if constexpr (PK) {
+                // a pair of samples per step: delta, kq*delta, q, K and R*K as packed instructions on both
+                // samples, then the sums take sample s and sample s+1 in turn (core.hpp:602-603 order)
+                f2 rb2[C];
+                const f2 kq2 = {kq, kq};
+#pragma unroll
+                for (int c = 0; c < C; c++)
+                    rb2[c] = f2{rbar[c], rbar[c]};
+                // hand-scheduled blocks of 8 (C = 1) / 4 (C = 3) samples; the slots of a block that lie beyond S are
+                // padding (K = P = +0 exactly), whole blocks beyond S are skipped (wave-uniform)
+                constexpr int kBlk = (C == 1) ? 8 : 4;
+#pragma unroll
+                for (int s0 = 0; s0 < SPAD; s0 += kBlk) {
+                    if (!(s0 < SPAD - kPadSlack || s0 < S))
+                        continue;
+                    if constexpr (C == 1) {
+                        f2 P[4], K[4];
+                        const f2 r4[4] = {R2[0][s0 / 2], R2[0][s0 / 2 + 1], R2[0][s0 / 2 + 2], R2[0][s0 / 2 + 3]};
+                        mean_shift_pk_octet(r4, rb2[0], kq2, P, K);
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            A[0] = A[0] + P[j].x;                // core.hpp:602, ascending s
+                            B = B + K[j].x;                      // core.hpp:603
+                            A[0] = A[0] + P[j].y;
+                            B = B + K[j].y;
+                        }
+                    } else {
+                        f2 Pa[3], Pb[3], Ka, Kb;
+                        const f2 ra[3] = {R2[0][s0 / 2], R2[1][s0 / 2], R2[C - 1][s0 / 2]};
+                        const f2 rb[3] = {R2[0][s0 / 2 + 1], R2[1][s0 / 2 + 1], R2[C - 1][s0 / 2 + 1]};
+                        const f2 m[3] = {rb2[0], rb2[C > 1 ? 1 : 0], rb2[C - 1]};
+                        mean_shift_pk_rgb_quad(ra, rb, m, kq2, Pa, Pb, Ka, Kb);
+#pragma unroll
+                        for (int c = 0; c < C; c++)
+                            A[c] = A[c] + Pa[c].x;
+                        B = B + Ka.x;
+#pragma unroll
+                        for (int c = 0; c < C; c++)
+                            A[c] = A[c] + Pa[c].y;
+                        B = B + Ka.y;
+#pragma unroll
+                        for (int c = 0; c < C; c++)
+                            A[c] = A[c] + Pb[c].x;
+                        B = B + Kb.x;
+#pragma unroll
+                        for (int c = 0; c < C; c++)
+                            A[c] = A[c] + Pb[c].y;
+                        B = B + Kb.y;
+                    }
+                }
+            } else if (C == 1) {
                 // hand-scheduled, four samples per block (rslf_device.hpp).  Only the last kPadSlack slots can
                 // be padding: there a wave-uniform test skips what lies beyond S (a padded slot would add +0
                 // to both sums, so skipping it changes nothing but the instruction count).
@@ -851,15 +920,21 @@ constexpr int scan_reg_waves(int spad, int c)
     return w > 8 ? 8 : (w < 1 ? 1 : w);
 }
 
+// One wave per SIMD: a wave issues a VALU instruction every ~5 clocks whatever it is (tools/ubench_valu.hip),
+// so packed fp32 halves the issue slots of the mean-shift pass.  With two or more waves the SIMD is already
+// saturated by scalar instructions and packed ones run at half rate.
+constexpr bool scan_reg_packed_math(int spad, int c) { return scan_reg_waves(spad, c) == 1; }
+
 template <int SPAD, int C>
 __device__ __forceinline__ void scan_reg_rows(const ScanArgs& a, int v, int u, int d0, int d1, Best<C>& best, float* otab)
 {
+    constexpr bool PK = scan_reg_packed_math(SPAD, C);
     if (wave_is_interior(a, u))
-        scan_reg_body<SPAD, C, false, true>(a, v, u, d0, d1, best, otab);
+        scan_reg_body<SPAD, C, false, true, PK>(a, v, u, d0, d1, best, otab);
     else if (!a.dmin_vu)
-        scan_reg_body<SPAD, C, true, true>(a, v, u, d0, d1, best, otab);
+        scan_reg_body<SPAD, C, true, true, PK>(a, v, u, d0, d1, best, otab);
     else
-        scan_reg_body<SPAD, C, true, false>(a, v, u, d0, d1, best, otab);
+        scan_reg_body<SPAD, C, true, false, PK>(a, v, u, d0, d1, best, otab);
 }
 
 template <int SPAD, int C>
@@ -877,7 +952,7 @@ template <int SPAD, int C>
 __global__ __launch_bounds__(64 * kScanWaves) __attribute__((amdgpu_waves_per_eu(scan_reg_waves(SPAD + 24, C), scan_reg_waves(SPAD + 24, C))))
 void k2_scan_reg_packed(ScanArgs a)
 {
-    RSLF_SCAN_PACKED_LOOP((scan_reg_body<SPAD, C, true, false>(a, v, u, d0, d1, best, nullptr)))
+    RSLF_SCAN_PACKED_LOOP((scan_reg_body<SPAD, C, true, false, scan_reg_packed_math(SPAD + 24, C)>(a, v, u, d0, d1, best, nullptr)))
 }
 
 }  // namespace rslf

@@ -87,6 +87,106 @@ __device__ __forceinline__ int floor_to_int(float x)
     return i;
 }
 
+// Two floats in an aligned register pair: operands of v_pk_add_f32 / v_pk_mul_f32.  Each half is the same
+// IEEE operation as the scalar instruction (tools/ubench_pk.hip checks it bit for bit, sentinel and denormal
+// products included).  At one wave per SIMD a wave issues one VALU instruction every ~5 clocks whatever it
+// is, so there -- and only there -- a packed instruction does two samples' work for one issue slot.
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f2 kernel_weight_pk(f2 q)   // max(1 - q, 0) on both halves
+{
+    f2 k;
+    const f2 one = {1.0f, 1.0f};
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1] clamp" : "=v"(k) : "v"(one), "v"(q));
+    return k;
+}
+
+// Eight samples (four pairs) of one 1-channel mean-shift pass in packed instructions, issued stage by stage
+// (a dependent packed instruction needs its producer several slots back).  Leaves P = R*K and K per pair;
+// the caller adds them to the sums one sample at a time.
+__device__ __forceinline__ void mean_shift_pk_octet(const f2 (&r)[4], f2 rb, f2 kq, f2 (&P)[4], f2 (&K)[4])
+{
+    const f2 one = {1.0f, 1.0f};
+    f2 t0, t1, t2, t3;
+    asm("v_pk_add_f32 %[k0], %[r0], %[rb] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 %[k1], %[r1], %[rb] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 %[k2], %[r2], %[rb] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 %[k3], %[r3], %[rb] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_mul_f32 %[t0], %[kq], %[k0]\n\t"
+        "v_pk_mul_f32 %[t1], %[kq], %[k1]\n\t"
+        "v_pk_mul_f32 %[t2], %[kq], %[k2]\n\t"
+        "v_pk_mul_f32 %[t3], %[kq], %[k3]\n\t"
+        "v_pk_mul_f32 %[k0], %[k0], %[t0]\n\t"
+        "v_pk_mul_f32 %[k1], %[k1], %[t1]\n\t"
+        "v_pk_mul_f32 %[k2], %[k2], %[t2]\n\t"
+        "v_pk_mul_f32 %[k3], %[k3], %[t3]\n\t"
+        "v_pk_add_f32 %[k0], %[one], %[k0] neg_lo:[0,1] neg_hi:[0,1] clamp\n\t"
+        "v_pk_add_f32 %[k1], %[one], %[k1] neg_lo:[0,1] neg_hi:[0,1] clamp\n\t"
+        "v_pk_add_f32 %[k2], %[one], %[k2] neg_lo:[0,1] neg_hi:[0,1] clamp\n\t"
+        "v_pk_add_f32 %[k3], %[one], %[k3] neg_lo:[0,1] neg_hi:[0,1] clamp\n\t"
+        "v_pk_mul_f32 %[t0], %[r0], %[k0]\n\t"
+        "v_pk_mul_f32 %[t1], %[r1], %[k1]\n\t"
+        "v_pk_mul_f32 %[t2], %[r2], %[k2]\n\t"
+        "v_pk_mul_f32 %[t3], %[r3], %[k3]"
+        : [k0] "=&v"(K[0]), [k1] "=&v"(K[1]), [k2] "=&v"(K[2]), [k3] "=&v"(K[3]),
+          [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3)
+        : [r0] "v"(r[0]), [r1] "v"(r[1]), [r2] "v"(r[2]), [r3] "v"(r[3]), [rb] "v"(rb), [kq] "v"(kq), [one] "v"(one));
+    P[0] = t0;
+    P[1] = t1;
+    P[2] = t2;
+    P[3] = t3;
+}
+
+// Four samples (two pairs a, b) of one 3-channel pass: per channel delta, kq*delta, q; qs = (q0 + q2) + q1
+// (OpenCV 3.x reduceC_); K = clamp(1 - qs); P_c = R_c * K.  30 packed instructions for what takes 60 scalar ones.
+__device__ __forceinline__ void mean_shift_pk_rgb_quad(const f2 (&ra)[3], const f2 (&rb)[3], const f2 (&rbar)[3], f2 kq,
+                                                       f2 (&Pa)[3], f2 (&Pb)[3], f2& Ka, f2& Kb)
+{
+    const f2 one = {1.0f, 1.0f};
+    f2 da0, da1, da2, db0, db1, db2, ta0, ta1, ta2, tb0, tb1, tb2;
+    asm("v_pk_add_f32 %[da0], %[ra0], %[m0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 %[da1], %[ra1], %[m1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 %[da2], %[ra2], %[m2] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 %[db0], %[rb0], %[m0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 %[db1], %[rb1], %[m1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 %[db2], %[rb2], %[m2] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_mul_f32 %[ta0], %[kq], %[da0]\n\t"
+        "v_pk_mul_f32 %[ta1], %[kq], %[da1]\n\t"
+        "v_pk_mul_f32 %[ta2], %[kq], %[da2]\n\t"
+        "v_pk_mul_f32 %[tb0], %[kq], %[db0]\n\t"
+        "v_pk_mul_f32 %[tb1], %[kq], %[db1]\n\t"
+        "v_pk_mul_f32 %[tb2], %[kq], %[db2]\n\t"
+        "v_pk_mul_f32 %[da0], %[da0], %[ta0]\n\t"
+        "v_pk_mul_f32 %[da2], %[da2], %[ta2]\n\t"
+        "v_pk_mul_f32 %[db0], %[db0], %[tb0]\n\t"
+        "v_pk_mul_f32 %[db2], %[db2], %[tb2]\n\t"
+        "v_pk_mul_f32 %[da1], %[da1], %[ta1]\n\t"
+        "v_pk_mul_f32 %[db1], %[db1], %[tb1]\n\t"
+        "v_pk_add_f32 %[da0], %[da0], %[da2]\n\t"
+        "v_pk_add_f32 %[db0], %[db0], %[db2]\n\t"
+        "v_pk_add_f32 %[da0], %[da0], %[da1]\n\t"
+        "v_pk_add_f32 %[db0], %[db0], %[db1]\n\t"
+        "v_pk_add_f32 %[ka], %[one], %[da0] neg_lo:[0,1] neg_hi:[0,1] clamp\n\t"
+        "v_pk_add_f32 %[kb], %[one], %[db0] neg_lo:[0,1] neg_hi:[0,1] clamp\n\t"
+        "v_pk_mul_f32 %[ta0], %[ra0], %[ka]\n\t"
+        "v_pk_mul_f32 %[ta1], %[ra1], %[ka]\n\t"
+        "v_pk_mul_f32 %[ta2], %[ra2], %[ka]\n\t"
+        "v_pk_mul_f32 %[tb0], %[rb0], %[kb]\n\t"
+        "v_pk_mul_f32 %[tb1], %[rb1], %[kb]\n\t"
+        "v_pk_mul_f32 %[tb2], %[rb2], %[kb]"
+        : [da0] "=&v"(da0), [da1] "=&v"(da1), [da2] "=&v"(da2), [db0] "=&v"(db0), [db1] "=&v"(db1), [db2] "=&v"(db2),
+          [ta0] "=&v"(ta0), [ta1] "=&v"(ta1), [ta2] "=&v"(ta2), [tb0] "=&v"(tb0), [tb1] "=&v"(tb1), [tb2] "=&v"(tb2),
+          [ka] "=&v"(Ka), [kb] "=&v"(Kb)
+        : [ra0] "v"(ra[0]), [ra1] "v"(ra[1]), [ra2] "v"(ra[2]), [rb0] "v"(rb[0]), [rb1] "v"(rb[1]), [rb2] "v"(rb[2]),
+          [m0] "v"(rbar[0]), [m1] "v"(rbar[1]), [m2] "v"(rbar[2]), [kq] "v"(kq), [one] "v"(one));
+    Pa[0] = ta0;
+    Pa[1] = ta1;
+    Pa[2] = ta2;
+    Pb[0] = tb0;
+    Pb[1] = tb1;
+    Pb[2] = tb2;
+}
+
 // Four samples of one mean-shift pass (1 channel), hand-scheduled: 28 VALU instructions issued
 // stage by stage so that no instruction reads the result of the one before it (hipcc, left to
 // itself, allocates two temporaries and emits the 7-instruction chain of each sample back to
