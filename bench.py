@@ -285,7 +285,8 @@ def main() -> None:
                 "workload": "%s: %dx%d px x %d views x %d ch, %d hypotheses in [%g, %g], seed %d, all pixels confident" % (
                     args.config, U, V, S, C, D, cfg["dmin"], cfg["dmax"], cfg["seed"]),
                 "sharding": "none" if world == 1 else "scanline blocks + %d-row recomputed halo, RCCL gather of the output planes per step" % ((params.par_median_filter_size - 1) // 2),
-                "scan_kernel": "k2_scan_reg<%d>" % comp.stats.s_pad if comp.stats.scan_kernel == 1 else "k2_scan_generic<%d>" % C,
+                "scan_kernel": {1: "k2_scan_reg<%d,%d>" % (comp.stats.s_pad, C), 2: "k2_scan_stream<%d>" % C}.get(
+                    comp.stats.scan_kernel, "k2_scan_generic<%d>" % C),
                 "pixels_scanned": pixels,
             },
             "roofline": {
