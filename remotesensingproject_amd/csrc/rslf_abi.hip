@@ -1046,8 +1046,8 @@ extern "C" int rslf_depth_epi_2d(rslf_ctx* ctx, const rslf_volume* vol, const fl
     ctx->keep_total = true;
     bool first_visit = true;
     for (int s_hat : order) {
-        // After the centre view, propagation has explained most pixels: a visit scans a few per scanline
-        // and lasts as long as one wave's walk over its hypotheses -- share them out over 4x the waves.
+        // After the centre view, propagation has explained most pixels: a visit scans a few per scanline.
+        // Pack them into one list and share each tile's hypotheses out over 8 workgroups (k2_scan.hpp).
         ctx->scan_groups = first_visit ? 1 : 8;
         ctx->scan_packed = !first_visit;
         first_visit = false;
@@ -1055,21 +1055,23 @@ extern "C" int rslf_depth_epi_2d(rslf_ctx* ctx, const rslf_volume* vol, const fl
         float* Cd = d_Cd_svu + (size_t)s_hat * n;
         float* rbar = d_rbar_svu + (size_t)s_hat * n * C;
         uint8_t* cem = d_Ce_mask_svu + (size_t)s_hat * n;
-        // core.hpp:1012-1028.  The pile call leaves the median in `depth` and the raw plane in ctx->raw ...
-        rc = rslf_depth_epi_pile(ctx, vol, d_dmin_svu ? d_dmin_svu + (size_t)s_hat * n : nullptr,
+        // core.hpp:1012-1028: the pile call is the scan of every EPI followed by the selective median.  In the
+        // reference the stored plane keeps the RAW depths and only the local header is rebound to the median
+        // (core.hpp:892), which the propagation then paints from: so the scan writes `depth` and the median goes
+        // straight to ctx->filtered -- no plane copies.
+        rc = rslf_depth_epi_scan(ctx, vol, d_dmin_svu ? d_dmin_svu + (size_t)s_hat * n : nullptr,
                                  d_dmax_svu ? d_dmax_svu + (size_t)s_hat * n : nullptr, dmin, dmax, dim_d, s_hat,
                                  d_Ce_svu + (size_t)s_hat * n, cem, Cd, depth, rbar, p, mask_svu + (size_t)s_hat * n, nullptr,
-                                 nullptr, ctx->raw, nullptr);
+                                 nullptr, nullptr);
+        if (!rc)
+            rc = rslf_selective_median(ctx, vol, depth, ctx->filtered, s_hat, p->median_filter_size, cem,
+                                       p->median_filter_epsilon);
         if (rc) {
             ctx->keep_total = false;
             ctx->scan_groups = 1;
             ctx->scan_packed = false;
             return rc;
         }
-        // ... while in the reference the stored plane keeps the RAW depths and only the local header is
-        // rebound to the median (core.hpp:892): put them where the reference has them.
-        HIP_TRY(hipMemcpyAsync(ctx->filtered, depth, n * sizeof(float), hipMemcpyDeviceToDevice, st));
-        HIP_TRY(hipMemcpyAsync(depth, ctx->raw, n * sizeof(float), hipMemcpyDeviceToDevice, st));
         // core.hpp:1088-1129
         if (C == 1)
             hipLaunchKernelGGL(k4_propagate_claim<1>, grid_vu, dim3(256), 0, st, view_of(vol), s_hat, ctx->filtered, cem, rbar,
