@@ -425,3 +425,21 @@ def test_errors_do_not_throw_across_abi(rs):
     assert e.value.status == -2
     with pytest.raises(_lib.RslfError):
         rs.Volume(rs.default_context(), 2, 5, 70, 2)               # C = 2 unsupported
+
+
+def test_randomised_campaign_subset(monkeypatch):
+    """A fixed-seed slice of tools/fuzz_parity.py: random shapes, parameters, per-pixel ranges, masks, kernel
+    variants and launch shapes; every plane bit-identical to the oracle (profiles/r01_fuzz_parity.txt holds a
+    3000-case run)."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(os.path.dirname(__file__), "..", "tools", "fuzz_parity.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    for k in ("RSLF_FORCE_SCAN", "RSLF_FORCE_PACKED", "RSLF_FORCE_GROUPS"):
+        monkeypatch.setenv(k, os.environ.get(k, ""))   # restored after the test: run_case sets them per case
+    rng = np.random.default_rng(7)
+    for i in range(150):
+        c = fz.draw_case(rng)
+        fz.run_case(i, c, rng)
+    monkeypatch.delenv("RSLF_FORCE_SCAN", raising=False)
