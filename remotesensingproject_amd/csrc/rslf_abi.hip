@@ -70,9 +70,9 @@ struct rslf_ctx {
     // 2-D sweep scratch
     int* winner = nullptr;        // [S][V][U]
     uint8_t* sweep_mask = nullptr;
-    float* filtered = nullptr;    // [V][U]
-    float* raw = nullptr;         // [V][U]
-    size_t sweep_cap = 0;
+    float* filtered = nullptr;    // [V][U] median of the visited view, the propagation's source
+    size_t sweep_cap = 0;         // entries winner / sweep_mask can hold (S*V*U)
+    size_t sweep_plane_cap = 0;   // floats `filtered` can hold (V*U)
 };
 
 struct rslf_volume {
@@ -264,7 +264,6 @@ extern "C" int rslf_ctx_destroy(rslf_ctx* ctx)
     (void)hipFree(ctx->winner);
     (void)hipFree(ctx->sweep_mask);
     (void)hipFree(ctx->filtered);
-    (void)hipFree(ctx->raw);
     if (ctx->ev0)
         (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1)
@@ -984,26 +983,31 @@ extern "C" int rslf_edge_confidence_2d(rslf_ctx* ctx, const rslf_volume* vol, co
     return RSLF_OK;
 }
 
+// Two capacities: winner / running mask hold S*V*U entries, the median plane V*U.  (A single S*V*U
+// capacity once let a later volume with fewer views but larger planes overrun the plane: found by
+// tools/fuzz_sweep.py.)
 static int ensure_sweep_scratch(rslf_ctx* ctx, const rslf_volume* vol)
 {
     const size_t n = (size_t)vol->S * vol->V * vol->U;
     if (n > ctx->sweep_cap) {
         (void)hipFree(ctx->winner);
         (void)hipFree(ctx->sweep_mask);
-        (void)hipFree(ctx->filtered);
-        (void)hipFree(ctx->raw);
         ctx->winner = nullptr;
         ctx->sweep_mask = nullptr;
-        ctx->filtered = nullptr;
-        ctx->raw = nullptr;
         ctx->sweep_cap = 0;
         HIP_TRY(hipMalloc(&ctx->winner, n * sizeof(int)));
         HIP_TRY(hipMalloc(&ctx->sweep_mask, n));
-        HIP_TRY(hipMalloc(&ctx->filtered, (size_t)vol->V * vol->U * sizeof(float)));
-        HIP_TRY(hipMalloc(&ctx->raw, (size_t)vol->V * vol->U * sizeof(float)));
         ctx->sweep_cap = n;
         // every claim pass is undone by its apply pass, so one fill lasts
         HIP_TRY(hipMemsetAsync(ctx->winner, 0x7F, n * sizeof(int), ctx->stream));
+    }
+    const size_t plane = (size_t)vol->V * vol->U;
+    if (plane > ctx->sweep_plane_cap) {
+        (void)hipFree(ctx->filtered);
+        ctx->filtered = nullptr;
+        ctx->sweep_plane_cap = 0;
+        HIP_TRY(hipMalloc(&ctx->filtered, plane * sizeof(float)));
+        ctx->sweep_plane_cap = plane;
     }
     return RSLF_OK;
 }

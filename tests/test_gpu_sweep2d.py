@@ -109,3 +109,17 @@ def test_single_epi_computer(oracle_mod, C_, dtype):
     assert np.array_equal(got["depth"], ref["depth"])          # raw arg-max depths: no median in this class
     assert np.array_equal(got["rbar"], ref["rbar"])
     assert np.abs(got["disp_confidence"] - ref["Cd"]).max() <= 1e-5
+
+
+def test_scratch_reuse_across_shapes(oracle_mod):
+    """One context, volumes whose S*V*U shrinks while V*U grows: the per-view scratch (S*V*U entries) and the
+    per-plane scratch (V*U) have separate capacities.  A shared one once let the median plane overrun its
+    buffer and corrupt a neighbouring volume (found by tools/fuzz_sweep.py)."""
+    from remotesensingproject_amd import depth as rs
+    rng = np.random.default_rng(11)
+    for S, V, U in [(13, 2, 100), (5, 4, 110), (3, 16, 40), (2, 20, 45), (1, 30, 50)]:
+        vol = rng.uniform(0.0, 1.0, size=(V, S, U, 1)).astype(np.float32)
+        ref = oracle_mod.depth2d_run(vol, -1.0, 1.0, 12)
+        comp = rs.Depth2DComputer(vol, -1.0, 1.0, 12, epi_scale_factor=1.0)
+        comp.run()
+        _check(comp.results(), ref, "reuse_S%d_V%d_U%d" % (S, V, U))

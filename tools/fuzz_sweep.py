@@ -1,0 +1,112 @@
+"""Randomised parity campaign for the rows around the pile path: Depth2DComputer (2-D sweep + propagation) and
+FineToCoarse against the CPU oracle, on many small random light fields.
+
+    python tools/fuzz_sweep.py [cases] [seed]
+
+Two thirds of the cases run the 2-D sweep (random shape, channels, hypothesis count on both sides of the
+sparse-launch thresholds, scene kind), one third the whole fine-to-coarse pyramid.  Planes must be bit-identical
+(C_d within 1e-5).  Developer tool; exit code 1 on any failure.
+"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+import oracle
+from remotesensingproject_amd import depth as rs
+from remotesensingproject_amd.synth import make_lightfield
+
+
+def make_scene(rng, U, V, S, C, kind):
+    vol = make_lightfield(U, V, S, C, seed=int(rng.integers(1 << 30)), deltas=rng.integers(-1, 2, size=V).astype(np.float32))[0]
+    if kind == "noise":
+        vol = rng.uniform(0.0, 1.0, size=vol.shape).astype(np.float32)
+    elif kind == "mixed":
+        vol[V // 2:] = rng.uniform(0.0, 1.0, size=vol[V // 2:].shape).astype(np.float32)
+    elif kind == "jitter":      # a clean scene with per-view noise: propagation succeeds for some pixels only
+        vol = (vol + rng.normal(0.0, 0.03, size=vol.shape)).clip(0.0, 1.0).astype(np.float32)
+    return np.ascontiguousarray(vol, np.float32)
+
+
+def check_sweep(got, ref, label):
+    for k in ("edge_mask", "scan_mask"):
+        assert np.array_equal(got[k], getattr(ref, k)), (label, k)
+    for k, r in (("edge_confidence", ref.edge_confidence), ("depth", ref.depth), ("rbar", ref.rbar)):
+        bad = np.flatnonzero(got[k].reshape(-1) != r.reshape(-1))
+        assert bad.size == 0, (label, k, bad.size, np.unravel_index(bad[0], r.shape))
+    assert np.abs(got["disp_confidence"] - ref.disp_confidence).max() <= 1e-5, label
+
+
+def sweep_case(i, rng):
+    C = int(rng.choice([1, 1, 3]))
+    S = int(rng.choice([1, 2, 3, 5, 7, 9, 13]))
+    U = int(rng.choice([8, 33, 64, 65, 100, 150, 260]))
+    V = int(rng.integers(1, 9))
+    D = int(rng.choice([2, 5, 12, 16, 17, 31, 32, 40, 64, 70]))
+    kind = str(rng.choice(["struct", "noise", "mixed", "jitter"]))
+    lo = float(rng.choice([-1.0, -2.0, -0.5]))
+    hi = lo + float(rng.choice([2.0, 1.0, 3.5]))
+    vol = make_scene(rng, U, V, S, C, kind)
+    ref = oracle.depth2d_run(vol, lo, hi, D)
+    comp = rs.Depth2DComputer(vol, lo, hi, D, epi_scale_factor=1.0)
+    comp.run()
+    check_sweep(comp.results(), ref, "sweep%d %s" % (i, (C, S, U, V, D, kind, lo, hi)))
+    return int(comp.stats.pixels_scanned)
+
+
+def f2c_case(i, rng):
+    C = int(rng.choice([1, 1, 3]))
+    S = int(rng.choice([2, 3, 5, 7]))
+    U = int(rng.choice([20, 33, 64, 90, 130]))
+    V = int(rng.choice([11, 16, 24, 40, 65]))
+    D = int(rng.choice([5, 9, 16, 33, 40]))
+    kind = str(rng.choice(["struct", "mixed", "jitter"]))
+    vol = make_scene(rng, U, V, S, C, kind)
+    raw = (vol * np.float32(rng.choice([1.0, 200.0])) + np.float32(rng.choice([0.0, 3.0]))).astype(np.float32)
+    ref = oracle.fine_to_coarse_run(raw, -1.0, 1.0, D)
+    f = rs.FineToCoarse(raw, -1.0, 1.0, D)
+    label = "f2c%d %s" % (i, (C, S, U, V, D, kind))
+    assert [(c.m_epis.V, c.m_epis.U) for c in f.m_computers] == ref["dims"], label
+    f.run()
+    units = 0
+    for p, (comp, lv) in enumerate(zip(f.m_computers, ref["levels"])):
+        check_sweep(comp.results(), lv, "%s level %d" % (label, p))
+        assert np.array_equal(comp.get_valid_depths_mask_s_v_u().cpu().numpy(), ref["valids"][p]), (label, p)
+        units += int(comp.stats.pixels_scanned)
+    out_map, out_valid = f.get_results()
+    assert np.array_equal(out_map.cpu().numpy(), ref["fused_map"]), label
+    assert np.array_equal(out_valid.cpu().numpy(), ref["fused_valid"]), label
+    return units
+
+
+def main():
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 150
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    oracle.set_num_threads(min(oracle.usable_cpus(), 16))
+    only = int(os.environ.get("FUZZ_ONLY", "-1"))     # replay one case: every case has its own generator
+    bad, t0, pixels, n = 0, time.time(), 0, {"sweep": 0, "f2c": 0}
+    for i in range(cases):
+        if only >= 0 and i != only:
+            continue
+        rng = np.random.default_rng([seed, i])
+        which = "f2c" if i % 3 == 2 else "sweep"
+        try:
+            pixels += (f2c_case if which == "f2c" else sweep_case)(i, rng)
+            n[which] += 1
+        except AssertionError as e:
+            bad += 1
+            print("FAIL case %d: %s" % (i, str(e)[:400]), flush=True)
+        except Exception as e:  # noqa: BLE001
+            bad += 1
+            print("ERROR case %d (%s): %r" % (i, which, e), flush=True)
+        if (i + 1) % 25 == 0:
+            print("... %d cases, %d failures, %.0f s" % (i + 1, bad, time.time() - t0), flush=True)
+    print("fuzz_sweep: %d cases (seed %d; %d sweeps, %d pyramids passed), %d failures, %.0f s; %d pixels scanned on the GPU side" % (
+        cases, seed, n["sweep"], n["f2c"], bad, time.time() - t0, pixels))
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
