@@ -49,7 +49,10 @@ def draw_case(rng):
                 iters=float(rng.choice([10.0, 10.0, 1.0, 3.5, 12.0])), h=float(rng.choice([0.2, 0.2, 0.1, 0.5])),
                 thr=float(rng.choice([0.02, 0.02, 0.0, 0.2])), raw_thr=float(rng.choice([0.0, 0.0, 0.3])),
                 median=int(rng.choice([5, 5, 3, 7, 1])), shadows=bool(rng.uniform() < 0.8),
-                negative=bool(rng.uniform() < 0.1), interp=int(rng.choice([0, 0, 0, 0, 1, 2])))
+                negative=bool(rng.uniform() < 0.1), interp=int(rng.choice([0, 0, 0, 0, 1, 2])),
+                # how the light field reaches the device: dense device tensor, host EPIs (f32, scale 1), host EPIs
+                # normalised by their max (dc.hpp:442-460), uint8 EPIs (x/255, dc.hpp:470), uint8 image stack (io.cpp:194-227)
+                form=str(rng.choice(["dense", "dense", "epis_f32", "epis_max", "epis_u8", "images_u8"])))
 
 
 def make_volume(c, rng):
@@ -88,8 +91,27 @@ def run_case(i, c, rng):
     pr.par_interpolation_class = c["interp"]
     s_hat = c["s_hat"]
     if not (c["planes"] or c["mask"]):
+        form = c["form"] if not c["negative"] else "dense"
+        sq = (lambda a: np.ascontiguousarray(a[..., 0])) if C == 1 else np.ascontiguousarray   # [S,U,1] -> [S,U]
+        if form == "dense":
+            src, scale = torch.from_numpy(vol).cuda(), 1.0
+        elif form == "epis_f32":
+            src, scale = [sq(vol[v]) for v in range(V)], 1.0
+        elif form == "epis_max":
+            raw = (vol * np.float32(rng.uniform(2.0, 300.0))).astype(np.float32)
+            src, scale = [sq(raw[v]) for v in range(V)], -1.0
+            vol, _ = oracle.normalize_f32(raw, -1.0)
+        else:
+            raw = (vol.clip(0.0, 1.0) * 255.0).astype(np.uint8)
+            vol = oracle.normalize_u8(raw)
+            if form == "epis_u8":
+                src, scale = [sq(raw[v]) for v in range(V)], 1.0
+            else:
+                src, scale = rs.Volume.from_images([sq(raw[:, s_]) for s_ in range(S)]), 1.0
         ref = oracle.depth1d_pile_run(vol, c["dmin"], c["dmax"], c["D"], s_hat, params=po)
-        comp = rs.Depth1DComputer_pile(vol, c["dmin"], c["dmax"], c["D"], s_hat, 1.0, pr)
+        if isinstance(src, torch.Tensor):
+            src = rs.Volume.from_dense(src, 1.0)
+        comp = rs.Depth1DComputer_pile(src, c["dmin"], c["dmax"], c["D"], s_hat, scale, pr)
         comp.run()
         got = comp.results()
         assert_pile_parity(got, ref, label="case%d" % i)
