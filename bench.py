@@ -48,7 +48,13 @@ def cpu_baseline(cfg: dict, budget_s: float = 12.0) -> dict:
     threads = int(os.environ.get("RSLF_CPU_THREADS", "0")) or min(oracle.usable_cpus(), 16)
     oracle.set_num_threads(threads)
     rows = max(2 * threads, 8)
-    vol, _ = make_lightfield(cfg["U"], rows, cfg["S"], cfg["C"], seed=cfg["seed"], dmin=cfg["dmin"], dmax=cfg["dmax"])
+    if cfg["seed"] is None:   # c1: the committed crop of data/000.tif, 9 identical views (see main)
+        crop = np.load(os.path.join(ROOT, "tests", "golden", "c1_crop_000tif_rows400_424.npy"))
+        tif_max = json.load(open(os.path.join(ROOT, "tests", "golden", "c1_anchor.json")))["tif_max"]
+        plane = crop[np.arange(rows) % crop.shape[0]] * np.float32(1.0 / float(tif_max))
+        vol = np.ascontiguousarray(np.repeat(plane[:, None, :, None], cfg["S"], axis=1), np.float32)
+    else:
+        vol, _ = make_lightfield(cfg["U"], rows, cfg["S"], cfg["C"], seed=cfg["seed"], dmin=cfg["dmin"], dmax=cfg["dmax"])
     # units = pixels whose mask is set on entry to the scan (core.hpp:515-527) x hypotheses
     pixels = int((oracle.edge_confidence_pile(vol, cfg["S"] // 2)[1] > 0).sum())
     oracle.depth1d_pile_run(vol[:threads], cfg["dmin"], cfg["dmax"], cfg["D"])   # untimed: thread pool, page faults
@@ -64,7 +70,7 @@ def cpu_baseline(cfg: dict, budget_s: float = 12.0) -> dict:
         "unit": "Mpixel*hyp/s",
         "cores": threads,
         "kind": "port",
-        "sample": "%d scanlines x %d px x %d views x %d hypotheses of the same synthetic field, %d passes, %.1f s" % (
+        "sample": "%d scanlines x %d px x %d views x %d hypotheses of the same field, %d passes, %.1f s" % (
             rows, cfg["U"], cfg["S"], cfg["D"], reps, elapsed),
     }
 
@@ -196,8 +202,18 @@ def main() -> None:
     params = rs.Depth1DParameters()
     shard = sharding.make_shard(V, rank, world, params.par_median_filter_size)
 
-    # synthetic light field: every rank draws the same textures and keeps its scanlines (+halo)
-    host, _ = make_lightfield(U, V, S, C, seed=cfg["seed"], dmin=cfg["dmin"], dmax=cfg["dmax"], rows=shard.rows)
+    if cfg["seed"] is None:
+        # c1 (BASELINE.json configs[0]): data/000.tif replicated into 9 identical views.  The file itself does not
+        # travel; the committed 24-row crop (tests/golden, rows 400-424) is tiled to the config's 960 scanlines and
+        # normalised by the file's max as the constructor does (dc.hpp:474).
+        crop = np.load(os.path.join(ROOT, "tests", "golden", "c1_crop_000tif_rows400_424.npy"))
+        tif_max = json.load(open(os.path.join(ROOT, "tests", "golden", "c1_anchor.json")))["tif_max"]
+        rows_v = np.arange(V)[shard.rows] % crop.shape[0]
+        plane = crop[rows_v] * np.float32(1.0 / float(tif_max))
+        host = np.ascontiguousarray(np.repeat(plane[:, None, :, None], S, axis=1), np.float32)
+    else:
+        # synthetic light field: every rank draws the same textures and keeps its scanlines (+halo)
+        host, _ = make_lightfield(U, V, S, C, seed=cfg["seed"], dmin=cfg["dmin"], dmax=cfg["dmax"], rows=shard.rows)
     ctx = rs.default_context(dev)
     vol = rs.Volume.from_dense(torch.from_numpy(host).to(dev), 1.0, ctx)
     del host
@@ -280,10 +296,12 @@ def main() -> None:
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic" if backend == "nccl" else "synthetic (REHEARSAL: %s backend, not a result)" % backend,
+            "data": ("synthetic" if cfg["seed"] is not None else "crop of the reference's data/000.tif, tiled") if backend == "nccl" else "synthetic (REHEARSAL: %s backend, not a result)" % backend,
             "config": {
-                "workload": "%s: %dx%d px x %d views x %d ch, %d hypotheses in [%g, %g], seed %d, all pixels confident" % (
-                    args.config, U, V, S, C, D, cfg["dmin"], cfg["dmax"], cfg["seed"]),
+                "workload": "%s: %dx%d px x %d views x %d ch, %d hypotheses in [%g, %g], %s" % (
+                    args.config, U, V, S, C, D, cfg["dmin"], cfg["dmax"],
+                    "seed %d, all pixels confident" % cfg["seed"] if cfg["seed"] is not None else
+                    "24-row crop of data/000.tif tiled to %d scanlines, %d identical views, real edge mask" % (V, S)),
                 "sharding": "none" if world == 1 else "scanline blocks + %d-row recomputed halo, RCCL gather of the output planes per step" % ((params.par_median_filter_size - 1) // 2),
                 "scan_kernel": {1: "k2_scan_reg<%d,%d>" % (comp.stats.s_pad, C), 2: "k2_scan_stream<%d>" % C}.get(
                     comp.stats.scan_kernel, "k2_scan_generic<%d>" % C),
