@@ -200,7 +200,7 @@ def main() -> None:
         cfg["V"] = args.rows
     U, V, S, C, D = cfg["U"], cfg["V"], cfg["S"], cfg["C"], cfg["D"]
     params = rs.Depth1DParameters()
-    shard = sharding.make_shard(V, rank, world, params.par_median_filter_size)
+    shard = sharding.make_shard(V, rank, world, params.par_median_filter_size, params.par_edge_confidence_opening_size)
 
     if cfg["seed"] is None:
         # c1 (BASELINE.json configs[0]): data/000.tif replicated into 9 identical views.  The file itself does not
@@ -302,7 +302,8 @@ def main() -> None:
                     args.config, U, V, S, C, D, cfg["dmin"], cfg["dmax"],
                     "seed %d, all pixels confident" % cfg["seed"] if cfg["seed"] is not None else
                     "24-row crop of data/000.tif tiled to %d scanlines, %d identical views, real edge mask" % (V, S)),
-                "sharding": "none" if world == 1 else "scanline blocks + %d-row recomputed halo, RCCL gather of the output planes per step" % ((params.par_median_filter_size - 1) // 2),
+                "sharding": "none" if world == 1 else "scanline blocks + %d-row recomputed halo, RCCL gather of the output planes per step" % sharding.halo_rows(
+                    params.par_median_filter_size, params.par_edge_confidence_opening_size),
                 "scan_kernel": {1: "k2_scan_reg<%d,%d>" % (comp.stats.s_pad, C), 2: "k2_scan_stream<%d>" % C}.get(
                     comp.stats.scan_kernel, "k2_scan_generic<%d>" % C),
                 "pixels_scanned": pixels,

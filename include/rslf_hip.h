@@ -58,8 +58,9 @@ typedef struct rslf_params {
     float raw_score_threshold;          /* 0 */
     float mean_shift_max_iter;          /* 10; a float in the reference (:115) */
     int   edge_confidence_filter_size;  /* 9 */
-    int   edge_confidence_opening_type; /* cv::MORPH_ELLIPSE = 2 (unused: size 1) */
-    int   edge_confidence_opening_size; /* 1 = no morphological opening; >1 is RSLF_ERR_UNSUPPORTED */
+    int   edge_confidence_opening_type; /* cv::MORPH_RECT 0 / MORPH_CROSS 1 / MORPH_ELLIPSE 2 (default) */
+    int   edge_confidence_opening_size; /* 1 = no morphological opening (default); k in 2..31: cv::morphologyEx(MORPH_OPEN)
+                                           with getStructuringElement(type, Size(k, k)) on the edge mask (core.hpp:759-768) */
     int   median_filter_size;           /* 5 (odd, <= 7) */
     float median_filter_epsilon;        /* 0.1 */
     float propagation_epsilon;          /* 0.1 (unused by this path) */

@@ -35,6 +35,8 @@ class OracleParams(C.Structure):
         ("shadow_level", C.c_float),
         ("kernel_bandwidth", C.c_float),
         ("interpolation", C.c_int),     # 0 linear, 1 nearest (interp.hpp:80-92), 2 nearest as built (interp.hpp:118)
+        ("edge_confidence_opening_type", C.c_int),   # cv::MORPH_RECT 0 / CROSS 1 / ELLIPSE 2
+        ("edge_confidence_opening_size", C.c_int),   # 1 = off
     ]
 
 

@@ -34,6 +34,8 @@ def default_params() -> dict:
         shadow_level=F(0.05 * SQRT3),
         kernel_bandwidth=F(0.2),
         interpolation=0,             # core.hpp:76: Interpolation1DLinear; 1 / 2 = nearest (see rslf_oracle.h)
+        edge_confidence_opening_type=2,   # cv::MORPH_ELLIPSE, core.hpp:28
+        edge_confidence_opening_size=1,   # core.hpp:29: 1 = no opening
     )
 
 
@@ -74,6 +76,57 @@ def edge_confidence_row(row: np.ndarray, p: dict):
         Ce[_norm(row) < p["shadow_level"]] = F(0)
     mask = np.where(Ce > p["edge_score_threshold"], 255, 0).astype(np.uint8)
     return Ce, mask
+
+
+def structuring_element(shape: int, k: int) -> np.ndarray:
+    """cv::getStructuringElement(shape, Size(k, k)), default anchor (OpenCV 3.x morph.cpp): [k,k] bool."""
+    r = c = k // 2
+    el = np.zeros((k, k), bool)
+    for i in range(k):
+        if shape == 0 or (shape == 1 and i == k // 2):
+            el[i, :] = True
+        elif shape == 1:
+            el[i, k // 2] = True
+        else:
+            dy = i - r
+            if abs(dy) <= r:
+                inv_r2 = 1.0 / (r * r) if r else 0.0
+                dx = int(np.rint(c * np.sqrt((r * r - dy * dy) * inv_r2)))     # cvRound
+                el[i, max(c - dx, 0):min(c + dx + 1, k)] = True
+    return el
+
+
+def morph_open(mask: np.ndarray, shape: int, k: int) -> np.ndarray:
+    """cv::morphologyEx(MORPH_OPEN): erosion then dilation over the structuring element, anchor (k/2, k/2);
+    outside the image counts as 255 for the erosion and 0 for the dilation (morphologyDefaultBorderValue).
+    Written with shifted planes, unlike the C oracle's per-pixel loops."""
+    el = structuring_element(shape, k)
+    a = k // 2
+    V, U = mask.shape
+
+    def one(src, fill, reduce):
+        pad = np.full((V + 2 * k, U + 2 * k), fill, np.uint8)
+        pad[k:k + V, k:k + U] = src
+        acc = np.full((V, U), fill, np.uint8)
+        for i in range(k):
+            for j in range(k):
+                if el[i, j]:
+                    y0, x0 = k + i - a, k + j - a
+                    acc = reduce(acc, pad[y0:y0 + V, x0:x0 + U])
+        return acc
+
+    return one(one(mask, 255, np.minimum), 0, np.maximum)
+
+
+def _edge_confidence_plane(vol, s, p):
+    """compute_1D_edge_confidence_pile (core.hpp:728-770): every row, then the optional opening."""
+    V, S, U, C = vol.shape
+    Ce = np.zeros((V, U), F); cm = np.zeros((V, U), np.uint8)
+    for v in range(V):
+        Ce[v], cm[v] = edge_confidence_row(vol[v, s], p)
+    if int(p.get("edge_confidence_opening_size", 1)) > 1:      # core.hpp:759-768
+        cm = morph_open(cm, int(p.get("edge_confidence_opening_type", 2)), int(p["edge_confidence_opening_size"]))
+    return Ce, cm
 
 
 def _kernel(delta: np.ndarray, inv_h2: F, k1: F) -> np.ndarray:
@@ -213,9 +266,9 @@ def depth1d_pile_run(vol, dmin, dmax, D, s_hat=-1, p=None):
                idx=np.full((V, U), -1, np.int32), score=np.zeros((V, U), F))
     dmin_u = np.full(U, dmin, F)
     dmax_u = np.full(U, dmax, F)
+    Ce_all, cm_all = _edge_confidence_plane(vol, s_hat, p)
     for v in range(V):
-        Ce, m = edge_confidence_row(vol[v, s_hat], p)
-        r = depth_epi(vol[v], dmin_u, dmax_u, D, s_hat, Ce, m, p)
+        r = depth_epi(vol[v], dmin_u, dmax_u, D, s_hat, Ce_all[v], cm_all[v], p)
         out["Ce"][v], out["Ce_mask"][v], out["Cd"][v] = r["Ce"], r["Ce_mask"], r["Cd"]
         out["depth_raw"][v], out["rbar"][v], out["idx"][v], out["score"][v] = r["depth"], r["rbar"], r["idx"], r["score"]
     out["depth"] = selective_median(out["depth_raw"], vol, s_hat, out["Ce_mask"],
@@ -230,8 +283,7 @@ def depth2d_run(vol, dmin, dmax, D, p=None, propagation_epsilon=F(0.1)):
     V, S, U, C = vol.shape
     Ce = np.zeros((S, V, U), F); cm = np.zeros((S, V, U), np.uint8)
     for s in range(S):
-        for v in range(V):
-            Ce[s, v], cm[s, v] = edge_confidence_row(vol[v, s], p)
+        Ce[s], cm[s] = _edge_confidence_plane(vol, s, p)
     Cd = np.zeros((S, V, U), F); depth = np.zeros((S, V, U), F); rbar = np.zeros((S, V, U, C), F)
     mask = cm.copy()                                            # core.hpp:958-965
     s_mid = int(np.floor(S / 2.0))

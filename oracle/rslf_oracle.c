@@ -36,6 +36,8 @@ void oracle_default_params(oracle_params* p)
     p->shadow_level = (float)(0.05 * SQRT3_D);
     p->kernel_bandwidth = (float)0.2;
     p->interpolation = ORACLE_INTERP_LINEAR;   /* core.hpp:76 */
+    p->edge_confidence_opening_type = 2;       /* cv::MORPH_ELLIPSE, core.hpp:28 */
+    p->edge_confidence_opening_size = 1;       /* core.hpp:29 */
 }
 
 /* Interpolation1DNearestNeighbour::interpolate_mat (interp.hpp:94-131): the sample index for position x,
@@ -165,6 +167,66 @@ void oracle_edge_confidence_row(const float* row, int U, int C,
 
 /* ---- core.hpp:728-770 ------------------------------------------------- */
 
+/* cv::getStructuringElement (OpenCV 3.x imgproc/src/morph.cpp): r = k/2, c = k/2, anchor = (k/2, k/2);
+ * RECT: every column; CROSS: the anchor row entirely, else the anchor column; ELLIPSE: columns
+ * [c - dx, c + dx + 1) with dx = cvRound(c * sqrt((r*r - dy*dy) / (r*r))), dy = i - r, rows with |dy| <= r. */
+void oracle_structuring_element(int shape, int k, uint8_t* out)
+{
+    const int r = k / 2, c = k / 2;
+    const double inv_r2 = r ? 1.0 / ((double)r * r) : 0.0;
+    memset(out, 0, (size_t)k * k);
+    for (int i = 0; i < k; i++) {
+        int j1 = 0, j2 = 0;
+        if (shape == 0 || (shape == 1 && i == k / 2)) {
+            j2 = k;
+        } else if (shape == 1) {
+            j1 = k / 2;
+            j2 = j1 + 1;
+        } else {
+            const int dy = i - r;
+            if (abs(dy) <= r) {
+                const int dx = (int)lrint(c * sqrt((r * r - dy * dy) * inv_r2));   /* saturate_cast<int>(double) = cvRound */
+                j1 = c - dx > 0 ? c - dx : 0;
+                j2 = c + dx + 1 < k ? c + dx + 1 : k;
+            }
+        }
+        for (int j = j1; j < j2; j++)
+            out[(size_t)i * k + j] = 1;
+    }
+}
+
+static void morph_pass(const uint8_t* src, uint8_t* dst, int V, int U, const uint8_t* el, int k, int dilate)
+{
+    const int a = k / 2;   /* anchor */
+#pragma omp parallel for schedule(static)
+    for (int v = 0; v < V; v++)
+        for (int u = 0; u < U; u++) {
+            int acc = dilate ? 0 : 255;
+            for (int i = 0; i < k; i++)
+                for (int j = 0; j < k; j++) {
+                    if (!el[(size_t)i * k + j])
+                        continue;
+                    const int y = v + i - a, x = u + j - a;
+                    if (y < 0 || y >= V || x < 0 || x >= U)
+                        continue;   /* border value: +max for erosion, min for dilation -- never wins */
+                    const int val = src[(size_t)y * U + x];
+                    acc = dilate ? (val > acc ? val : acc) : (val < acc ? val : acc);
+                }
+            dst[(size_t)v * U + u] = (uint8_t)acc;
+        }
+}
+
+void oracle_morph_open(uint8_t* mask_vu, int V, int U, int shape, int k)
+{
+    uint8_t* el = (uint8_t*)malloc((size_t)k * k);
+    uint8_t* tmp = (uint8_t*)malloc((size_t)V * U);
+    oracle_structuring_element(shape, k, el);
+    morph_pass(mask_vu, tmp, V, U, el, k, 0);   /* erode  */
+    morph_pass(tmp, mask_vu, V, U, el, k, 1);   /* dilate */
+    free(tmp);
+    free(el);
+}
+
 void oracle_edge_confidence_pile(const float* vol, int V, int S, int U, int C,
                                  int s, float* Ce_vu, uint8_t* mask_vu,
                                  const oracle_params* p)
@@ -175,7 +237,8 @@ void oracle_edge_confidence_pile(const float* vol, int V, int S, int U, int C,
         oracle_edge_confidence_row(row, U, C, Ce_vu + (size_t)v * U,
                                    mask_vu + (size_t)v * U, p);
     }
-    /* par_edge_confidence_opening_size == 1: no morphology (core.hpp:759, :29) */
+    if (p->edge_confidence_opening_size > 1)   /* core.hpp:759-768 */
+        oracle_morph_open(mask_vu, V, U, p->edge_confidence_opening_type, p->edge_confidence_opening_size);
 }
 
 /* ---- core.hpp:480-661 ------------------------------------------------- */

@@ -53,7 +53,16 @@ typedef struct oracle_params {
     float shadow_level;              /* 0.05*sqrt(3)                    core.hpp:31  */
     float kernel_bandwidth;          /* h = 0.2                         core.hpp:26  */
     int   interpolation;             /* par_interpolation_class (core.hpp:76-77, :108): ORACLE_INTERP_* */
+    int   edge_confidence_opening_type; /* cv::MORPH_RECT 0 / MORPH_CROSS 1 / MORPH_ELLIPSE 2 (default) core.hpp:28 */
+    int   edge_confidence_opening_size; /* 1 = no opening (default)            core.hpp:29, :759     */
 } oracle_params;
+
+/* cv::getStructuringElement(shape, Size(k, k)) with the default anchor (k/2, k/2), as OpenCV 3.x builds it:
+ * element[i][j] != 0 for j in [j1, j2) of row i.  out: k*k bytes (0/1). */
+void oracle_structuring_element(int shape, int k, uint8_t* out);
+/* cv::morphologyEx(mask, mask, MORPH_OPEN, element): erosion then dilation, BORDER_CONSTANT with
+ * morphologyDefaultBorderValue (pixels outside the image never win the min / the max).  In place, V x U. */
+void oracle_morph_open(uint8_t* mask_vu, int V, int U, int shape, int k);
 
 /* par_interpolation_class.  LINEAR = Interpolation1DLinear (interp.hpp:155-193), the default.
  * NEAREST = Interpolation1DNearestNeighbour as its scalar interpolate() states it (interp.hpp:80-92):

@@ -140,6 +140,41 @@ __global__ __launch_bounds__(256) void k1_edge_confidence(VolView vol, int s, Ed
     mask[o] = (ce > ec.edge_thr) ? 255 : 0;
 }
 
+// ---- optional morphological opening of the edge mask -----------------------
+// core.hpp:759-768: cv::morphologyEx(mask, mask, MORPH_OPEN, getStructuringElement(type, Size(k, k))).
+// One pass = erosion (min) or dilation (max) over the element's set pixels around the anchor (k/2, k/2);
+// pixels outside the plane never win (morphologyDefaultBorderValue).  The element arrives as one bit row
+// per kernel row (k <= 31).  HBM-bound byte work: k*k mask reads per pixel, served by L1/L2.
+struct MorphElement {
+    int k;
+    unsigned rows[31];
+};
+
+__global__ __launch_bounds__(256) void k1_morph_pass(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int V, int U,
+                                                    MorphElement el, int dilate)
+{
+    const int v = blockIdx.y;
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= U)
+        return;
+    const int a = el.k / 2;
+    int acc = dilate ? 0 : 255;
+    for (int i = 0; i < el.k; i++) {
+        const int y = v + i - a;
+        if (y < 0 || y >= V)
+            continue;
+        const unsigned bits = el.rows[i];
+        for (int j = 0; j < el.k; j++) {
+            const int x = u + j - a;
+            if (!((bits >> j) & 1u) || x < 0 || x >= U)
+                continue;
+            const int val = src[(long long)y * U + x];
+            acc = dilate ? max(acc, val) : min(acc, val);
+        }
+    }
+    dst[(long long)v * U + u] = (uint8_t)acc;
+}
+
 // ---- compaction of the scan mask -------------------------------------------
 // core.hpp:510-516: scan mask = edge mask (& caller mask, written back in
 // place), then findNonZero.  One block per scanline writes the ascending list

@@ -195,9 +195,11 @@ static int check_params(const rslf_params* p)
 {
     if (!p)
         return fail(RSLF_ERR_INVALID_ARG, "params is NULL");
-    if (p->edge_confidence_opening_size > 1)
-        return fail(RSLF_ERR_UNSUPPORTED, "edge_confidence_opening_size > 1 (morphological opening) is not implemented; "
-                                          "the reference default is 1 = off (core.hpp:29, :759)");
+    if (p->edge_confidence_opening_size > 31)
+        return fail(RSLF_ERR_UNSUPPORTED, "edge_confidence_opening_size=%d: structuring elements up to 31 x 31", p->edge_confidence_opening_size);
+    if (p->edge_confidence_opening_size > 1 && (p->edge_confidence_opening_type < 0 || p->edge_confidence_opening_type > 2))
+        return fail(RSLF_ERR_INVALID_ARG, "edge_confidence_opening_type=%d is not cv::MORPH_RECT (0), MORPH_CROSS (1) or MORPH_ELLIPSE (2)",
+                    p->edge_confidence_opening_type);
     if (p->edge_confidence_filter_size < 1 || (p->edge_confidence_filter_size & 1) == 0)
         return fail(RSLF_ERR_INVALID_ARG, "edge_confidence_filter_size must be odd and >= 1");
     if (p->median_filter_size < 1 || (p->median_filter_size & 1) == 0 || p->median_filter_size > kMedianMaxSize)
@@ -550,6 +552,38 @@ extern "C" int rslf_volume_pack_device_f32(rslf_volume* vol, const float* d_vsuc
     return minmax_end(vol);
 }
 
+// cv::getStructuringElement(shape, Size(k, k)) with the default anchor, as OpenCV 3.x builds it (imgproc/src/morph.cpp):
+// RECT every column; CROSS the anchor row entirely, elsewhere the anchor column; ELLIPSE the columns
+// [c - dx, c + dx + 1), dx = cvRound(c * sqrt((r*r - dy*dy) / (r*r))), r = c = k/2, dy = i - r.
+static MorphElement structuring_element(int shape, int k)
+{
+    MorphElement el;
+    el.k = k;
+    const int r = k / 2, c = k / 2;
+    const double inv_r2 = r ? 1.0 / ((double)r * r) : 0.0;
+    for (int i = 0; i < 31; i++)
+        el.rows[i] = 0;
+    for (int i = 0; i < k; i++) {
+        int j1 = 0, j2 = 0;
+        if (shape == 0 || (shape == 1 && i == k / 2)) {
+            j2 = k;
+        } else if (shape == 1) {
+            j1 = k / 2;
+            j2 = j1 + 1;
+        } else {
+            const int dy = i - r;
+            if (std::abs(dy) <= r) {
+                const int dx = (int)std::lrint(c * std::sqrt((r * r - dy * dy) * inv_r2));
+                j1 = std::max(c - dx, 0);
+                j2 = std::min(c + dx + 1, k);
+            }
+        }
+        for (int j = j1; j < j2; j++)
+            el.rows[i] |= 1u << j;
+    }
+    return el;
+}
+
 // ---- hot path -------------------------------------------------------------
 
 extern "C" int rslf_edge_confidence_pile(rslf_ctx* ctx, const rslf_volume* vol, int s, const rslf_params* p,
@@ -576,6 +610,17 @@ extern "C" int rslf_edge_confidence_pile(rslf_ctx* ctx, const rslf_volume* vol, 
     else
         hipLaunchKernelGGL(k1_edge_confidence<3>, grid, dim3(256), 0, ctx->stream, view_of(vol), s, ec, d_Ce_vu, d_Ce_mask_vu);
     HIP_TRY(hipGetLastError());
+    if (p->edge_confidence_opening_size > 1) {   // core.hpp:759-768
+        rc = ensure_plane_scratch(ctx, vol->V, vol->U);
+        if (rc)
+            return rc;
+        const MorphElement el = structuring_element(p->edge_confidence_opening_type, p->edge_confidence_opening_size);
+        uint8_t* tmp = reinterpret_cast<uint8_t*>(ctx->depth_tmp);   // V*U floats: room for a byte plane
+        hipLaunchKernelGGL(k1_morph_pass, grid, dim3(256), 0, ctx->stream, d_Ce_mask_vu, tmp, vol->V, vol->U, el, 0);   // erode
+        HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(k1_morph_pass, grid, dim3(256), 0, ctx->stream, tmp, d_Ce_mask_vu, vol->V, vol->U, el, 1);   // dilate
+        HIP_TRY(hipGetLastError());
+    }
     return RSLF_OK;
 }
 

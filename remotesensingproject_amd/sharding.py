@@ -67,8 +67,18 @@ class Shard:
         return slice(self.v0 - self.lo, self.v1 - self.lo)
 
 
-def make_shard(V: int, rank: int, world: int, median_filter_size: int = 5) -> Shard:
-    halo = (median_filter_size - 1) // 2          # core.hpp:686
+def halo_rows(median_filter_size: int = 5, opening_size: int = 1) -> int:
+    """Scanlines either side of a block that must be recomputed for the block's rows to come out exact: the
+    selective median reads +-(size-1)/2 rows (core.hpp:686), and those rows' masks depend, through the optional
+    opening (erosion then dilation, core.hpp:759-768), on +-2*(k/2) rows more."""
+    halo = (median_filter_size - 1) // 2
+    if opening_size > 1:
+        halo += 2 * (opening_size // 2)
+    return halo
+
+
+def make_shard(V: int, rank: int, world: int, median_filter_size: int = 5, opening_size: int = 1) -> Shard:
+    halo = halo_rows(median_filter_size, opening_size)
     v0, v1 = row_partition(V, world)[rank]
     return Shard(rank, world, V, v0, v1, max(0, v0 - halo), min(V, v1 + halo))
 
@@ -190,11 +200,11 @@ def gather_planes(planes: Dict[str, torch.Tensor], shard: Shard, U: int, C: int,
 
 
 def run_sharded(local_compute: Callable[[Shard], Dict[str, torch.Tensor]], V: int, U: int, C: int,
-                median_filter_size: int = 5, group=None) -> Optional[Dict[str, torch.Tensor]]:
+                median_filter_size: int = 5, group=None, opening_size: int = 1) -> Optional[Dict[str, torch.Tensor]]:
     """local_compute(shard) -> output planes for rows [shard.lo, shard.hi) (it must run the
     full K1+K2+K3 path on exactly those rows); returns the stitched planes on rank 0."""
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     world = dist.get_world_size(group) if dist.is_initialized() else 1
-    shard = make_shard(V, rank, world, median_filter_size)
+    shard = make_shard(V, rank, world, median_filter_size, opening_size)
     planes = local_compute(shard)
     return gather_planes(planes, shard, U, C, group)

@@ -253,6 +253,30 @@ def test_nothing_to_scan(rs, oracle_mod):
     assert not got["edge_mask"].any() and (got["depth_idx"] == -1).all()
 
 
+@pytest.mark.parametrize("shape,k", [(0, 3), (1, 3), (2, 3), (2, 5), (2, 4), (0, 2), (1, 7), (2, 9)])
+def test_morphological_opening_of_the_edge_mask(rs, oracle_mod, shape, k):
+    """par_edge_confidence_opening_size > 1 (core.hpp:759-768): cv::morphologyEx(MORPH_OPEN) with
+    getStructuringElement(type, Size(k, k)) on the V x U edge mask before the scan -- rectangle, cross and
+    ellipse, odd and even sizes; a blotchy field so that the opening removes some islands and keeps others."""
+    rng = np.random.default_rng(60 + 10 * shape + k)
+    V, S, U = 24, 5, 90
+    blobs = np.zeros((V, U), bool)                                # textured segments on a flat (C_e = 0) ground
+    for v in range(V):
+        for a in rng.integers(0, U - 10, size=2):
+            blobs[v, a:a + int(rng.integers(1, 10))] = True
+    blobs[2:V - 3, 8:30] = True                                   # and one block large enough to survive any element here
+    tex = rng.uniform(0.2, 1.0, size=(V, S, U, 1)).astype(np.float32)
+    vol = np.where(blobs[:, None, :, None], tex, np.float32(0.5)).astype(np.float32)
+    po = oracle_mod.default_params()
+    po.edge_confidence_opening_type, po.edge_confidence_opening_size = shape, k
+    pr = rs.Depth1DParameters(par_edge_confidence_opening_type=shape, par_edge_confidence_opening_size=k)
+    ref = oracle_mod.depth1d_pile_run(vol, -1.0, 1.0, 9, params=po)
+    plain = oracle_mod.depth1d_pile_run(vol, -1.0, 1.0, 9)
+    assert 0 < (ref.edge_mask > 0).sum() < (plain.edge_mask > 0).sum()    # the opening did remove pixels
+    comp, got = _run(rs, vol, -1.0, 1.0, 9, params=pr)
+    assert_pile_parity(got, ref, label="opening_%d_%d" % (shape, k))
+
+
 def test_negative_radiances_take_generic_path(rs, oracle_mod):
     """max(R,0) != R when the input goes negative (core.hpp:580): register scan must not run."""
     rng = np.random.default_rng(11)
@@ -421,8 +445,8 @@ def test_errors_do_not_throw_across_abi(rs):
     with pytest.raises(_lib.RslfError):
         rs.Depth1DComputer_pile(vol, -1.0, 1.0, 1).run()           # dim_d < 2
     with pytest.raises(_lib.RslfError) as e:
-        rs.Depth1DComputer_pile(vol, -1.0, 1.0, 8, parameters=rs.Depth1DParameters(par_edge_confidence_opening_size=3)).run()
-    assert e.value.status == -2
+        rs.Depth1DComputer_pile(vol, -1.0, 1.0, 8, parameters=rs.Depth1DParameters(par_edge_confidence_opening_size=33)).run()
+    assert e.value.status == -2                                    # structuring elements up to 31 x 31
     with pytest.raises(_lib.RslfError):
         rs.Volume(rs.default_context(), 2, 5, 70, 2)               # C = 2 unsupported
 
@@ -443,3 +467,29 @@ def test_randomised_campaign_subset(monkeypatch):
         c = fz.draw_case(rng)
         fz.run_case(i, c, rng)
     monkeypatch.delenv("RSLF_FORCE_SCAN", raising=False)
+
+
+def test_sharded_rows_with_opening_match_unsharded(rs, oracle_mod):
+    """Scanline sharding when the edge mask is opened (5x5 ellipse): the recomputed halo must cover the median's
+    2 rows plus twice the element's radius (sharding.halo_rows), then stitched shards equal the unsharded run."""
+    from remotesensingproject_amd import sharding
+    rng = np.random.default_rng(91)
+    V, S, U = 37, 5, 80
+    blobs = rng.uniform(size=(V, U)) < 0.08
+    for _ in range(3):                                            # grow the seeds into ragged patches
+        blobs = blobs | np.roll(blobs, 1, 0) | np.roll(blobs, 1, 1) | (np.roll(blobs, -1, 1) & (rng.uniform(size=(V, U)) < 0.7))
+    tex = rng.uniform(0.2, 1.0, size=(V, S, U, 1)).astype(np.float32)
+    vol = np.where(blobs[:, None, :, None], tex, np.float32(0.5)).astype(np.float32)
+    pr = rs.Depth1DParameters(par_edge_confidence_opening_type=2, par_edge_confidence_opening_size=5)
+    assert sharding.halo_rows(5, 5) == 6
+    whole, a = _run(rs, vol, -1.0, 1.0, 8, params=pr)
+    assert 0 < (a["edge_mask"] > 0).sum() < V * U
+    for world in (2, 3):
+        out = {k: np.zeros_like(x) for k, x in a.items()}
+        for r in range(world):
+            sh = sharding.make_shard(V, r, world, 5, 5)
+            cs, got = _run(rs, np.ascontiguousarray(vol[sh.rows]), -1.0, 1.0, 8, params=pr)
+            for k in out:
+                out[k][sh.v0:sh.v1] = got[k][sh.interior]
+        for k in a:
+            assert np.array_equal(out[k], a[k]), (world, k)

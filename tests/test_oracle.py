@@ -116,6 +116,60 @@ def test_degenerate_shapes_restatements_agree(oracle_mod, shape):
         assert set(np.unique(r.depth_idx)) <= {-1, 0}     # ties: cv::minMaxLoc keeps the first maximum
 
 
+def test_structuring_elements_and_opening(oracle_mod):
+    """cv::getStructuringElement as OpenCV 3.x builds it (the 5x5 ellipse is the documented
+    [[0,0,1,0,0],[1,1,1,1,1],[1,1,1,1,1],[1,1,1,1,1],[0,0,1,0,0]]), and the opening in both restatements."""
+    import ctypes as C
+    from oracle import oracle_np as onp
+    L = oracle_mod.lib()
+    el = np.zeros(25, np.uint8)
+    L.oracle_structuring_element(2, 5, el.ctypes.data_as(C.c_void_p))
+    want = np.array([[0, 0, 1, 0, 0], [1, 1, 1, 1, 1], [1, 1, 1, 1, 1], [1, 1, 1, 1, 1], [0, 0, 1, 0, 0]], np.uint8)
+    assert np.array_equal(el.reshape(5, 5), want)
+    assert np.array_equal(onp.structuring_element(2, 5).astype(np.uint8), want)
+    el3 = np.zeros(9, np.uint8)
+    L.oracle_structuring_element(1, 3, el3.ctypes.data_as(C.c_void_p))
+    assert np.array_equal(el3.reshape(3, 3), np.array([[0, 1, 0], [1, 1, 1], [0, 1, 0]], np.uint8))
+    rng = np.random.default_rng(5)
+    for shape in (0, 1, 2):
+        for k in (2, 3, 4, 5, 7, 9):
+            m = (rng.uniform(size=(17, 40)) < 0.7).astype(np.uint8) * 255
+            c = m.copy()
+            L.oracle_morph_open(c.ctypes.data_as(C.c_void_p), 17, 40, shape, k)
+            n = onp.morph_open(m, shape, k)
+            assert np.array_equal(c, n), (shape, k)
+            c2 = c.copy()
+            L.oracle_morph_open(c2.ctypes.data_as(C.c_void_p), 17, 40, shape, k)
+            if k % 2 == 1:                                  # symmetric element about its anchor:
+                assert (c <= m).all()                       #   an opening never adds pixels
+                assert np.array_equal(c2, c), (shape, k)    #   and is idempotent
+            # even sizes: the anchor k/2 is off centre and erosion and dilation use the same offsets (OpenCV's
+            # MorphFilter does not reflect the element), so the "opening" also shifts by one pixel
+
+
+@pytest.mark.parametrize("shape,k", [(2, 3), (0, 4), (1, 5)])
+def test_opening_in_the_pile_restatements_agree(oracle_mod, shape, k):
+    from oracle import oracle_np as onp
+    rng = np.random.default_rng(8 + k)
+    V, S, U = 10, 5, 60
+    blobs = np.zeros((V, U), bool)                               # textured segments on a flat (C_e = 0) ground
+    for v in range(V):
+        for a in rng.integers(0, U - 10, size=2):
+            blobs[v, a:a + int(rng.integers(1, 10))] = True
+    blobs[2:V - 3, 8:30] = True                                   # and one block large enough to survive any element here
+    tex = rng.uniform(0.2, 1.0, size=(V, S, U, 1)).astype(np.float32)
+    vol = np.where(blobs[:, None, :, None], tex, np.float32(0.5)).astype(np.float32)
+    pc = oracle_mod.default_params()
+    pc.edge_confidence_opening_type, pc.edge_confidence_opening_size = shape, k
+    pn = onp.default_params()
+    pn["edge_confidence_opening_type"], pn["edge_confidence_opening_size"] = shape, k
+    r = oracle_mod.depth1d_pile_run(vol, -1.0, 1.0, 7, params=pc)
+    n = onp.depth1d_pile_run(vol, np.float32(-1.0), np.float32(1.0), 7, p=pn)
+    for ko, kn in (("edge_confidence", "Ce"), ("edge_mask", "Ce_mask"), ("depth_idx", "idx"), ("score", "score"),
+                   ("depth_raw", "depth_raw"), ("rbar", "rbar"), ("disp_confidence", "Cd"), ("depth", "depth")):
+        assert np.array_equal(getattr(r, ko), n[kn]), (shape, k, ko)
+
+
 def test_analytic_known_answer(oracle_mod):
     """Independent of every OpenCV-semantics assumption: integer true disparity on the grid =>
     all samples of the true line are identical => K == 1, score == 1.0 exactly, argmax known."""

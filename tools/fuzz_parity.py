@@ -50,6 +50,7 @@ def draw_case(rng):
                 thr=float(rng.choice([0.02, 0.02, 0.0, 0.2])), raw_thr=float(rng.choice([0.0, 0.0, 0.3])),
                 median=int(rng.choice([5, 5, 3, 7, 1])), shadows=bool(rng.uniform() < 0.8),
                 negative=bool(rng.uniform() < 0.1), interp=int(rng.choice([0, 0, 0, 0, 1, 2])),
+                opening=(int(rng.choice([0, 1, 2])), int(rng.choice([2, 3, 4, 5, 7]))) if rng.uniform() < 0.15 else (2, 1),
                 # how the light field reaches the device: dense device tensor, host EPIs (f32, scale 1), host EPIs
                 # normalised by their max (dc.hpp:442-460), uint8 EPIs (x/255, dc.hpp:470), uint8 image stack (io.cpp:194-227)
                 form=str(rng.choice(["dense", "dense", "epis_f32", "epis_max", "epis_u8", "images_u8"])))
@@ -89,6 +90,8 @@ def run_case(i, c, rng):
         setattr(pr, "par_" + name, val)
     po.interpolation = c["interp"]
     pr.par_interpolation_class = c["interp"]
+    po.edge_confidence_opening_type, po.edge_confidence_opening_size = c["opening"]
+    pr.par_edge_confidence_opening_type, pr.par_edge_confidence_opening_size = c["opening"]
     s_hat = c["s_hat"]
     if not (c["planes"] or c["mask"]):
         form = c["form"] if not c["negative"] else "dense"
