@@ -197,6 +197,16 @@ int rslf_depth1d_run(rslf_ctx* ctx, const rslf_volume* vol, float dmin, float dm
                      float* d_Ce_vu, uint8_t* d_Ce_mask_vu, float* d_Cd_vu, float* d_depth_vu,
                      float* d_rbar_vu, int32_t* d_idx_vu, float* d_score_vu, rslf_stats* stats);
 
+/* The optional last argument of compute_1D_depth_epi / _pile (a_K_r_m_rbar_(v_)s_u, core.hpp:266, :309; written at
+ * :647-651): for every pixel that received a disparity, K(r - rbar)[:, d*] of its winning hypothesis, i.e. the
+ * kernel values of the last mean-shift pass over the S views.  d_idx_vu is the arg-max plane a scan produced
+ * (rslf_depth_epi_scan / rslf_depth_epi_pile with the same volume, ranges, dim_d, s_hat and parameters);
+ * d_K_vsu is [V][S][U] (the reference's Vec<Mat> of V mats S x U).  Pixels with idx < 0 are left untouched, as
+ * the reference leaves them.  Costs 1/dim_d of a scan. */
+int rslf_kernel_columns_pile(rslf_ctx* ctx, const rslf_volume* vol, const float* d_dmin_vu, const float* d_dmax_vu,
+                             float dmin, float dmax, int dim_d, int s_hat, const rslf_params* p,
+                             const int32_t* d_idx_vu, float* d_K_vsu);
+
 /* rslf::selective_median_filter -- core.hpp:366-375, impl :663-718.
  * d_dst_vu must not alias d_src_vu; it is fully written (0 where mask is 0). */
 int rslf_selective_median(rslf_ctx* ctx, const rslf_volume* vol, const float* d_src_vu, float* d_dst_vu,

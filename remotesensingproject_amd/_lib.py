@@ -26,7 +26,7 @@ SYMBOLS = [
     "rslf_edge_confidence_2d", "rslf_depth_epi_2d", "rslf_depth2d_run",
     "rslf_depth_epi_scan", "rslf_depth1d_run",
     "rslf_f2c_level_dims", "rslf_downsample_epis_f32", "rslf_device_max_f32", "rslf_f2c_tighten_bounds", "rslf_f2c_fuse",
-    "rslf_depth2d_run_host", "rslf_fine_to_coarse_run_host",
+    "rslf_depth2d_run_host", "rslf_fine_to_coarse_run_host", "rslf_kernel_columns_pile",
 ]
 
 
@@ -133,6 +133,7 @@ def lib():
                                         C.POINTER(RslfStats)]
     L.rslf_depth1d_pile_run_host.argtypes = L.rslf_depth1d_pile_run.argtypes
     L.rslf_last_scan_kernel_ms.argtypes = [vp, C.POINTER(cf)]
+    L.rslf_kernel_columns_pile.argtypes = [vp, vp, vp, vp, cf, cf, ci, ci, C.POINTER(RslfParams), vp, vp]
     L.rslf_depth2d_run_host.argtypes = [vp, vp, cf, cf, ci, C.POINTER(RslfParams), vp, vp, vp, vp, vp, C.POINTER(RslfStats)]
     L.rslf_fine_to_coarse_run_host.argtypes = [vp, C.POINTER(vp), ci, ci, ci, ci, ci, C.c_size_t, cf, cf, ci, cf, C.POINTER(RslfParams),
                                                ci, ci, vp, vp, C.POINTER(ci), C.POINTER(RslfStats)]

@@ -289,8 +289,11 @@ __global__ __launch_bounds__(64) void k2_scan_combine(ScanArgs a)
 // kept between mean-shift passes: every pass re-gathers its samples from the
 // slab (L1/L2 hits).  ~3x the instructions of the register variant.
 // ---------------------------------------------------------------------------
+// `Kcol` (nullable): where K(r - rbar) of the LAST pass goes, element s at Kcol[s * kstride] -- the optional
+// K_r_m_rbar column of core.hpp:647-651, filled by k2_kernel_column for one hypothesis per pixel.
 template <int C>
-__device__ __forceinline__ void scan_generic_body(const ScanArgs& a, int v, int u, int d0, int d1, Best<C>& best)
+__device__ __forceinline__ void scan_generic_body(const ScanArgs& a, int v, int u, int d0, int d1, Best<C>& best,
+                                                  float* __restrict__ Kcol = nullptr, long long kstride = 0)
 {
     const VolView& vol = a.vol;
     const float* epi = vol.row(v, 0, 0);
@@ -379,6 +382,8 @@ __device__ __forceinline__ void scan_generic_body(const ScanArgs& a, int v, int 
                 }
                 B = B + K;
                 card = card + (valid ? 1.0f : 0.0f);
+                if (Kcol && it == a.k.n_iter - 1)
+                    Kcol[(long long)s * kstride] = K;              // core.hpp:650
             }
 #pragma unroll
             for (int c = 0; c < C; c++) {
@@ -436,6 +441,26 @@ template <int C>
 __global__ __launch_bounds__(64 * kScanWaves) void k2_scan_generic(ScanArgs a)
 {
     RSLF_SCAN_KERNEL_BODY((scan_generic_body<C>(a, v, u, d0, d1, best)), (scan_generic_body<C>(a, v, u, d0, d1, best)))
+}
+
+// The optional last output of compute_1D_depth_epi (core.hpp:266, :647-651): for every pixel that received a
+// disparity, the column K(r - rbar)[:, d*] of its winning hypothesis, S values.  One thread per pixel re-runs
+// that ONE hypothesis with the generic arithmetic (the same operations as every scan variant, so the same
+// bits) and stores the last pass's K; 1/D of the scan's work.  Pixels without a disparity are left untouched,
+// as in the reference.  K_vsu is [V][S][U].
+template <int C>
+__global__ __launch_bounds__(256) void k2_kernel_column(ScanArgs a, const int32_t* __restrict__ idx_vu, float* __restrict__ K_vsu)
+{
+    const int v = blockIdx.y;
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= a.vol.U)
+        return;
+    const int d = idx_vu[(long long)v * a.vol.U + u];
+    if (d < 0)
+        return;
+    Best<C> best;
+    best.init();
+    scan_generic_body<C>(a, v, u, d, d + 1, best, K_vsu + (long long)v * a.vol.S * a.vol.U + u, (long long)a.vol.U);
 }
 
 // ---------------------------------------------------------------------------

@@ -870,6 +870,43 @@ extern "C" int rslf_depth_epi_scan(rslf_ctx* ctx, const rslf_volume* vol, const 
     return RSLF_OK;
 }
 
+extern "C" int rslf_kernel_columns_pile(rslf_ctx* ctx, const rslf_volume* vol, const float* d_dmin_vu, const float* d_dmax_vu,
+                                        float dmin, float dmax, int dim_d, int s_hat, const rslf_params* p,
+                                        const int32_t* d_idx_vu, float* d_K_vsu)
+{
+    if (!ctx || !vol || !d_idx_vu || !d_K_vsu)
+        return fail(RSLF_ERR_INVALID_ARG, "NULL argument");
+    int rc = check_params(p);
+    if (rc)
+        return rc;
+    if ((d_dmin_vu == nullptr) != (d_dmax_vu == nullptr))
+        return fail(RSLF_ERR_INVALID_ARG, "d_dmin_vu and d_dmax_vu must both be given or both be NULL");
+    if (dim_d < 2)
+        return fail(RSLF_ERR_INVALID_ARG, "dim_d=%d: the hypothesis grid divides by dim_d-1 (core.hpp:548)", dim_d);
+    if (s_hat < 0 || s_hat >= vol->S)
+        return fail(RSLF_ERR_INVALID_ARG, "s_hat=%d outside [0,%d)", s_hat, vol->S);
+    if (!vol->filled)
+        return fail(RSLF_ERR_INVALID_ARG, "volume has not been filled");
+    HIP_TRY(hipSetDevice(ctx->device));
+    ScanArgs a = {};
+    a.vol = view_of(vol);
+    a.dmin_vu = d_dmin_vu;
+    a.dmax_vu = d_dmax_vu;
+    a.dmin = dmin;
+    a.dmax = dmax;
+    a.dim_d = dim_d;
+    a.s_hat = s_hat;
+    a.k = make_scan_consts(p);
+    a.groups = 1;
+    const dim3 grid((vol->U + 255) / 256, vol->V);
+    if (vol->C == 1)
+        hipLaunchKernelGGL(k2_kernel_column<1>, grid, dim3(256), 0, ctx->stream, a, d_idx_vu, d_K_vsu);
+    else
+        hipLaunchKernelGGL(k2_kernel_column<3>, grid, dim3(256), 0, ctx->stream, a, d_idx_vu, d_K_vsu);
+    HIP_TRY(hipGetLastError());
+    return RSLF_OK;
+}
+
 extern "C" int rslf_depth_epi_pile(rslf_ctx* ctx, const rslf_volume* vol, const float* d_dmin_vu, const float* d_dmax_vu,
                                    float dmin, float dmax, int dim_d, int s_hat, float* d_Ce_vu, uint8_t* d_Ce_mask_vu,
                                    float* d_Cd_vu, float* d_depth_vu, float* d_rbar_vu, const rslf_params* p,

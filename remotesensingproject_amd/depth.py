@@ -261,20 +261,29 @@ def compute_1D_depth_epi_pile(vol: Volume, a_dmin_v_u, a_dmax_v_u, a_dim_d: int,
                               a_rbar_v_u: torch.Tensor, a_parameters: Depth1DParameters | None = None,
                               a_mask_v_u: torch.Tensor | None = None, *, idx_v_u: torch.Tensor | None = None,
                               score_v_u: torch.Tensor | None = None, depth_raw_v_u: torch.Tensor | None = None,
-                              want_stats: bool = False) -> RslfStats | None:
+                              want_stats: bool = False, a_K_r_m_rbar_v_s_u: torch.Tensor | None = None) -> RslfStats | None:
     """core.hpp:293-310.  a_dmin_v_u / a_dmax_v_u are [V,U] f32 CUDA tensors or
     Python floats (the constant planes of dc.hpp:486-487).  All planes are
-    updated in place; a_best_depth_v_u ends as the selective median (core.hpp:892)."""
+    updated in place; a_best_depth_v_u ends as the selective median (core.hpp:892).
+    a_K_r_m_rbar_v_s_u ([V,S,U] f32, the reference's optional last argument, core.hpp:309): receives
+    K(r - rbar)[:, d*] for every pixel that got a disparity (core.hpp:647-651)."""
     p = (a_parameters or Depth1DParameters()).to_c()
     planes = isinstance(a_dmin_v_u, torch.Tensor)
     st = RslfStats() if want_stats else None
     vol.ctx.use_current_stream()
+    if a_K_r_m_rbar_v_s_u is not None and idx_v_u is None:
+        idx_v_u = torch.empty((vol.V, vol.U), dtype=torch.int32, device=a_best_depth_v_u.device)
     check(_lib.lib().rslf_depth_epi_pile(
         vol.ctx._h, vol._h, _ptr(a_dmin_v_u if planes else None), _ptr(a_dmax_v_u if planes else None),
         0.0 if planes else float(a_dmin_v_u), 0.0 if planes else float(a_dmax_v_u), a_dim_d, a_s_hat,
         _ptr(a_edge_confidence_v_u), _ptr(a_edge_confidence_mask_v_u), _ptr(a_disp_confidence_v_u),
         _ptr(a_best_depth_v_u), _ptr(a_rbar_v_u), C.byref(p), _ptr(a_mask_v_u), _ptr(idx_v_u), _ptr(score_v_u),
         _ptr(depth_raw_v_u), C.byref(st) if st is not None else None), "rslf_depth_epi_pile")
+    if a_K_r_m_rbar_v_s_u is not None:
+        check(_lib.lib().rslf_kernel_columns_pile(
+            vol.ctx._h, vol._h, _ptr(a_dmin_v_u if planes else None), _ptr(a_dmax_v_u if planes else None),
+            0.0 if planes else float(a_dmin_v_u), 0.0 if planes else float(a_dmax_v_u), a_dim_d, a_s_hat, C.byref(p),
+            _ptr(idx_v_u), _ptr(a_K_r_m_rbar_v_s_u)), "rslf_kernel_columns_pile")
     return st
 
 

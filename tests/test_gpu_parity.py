@@ -493,3 +493,47 @@ def test_sharded_rows_with_opening_match_unsharded(rs, oracle_mod):
                 out[k][sh.v0:sh.v1] = got[k][sh.interior]
         for k in a:
             assert np.array_equal(out[k], a[k]), (world, k)
+
+
+@pytest.mark.parametrize("C_,S,U,planes,mode", [(1, 9, 70, False, 0), (3, 7, 90, True, 0), (1, 33, 130, True, 0), (1, 11, 80, False, 1)])
+def test_kernel_columns_output(rs, oracle_mod, C_, S, U, planes, mode):
+    """The optional last argument of compute_1D_depth_epi_pile (a_K_r_m_rbar_v_s_u, core.hpp:309, :647-651):
+    K(r - rbar)[:, d*] of every pixel that received a disparity, bit-identical to the oracle; pixels without a
+    disparity keep what the caller's buffer held."""
+    import torch
+    rng = np.random.default_rng(70 + S)
+    V, D = 4, 14
+    vol = rng.uniform(0.0, 1.0, size=(V, S, U, C_)).astype(np.float32)
+    vol[1, :, 20:50] = 0.5                                        # a flat stretch: those pixels get no disparity
+    if planes:
+        dmin = rng.uniform(-2.0, 0.0, size=(V, U)).astype(np.float32)
+        dmax = (dmin + rng.uniform(0.0, 3.0, size=(V, U))).astype(np.float32)
+    else:
+        dmin = np.full((V, U), -1.0, np.float32)
+        dmax = np.full((V, U), 2.0, np.float32)
+    po = oracle_mod.default_params()
+    po.interpolation = mode
+    pr = rs.Depth1DParameters()
+    pr.par_interpolation_class = mode
+    s_hat = S // 2
+    Ce, cm = oracle_mod.edge_confidence_pile(vol, s_hat, params=po)
+    want = np.full((V, S, U), -7.0, np.float32)
+    idx_ref = np.full((V, U), -1, np.int32)
+    for v in range(V):
+        r = oracle_mod.depth_epi(vol[v], dmin[v], dmax[v], D, s_hat, Ce[v], cm[v], params=po, want_K=True)
+        got_d = r["idx"] >= 0
+        want[v][:, got_d] = r["K"][:, got_d]
+        idx_ref[v] = r["idx"]
+    assert (idx_ref < 0).any() and (idx_ref >= 0).any()
+    dev = "cuda"
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a).copy()).to(dev)
+    vd = rs.Volume.from_dense(vol)
+    tCe, tcm = t(Ce), t(cm)
+    tCd = torch.zeros((V, U), device=dev); tdepth = torch.zeros((V, U), device=dev); trbar = torch.zeros((V, U, C_), device=dev)
+    tK = torch.full((V, S, U), -7.0, device=dev)
+    rs.compute_1D_depth_epi_pile(vd, t(dmin) if planes else -1.0, t(dmax) if planes else 2.0, D, s_hat, tCe, tcm, tCd, tdepth, trbar,
+                                 pr, None, a_K_r_m_rbar_v_s_u=tK)
+    torch.cuda.synchronize()
+    got = tK.cpu().numpy()
+    assert np.array_equal(got, want)
+    assert ((got >= 0.0) & (got <= 1.0) | (got == -7.0)).all()
