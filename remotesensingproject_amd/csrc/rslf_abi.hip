@@ -1133,8 +1133,8 @@ extern "C" int rslf_depth_epi_2d(rslf_ctx* ctx, const rslf_volume* vol, const fl
     bool first_visit = true;
     for (int s_hat : order) {
         // After the centre view, propagation has explained most pixels: a visit scans a few per scanline.
-        // Pack them into one list and share each tile's hypotheses out over 8 workgroups (k2_scan.hpp).
-        ctx->scan_groups = first_visit ? 1 : 8;
+        // Pack them into one list and share each tile's hypotheses out over up to 16 workgroups (k2_scan.hpp).
+        ctx->scan_groups = first_visit ? 1 : 16;
         ctx->scan_packed = !first_visit;
         first_visit = false;
         float* depth = d_depth_svu + (size_t)s_hat * n;
