@@ -5,8 +5,9 @@
 // the window pixels that are also in the mask and whose radiance at s_hat is
 // within epsilon (norm<>, src/rslf_types.cpp:80-91) of the centre's; 0 elsewhere
 // (core.hpp:678-679).  One thread per pixel; candidates are parked in LDS
-// ([slot][thread], conflict-free) and ranked by counting -- value-deterministic
-// like std::nth_element (core.hpp:713).  Reads rows v-w..v+w, so it runs as its
+// ([slot][thread], conflict-free; size*size*1 KiB of dynamic LDS per block, so
+// the default 5x5 window leaves room for six blocks per CU) and ranked by
+// counting -- value-deterministic like std::nth_element (core.hpp:713).  Reads rows v-w..v+w, so it runs as its
 // own launch after K2 (a <2 us boundary).
 #pragma once
 
@@ -21,7 +22,8 @@ __global__ __launch_bounds__(256) void k3_selective_median(VolView vol, const fl
                                                           float* __restrict__ dst, const uint8_t* __restrict__ mask,
                                                           int s_hat, int size, float eps)
 {
-    __shared__ float cand[kMedianMaxSize * kMedianMaxSize][256];
+    extern __shared__ __attribute__((aligned(16))) float s_median_cand[];   // [size*size][256]
+    float (*cand)[256] = reinterpret_cast<float (*)[256]>(s_median_cand);
     const int v = blockIdx.y;
     const int u = blockIdx.x * blockDim.x + threadIdx.x;
     if (u >= vol.U)

@@ -637,11 +637,12 @@ extern "C" int rslf_selective_median(rslf_ctx* ctx, const rslf_volume* vol, cons
         return fail(RSLF_ERR_INVALID_ARG, "s_hat=%d outside [0,%d)", s_hat, vol->S);
     HIP_TRY(hipSetDevice(ctx->device));
     const dim3 grid((vol->U + 255) / 256, vol->V);
+    const size_t lds = (size_t)size * size * 256 * sizeof(float);   // one candidate slot per window pixel and thread
     if (vol->C == 1)
-        hipLaunchKernelGGL(k3_selective_median<1>, grid, dim3(256), 0, ctx->stream, view_of(vol), d_src_vu, d_dst_vu, d_mask_vu,
+        hipLaunchKernelGGL(k3_selective_median<1>, grid, dim3(256), lds, ctx->stream, view_of(vol), d_src_vu, d_dst_vu, d_mask_vu,
                            s_hat, size, epsilon);
     else
-        hipLaunchKernelGGL(k3_selective_median<3>, grid, dim3(256), 0, ctx->stream, view_of(vol), d_src_vu, d_dst_vu, d_mask_vu,
+        hipLaunchKernelGGL(k3_selective_median<3>, grid, dim3(256), lds, ctx->stream, view_of(vol), d_src_vu, d_dst_vu, d_mask_vu,
                            s_hat, size, epsilon);
     HIP_TRY(hipGetLastError());
     return RSLF_OK;
