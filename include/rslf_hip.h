@@ -273,7 +273,8 @@ int rslf_f2c_level_dims(int V, int U, int* V2, int* U2);
 int rslf_downsample_epis_f32(rslf_ctx* ctx, const float* d_in_vsuc, int V, int S, int U, int C, float* d_out_vsuc);
 /* max over a device buffer: the per-level epi_scale_factor of Depth2DComputer's constructor
  * (include/rslf_depth_computation.hpp:671-690).  Synchronises. */
-int rslf_device_max_f32(rslf_ctx* ctx, const float* d_values, size_t n, float* h_max);
+int rslf_device_max_f32(rslf_ctx* ctx, const float* d_values, size_t n, float* h_max);   /* returns the value: waits */
+/* The three helpers below enqueue on the context's stream and return, like every device entry point. */
 /* FineToCoarse::run(), bound tightening -- include/rslf_fine_to_coarse.hpp:171-299: d_dmin/d_dmax of
  * the coarser level ([S][V_down][U_down], in/out) from the finer level's disparities and validity. */
 int rslf_f2c_tighten_bounds(rslf_ctx* ctx, const float* d_depth_up_svu, const uint8_t* d_valid_up_svu, int S, int V_up,

@@ -73,6 +73,11 @@ struct rslf_ctx {
     float* filtered = nullptr;    // [V][U] median of the visited view, the propagation's source
     size_t sweep_cap = 0;         // entries winner / sweep_mask can hold (S*V*U)
     size_t sweep_plane_cap = 0;   // floats `filtered` can hold (V*U)
+    // grow-only scratch of the once-per-level helpers (pyramid, tightening, fusion): reused across calls, so
+    // these helpers neither allocate nor free -- and so never force a device-wide synchronisation
+    static constexpr int kHelperSlots = 4;
+    void* helper[kHelperSlots] = {nullptr, nullptr, nullptr, nullptr};
+    size_t helper_cap[kHelperSlots] = {0, 0, 0, 0};
 };
 
 struct rslf_volume {
@@ -263,6 +268,8 @@ extern "C" int rslf_ctx_destroy(rslf_ctx* ctx)
     (void)hipFree(ctx->minmax);
     (void)hipFree(ctx->staging);
     (void)hipFree(ctx->scan_partial);
+    for (int i = 0; i < rslf_ctx::kHelperSlots; i++)
+        (void)hipFree(ctx->helper[i]);
     (void)hipFree(ctx->winner);
     (void)hipFree(ctx->sweep_mask);
     (void)hipFree(ctx->filtered);
@@ -380,11 +387,32 @@ static int ensure_staging(rslf_ctx* ctx, size_t bytes)
     return RSLF_OK;
 }
 
+// Helper scratch slot `slot`, at least `bytes` large.  Growing it frees the old buffer, which waits for the
+// device; after the first call of a given size nothing is allocated any more.
+static int helper_scratch(rslf_ctx* ctx, int slot, size_t bytes, void** out)
+{
+    if (bytes > ctx->helper_cap[slot]) {
+        if (ctx->helper[slot])
+            HIP_TRY(hipFree(ctx->helper[slot]));
+        ctx->helper[slot] = nullptr;
+        ctx->helper_cap[slot] = 0;
+        HIP_TRY(hipMalloc(&ctx->helper[slot], bytes));
+        ctx->helper_cap[slot] = bytes;
+    }
+    *out = ctx->helper[slot];
+    return RSLF_OK;
+}
+
+__global__ void k_init_minmax(float* minmax)
+{
+    minmax[0] = INFINITY;
+    minmax[1] = -INFINITY;
+}
+
 static int minmax_begin(rslf_ctx* ctx)
 {
-    const float init[2] = {INFINITY, -INFINITY};
-    HIP_TRY(hipMemcpyAsync(ctx->minmax, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));   // `init` is a stack temporary
+    hipLaunchKernelGGL(k_init_minmax, dim3(1), dim3(1), 0, ctx->stream, ctx->minmax);
+    HIP_TRY(hipGetLastError());
     return RSLF_OK;
 }
 
@@ -1235,19 +1263,20 @@ extern "C" int rslf_downsample_epis_f32(rslf_ctx* ctx, const float* d_in_vsuc, i
     rslf_f2c_level_dims(V, U, &V2, &U2);
     if (V2 < 1 || U2 < 1)
         return fail(RSLF_ERR_INVALID_ARG, "level too small to halve");
-    DevBuf tmp;
-    HIP_TRY(tmp.alloc((size_t)V * S * U * C * sizeof(float)));
+    void* tmp_p = nullptr;
+    int rc = helper_scratch(ctx, 0, (size_t)V * S * U * C * sizeof(float), &tmp_p);
+    if (rc)
+        return rc;
     hipStream_t st = ctx->stream;
     const long long row_blocks = (long long)V * S * ((U * C + 255) / 256);
     if (row_blocks > (1ll << 31) - 1)
         return fail(RSLF_ERR_UNSUPPORTED, "volume too large for one downsampling launch");
-    hipLaunchKernelGGL(k5_gauss_rows, dim3((unsigned)row_blocks), dim3(256), 0, st, d_in_vsuc, (float*)tmp.p, (long long)V * S, U, C);
+    hipLaunchKernelGGL(k5_gauss_rows, dim3((unsigned)row_blocks), dim3(256), 0, st, d_in_vsuc, (float*)tmp_p, (long long)V * S, U, C);
     HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(k5_gauss_cols_halve, dim3((U2 * C + 255) / 256, S, V2), dim3(256), 0, st, (const float*)tmp.p, d_out_vsuc,
+    hipLaunchKernelGGL(k5_gauss_cols_halve, dim3((U2 * C + 255) / 256, S, V2), dim3(256), 0, st, (const float*)tmp_p, d_out_vsuc,
                        V, S, U, C, V2, U2);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(st));   // tmp is released on return
-    return RSLF_OK;
+    return RSLF_OK;   // enqueued on the context's stream like every device entry point
 }
 
 extern "C" int rslf_device_max_f32(rslf_ctx* ctx, const float* d_values, size_t n, float* h_max)
@@ -1256,12 +1285,14 @@ extern "C" int rslf_device_max_f32(rslf_ctx* ctx, const float* d_values, size_t 
         return fail(RSLF_ERR_INVALID_ARG, "bad arguments");
     HIP_TRY(hipSetDevice(ctx->device));
     const int blocks = (int)std::min<size_t>((n + 255) / 256, 2048);
-    DevBuf part;
-    HIP_TRY(part.alloc((size_t)blocks * sizeof(float)));
-    hipLaunchKernelGGL(k5_max_partial, dim3(blocks), dim3(256), 0, ctx->stream, d_values, (long long)n, (float*)part.p);
+    void* part_p = nullptr;
+    int rc = helper_scratch(ctx, 1, (size_t)2048 * sizeof(float), &part_p);
+    if (rc)
+        return rc;
+    hipLaunchKernelGGL(k5_max_partial, dim3(blocks), dim3(256), 0, ctx->stream, d_values, (long long)n, (float*)part_p);
     HIP_TRY(hipGetLastError());
     std::vector<float> h(blocks);
-    HIP_TRY(hipMemcpyAsync(h.data(), part.p, (size_t)blocks * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(h.data(), part_p, (size_t)blocks * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     float m = h[0];
     for (int i = 1; i < blocks; i++)
@@ -1278,19 +1309,21 @@ extern "C" int rslf_f2c_tighten_bounds(rslf_ctx* ctx, const float* d_depth_up_sv
         return fail(RSLF_ERR_INVALID_ARG, "bad arguments");
     HIP_TRY(hipSetDevice(ctx->device));
     const size_t n_up = (size_t)S * V_up * U_up;
-    DevBuf left, right;
-    HIP_TRY(left.alloc(n_up * sizeof(int)));
-    HIP_TRY(right.alloc(n_up * sizeof(int)));
+    void *left_p = nullptr, *right_p = nullptr;
+    int rc = helper_scratch(ctx, 2, n_up * sizeof(int), &left_p);
+    if (!rc)
+        rc = helper_scratch(ctx, 3, n_up * sizeof(int), &right_p);
+    if (rc)
+        return rc;
     hipStream_t st = ctx->stream;
     const long long rows = (long long)S * V_up;
     hipLaunchKernelGGL(k5_nearest_valid, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, st, d_valid_up_svu, rows, U_up,
-                       (int*)left.p, (int*)right.p);
+                       (int*)left_p, (int*)right_p);
     HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(k5_tighten, dim3((U_down + 255) / 256, V_down, S), dim3(256), 0, st, d_depth_up_svu, (const int*)left.p,
-                       (const int*)right.p, S, V_up, U_up, d_dmin_down_svu, d_dmax_down_svu, V_down, U_down);
+    hipLaunchKernelGGL(k5_tighten, dim3((U_down + 255) / 256, V_down, S), dim3(256), 0, st, d_depth_up_svu, (const int*)left_p,
+                       (const int*)right_p, S, V_up, U_up, d_dmin_down_svu, d_dmax_down_svu, V_down, U_down);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(st));
-    return RSLF_OK;
+    return RSLF_OK;   // enqueued, not awaited
 }
 
 extern "C" int rslf_f2c_fuse(rslf_ctx* ctx, const float* const* d_disp, const uint8_t* const* d_valid, const int* Vp, const int* Up,
@@ -1302,15 +1335,20 @@ extern "C" int rslf_f2c_fuse(rslf_ctx* ctx, const float* const* d_disp, const ui
     hipStream_t st = ctx->stream;
     const size_t n0 = (size_t)S * Vp[0] * Up[0];
     // two ping-pong buffers at the finest size hold the running map / mask of every step
-    DevBuf mapA, mapB, mskA, mskB;
-    HIP_TRY(mapA.alloc(n0 * sizeof(float)));
-    HIP_TRY(mapB.alloc(n0 * sizeof(float)));
-    HIP_TRY(mskA.alloc(n0));
-    HIP_TRY(mskB.alloc(n0));
-    float* map_down = (float*)mapA.p;
-    float* map_next = (float*)mapB.p;
-    uint8_t* msk_down = (uint8_t*)mskA.p;
-    uint8_t* msk_next = (uint8_t*)mskB.p;
+    void *mapA = nullptr, *mapB = nullptr, *mskA = nullptr, *mskB = nullptr;
+    int rc = helper_scratch(ctx, 0, n0 * sizeof(float), &mapA);
+    if (!rc)
+        rc = helper_scratch(ctx, 2, n0 * sizeof(float), &mapB);
+    if (!rc)
+        rc = helper_scratch(ctx, 1, std::max<size_t>(n0, 2048 * sizeof(float)), &mskA);
+    if (!rc)
+        rc = helper_scratch(ctx, 3, n0, &mskB);
+    if (rc)
+        return rc;
+    float* map_down = (float*)mapA;
+    float* map_next = (float*)mapB;
+    uint8_t* msk_down = (uint8_t*)mskA;
+    uint8_t* msk_next = (uint8_t*)mskB;
     const size_t nl = (size_t)S * Vp[P - 1] * Up[P - 1];
     HIP_TRY(hipMemcpyAsync(map_down, d_disp[P - 1], nl * sizeof(float), hipMemcpyDeviceToDevice, st));
     HIP_TRY(hipMemcpyAsync(msk_down, d_valid[P - 1], nl, hipMemcpyDeviceToDevice, st));
@@ -1325,8 +1363,7 @@ extern "C" int rslf_f2c_fuse(rslf_ctx* ctx, const float* const* d_disp, const ui
     hipLaunchKernelGGL(k5_median3, dim3((Up[0] + 255) / 256, Vp[0], S), dim3(256), 0, st, map_down, d_out_map_svu, Vp[0], Up[0]);   // :127
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(d_out_valid_svu, msk_down, n0, hipMemcpyDeviceToDevice, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    return RSLF_OK;
+    return RSLF_OK;   // enqueued, not awaited
 }
 
 // ---- host-pointer forms of the rows around the path -----------------------------
