@@ -83,6 +83,11 @@ def test_partition_and_halo():
     # more ranks than rows: empty blocks are legal
     parts = sharding.row_partition(2, 4)
     assert parts == [(0, 1), (1, 2), (2, 2), (2, 2)]
+    # an opened edge mask widens the halo by twice the element radius (erosion, then dilation)
+    assert sharding.halo_rows(5, 1) == 2 and sharding.halo_rows(5, 3) == 4 and sharding.halo_rows(5, 5) == 6
+    assert sharding.halo_rows(7, 4) == 3 + 4 and sharding.halo_rows(1, 1) == 0
+    so = sharding.make_shard(1080, 3, 8, 5, 5)
+    assert (so.v0, so.v1, so.lo, so.hi) == (405, 540, 399, 546) and so.interior == slice(6, 141)
 
 
 def test_pack_unpack_roundtrip():
