@@ -125,8 +125,9 @@ int rslf_ctx_synchronize(rslf_ctx* ctx);
 /* include/rslf_depth_computation.hpp:425-477: the constructor copies the
  * caller's Vec<Mat> of V EPIs (each S x U, C channels interleaved) into float
  * Mats scaled to [0,1].  Here the copy lands in one HBM slab laid out
- * [V][S][C][pitch] (channel-planar rows, so a wavefront reading 64 consecutive
- * u of one row touches 2-3 cache lines). */
+ * [V][S][pitch][C]: one zero-padded row of `pitch` pixels per (EPI, view), channels
+ * interleaved like the reference's Mat rows, so the two lerp taps of a sample, all
+ * channels, are 2*C consecutive floats. */
 int rslf_volume_create(rslf_ctx* ctx, int V, int S, int U, int C, rslf_volume** out);
 int rslf_volume_destroy(rslf_volume* vol);
 int rslf_volume_describe(const rslf_volume* vol, rslf_volume_desc* out);

@@ -12,6 +12,7 @@ namespace rslf {
 // Replaces Depth1DComputer_pile's constructor copy/convertTo
 // (include/rslf_depth_computation.hpp:463-477) and, for the image-major source,
 // rslf::build_epis_from_imgs (src/rslf_io.cpp:194-227).
+// The slab row of (v, s) is pitch pixels x C interleaved channels (rslf_device.hpp).
 //   EPI-major   source: element (v,s,u,c) at src[((v*S + s)*U + u)*C + c]
 //   image-major source: element (v,s,u,c) at src[((s*V + v)*U + u)*C + c]
 // One block per (v, s) row; block-level min/max partials for the volume range.
@@ -29,17 +30,16 @@ __global__ __launch_bounds__(256) void k0_pack(const SrcT* __restrict__ src, flo
     float* out = dst + ((long long)v * S + s) * (long long)C * pitch;
 
     float mn = INFINITY, mx = -INFINITY;
-    for (int c = 0; c < C; c++) {
-        for (int u = threadIdx.x; u < pitch; u += blockDim.x) {
-            float x = 0.0f;   // zero padding beyond U (a 0-weight tap must stay finite)
-            if (u < U) {
-                // dc.hpp:470 / :474: convertTo with a float scale
-                x = (float)in[(long long)u * C + c] * scale;
-                mn = fminf(mn, x);
-                mx = fmaxf(mx, x);
-            }
-            out[(long long)c * pitch + u] = x;
+    // source and slab rows are both pixel-major with interleaved channels: a scaled copy, then zero padding
+    for (int i = threadIdx.x; i < pitch * C; i += blockDim.x) {
+        float x = 0.0f;   // zero padding beyond U (a 0-weight tap must stay finite)
+        if (i < U * C) {
+            // dc.hpp:470 / :474: convertTo with a float scale
+            x = (float)in[i] * scale;
+            mn = fminf(mn, x);
+            mx = fmaxf(mx, x);
         }
+        out[i] = x;
     }
     // block reduce
     for (int o = 32; o > 0; o >>= 1) {
@@ -106,14 +106,14 @@ __global__ __launch_bounds__(256) void k1_edge_confidence(VolView vol, int s, Ed
     const int u = blockIdx.x * blockDim.x + threadIdx.x;
     if (u >= vol.U)
         return;
-    const float* r0 = vol.row(v, s, 0);
+    const float* r0 = vol.row(v, s);
     const int centre = (ec.filter_size - 1) / 2;
     const long long o = (long long)v * vol.U + u;
 
     float e[C];
 #pragma unroll
     for (int c = 0; c < C; c++)
-        e[c] = r0[(long long)c * vol.pitch + u];
+        e[c] = r0[u * C + c];
 
     float ce = Ce[o];
     for (int j = 0; j < ec.filter_size; j++) {
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void k1_edge_confidence(VolView vol, int s, Ed
         const int q = reflect101(u + j - centre, vol.U);
 #pragma unroll
         for (int c = 0; c < C; c++) {
-            const float t = e[c] - r0[(long long)c * vol.pitch + q];
+            const float t = e[c] - r0[q * C + c];
             const float t2 = t * t;
             ce = ce + t2;
         }

@@ -296,7 +296,7 @@ __device__ __forceinline__ void scan_generic_body(const ScanArgs& a, int v, int 
                                                   float* __restrict__ Kcol = nullptr, long long kstride = 0)
 {
     const VolView& vol = a.vol;
-    const float* epi = vol.row(v, 0, 0);
+    const float* epi = vol.row(v, 0);
     const float uf = (float)u;
     const int Um1 = vol.U - 1;
     const long long o = (long long)v * vol.U + u;
@@ -310,7 +310,7 @@ __device__ __forceinline__ void scan_generic_body(const ScanArgs& a, int v, int 
         float rbar[C];
 #pragma unroll
         for (int c = 0; c < C; c++) {   // core.hpp:577: R[s_hat] is E[s_hat][u] exactly (position u + 0*d) ...
-            rbar[c] = epi[(long long)a.s_hat * vol.stride_s + (long long)c * vol.pitch + u];
+            rbar[c] = epi[(long long)a.s_hat * vol.stride_s + u * C + c];
             if (a.k.interp == 2 && u != 0)   // ... except as built (interp.hpp:118): bits(float(u)) is no column unless u = 0
                 rbar[c] = NAN;
         }
@@ -363,8 +363,8 @@ __device__ __forceinline__ void scan_generic_body(const ScanArgs& a, int v, int 
                     float q[C];
 #pragma unroll
                     for (int c = 0; c < C; c++) {
-                        const float m0 = omt * row[(long long)c * vol.pitch + j0];
-                        const float m1 = t * row[(long long)c * vol.pitch + j1];
+                        const float m0 = omt * row[j0 * C + c];
+                        const float m1 = t * row[j1 * C + c];
                         float R = m0 + m1;
                         R = valid ? R : NAN;
                         R0[c] = (R > 0.0f) ? R : 0.0f;
@@ -478,7 +478,7 @@ __device__ __forceinline__ void scan_stream_body(const ScanArgs& a, int v, int u
                                                  float* __restrict__ otab)
 {
     const VolView& vol = a.vol;
-    const float* epi = vol.row(v, 0, 0);
+    const float* epi = vol.row(v, 0);
     const float uf = (float)u;
     const unsigned Um1_bits = __float_as_uint((float)(vol.U - 1));
     const int S = vol.S;
@@ -491,11 +491,10 @@ __device__ __forceinline__ void scan_stream_body(const ScanArgs& a, int v, int u
     const float kq = (C == 1) ? a.k.k1 : a.k.inv_h2;
     const float slope = a.k.slope;
     const unsigned stride_b = (unsigned)vol.stride_s << 2;
-    const unsigned pitch_b = (unsigned)vol.pitch << 2;
     float centre[C];
 #pragma unroll
     for (int c = 0; c < C; c++)
-        centre[c] = epi[(long long)a.s_hat * vol.stride_s + (long long)c * vol.pitch + u];
+        centre[c] = epi[(long long)a.s_hat * vol.stride_s + u * C + c];
 
     for (int d = d0; d < d1; d++) {
         const float Dd = hypothesis(dmin, range, denom, d);
@@ -548,13 +547,14 @@ __device__ __forceinline__ void scan_stream_body(const ScanArgs& a, int v, int u
                         ok[j] = live && (__float_as_uint(x) <= Um1_bits);   // interp.hpp:182 (x is never -0)
                         i0 = ok[j] ? i0 : 0;
                     }
-                    const unsigned byteoff = ((unsigned)i0 << 2) + (live ? rowb : 0u);
+                    const unsigned byteoff = ((unsigned)(i0 * C) << 2) + (live ? rowb : 0u);
                     rowb += stride_b;
+                    // both taps of every channel are 2*C consecutive floats of the row (interleaved slab)
+                    const float* p = (const float*)((const char*)epi + byteoff);
 #pragma unroll
                     for (int c = 0; c < C; c++) {
-                        const float* p = (const float*)((const char*)epi + (byteoff + (unsigned)c * pitch_b));
-                        e0[c][j] = p[0];
-                        e1[c][j] = p[1];   // one global_load_dwordx2 with e0 (two dword loads measured 5-9 % slower)
+                        e0[c][j] = p[c];
+                        e1[c][j] = p[C + c];
                     }
                 }
 #pragma unroll
@@ -673,7 +673,7 @@ __device__ __forceinline__ void scan_reg_body(const ScanArgs& a, int v, int u, i
     constexpr int kGatherBatch = gather_batch(C);
     static_assert(SPAD % 8 == 0, "slot counts are multiples of 8");
     const VolView& vol = a.vol;
-    const float* epi = vol.row(v, 0, 0);
+    const float* epi = vol.row(v, 0);
     const float uf = (float)u;
     const int Um1 = vol.U - 1;
     const unsigned Um1_bits = __float_as_uint((float)Um1);
@@ -687,12 +687,11 @@ __device__ __forceinline__ void scan_reg_body(const ScanArgs& a, int v, int u, i
     const float kq = (C == 1) ? a.k.k1 : a.k.inv_h2;   // kernels.cpp:21 / :43
     const float slope = a.k.slope;
     const int stride_s = (int)vol.stride_s;
-    const unsigned pitch_b = (unsigned)vol.pitch << 2;
     // core.hpp:577: rbar starts from R[s_hat] = E[s_hat][u] for every hypothesis
     float centre[C];
 #pragma unroll
     for (int c = 0; c < C; c++)
-        centre[c] = epi[(long long)a.s_hat * vol.stride_s + (long long)c * vol.pitch + u];
+        centre[c] = epi[(long long)a.s_hat * vol.stride_s + u * C + c];
 
 #pragma unroll 1
     for (int d = d0; d < d1; d++) {
@@ -755,15 +754,16 @@ __device__ __forceinline__ void scan_reg_body(const ScanArgs& a, int v, int u, i
                         ok[j] = __float_as_uint(x) <= Um1_bits;
                         i0 = ok[j] ? i0 : 0;           // keep the address inside the row
                     }
-                    // 32-bit byte offset off the EPI's scalar base: one global_load_dwordx2 per channel
-                    const unsigned byteoff = (unsigned)(i0 + rowoff) << 2;
+                    // 32-bit byte offset off the EPI's scalar base
+                    const unsigned byteoff = (unsigned)(i0 * C + rowoff) << 2;
+                    // both taps of every channel are 2*C consecutive floats of the row (interleaved slab).  For
+                    // integral x the reference reads the first tap twice with weights 1 and 0; 0 * (second tap)
+                    // is the same +0 (rows are zero padded, so the second tap is finite)
+                    const float* p = (const float*)((const char*)epi + byteoff);
 #pragma unroll
                     for (int c = 0; c < C; c++) {
-                        const float* p = (const float*)((const char*)epi + (byteoff + (unsigned)c * pitch_b));
-                        // second tap = p[1]: for integral x the reference reads p[0] twice with weights
-                        // 1 and 0; 0 * p[1] is the same +0 (rows are zero padded, so p[1] is finite)
-                        e0[c][j] = p[0];
-                        e1[c][j] = p[1];
+                        e0[c][j] = p[c];
+                        e1[c][j] = p[C + c];
                     }
                 }
                 rowoff += stride_s;

@@ -35,24 +35,24 @@ __global__ __launch_bounds__(256) void k3_selective_median(VolView vol, const fl
         return;
     }
     const int w = (size - 1) / 2;
-    const float* rc = vol.row(v, s_hat, 0);
+    const float* rc = vol.row(v, s_hat);
     float ec[C];
 #pragma unroll
     for (int c = 0; c < C; c++)
-        ec[c] = rc[(long long)c * vol.pitch + u];
+        ec[c] = rc[u * C + c];
 
     int n = 0;
     const int k0 = max(0, v - w), k1 = min(V, v + w + 1);
     const int l0 = max(0, u - w), l1 = min(U, u + w + 1);
     for (int k = k0; k < k1; k++) {
-        const float* rk = vol.row(k, s_hat, 0);
+        const float* rk = vol.row(k, s_hat);
         for (int l = l0; l < l1; l++) {
             if (!mask[(long long)k * U + l])
                 continue;
             float df[C];
 #pragma unroll
             for (int c = 0; c < C; c++)
-                df[c] = ec[c] - rk[(long long)c * vol.pitch + l];
+                df[c] = ec[c] - rk[l * C + c];
             const float nr = (C == 1) ? norm1(df[0]) : norm3(df[0], df[C > 1 ? 1 : 0], df[C > 2 ? 2 : 0]);
             if (nr < eps) {
                 cand[n][threadIdx.x] = src[(long long)k * U + l];

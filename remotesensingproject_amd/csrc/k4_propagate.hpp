@@ -49,11 +49,11 @@ __global__ __launch_bounds__(256) void k4_propagate_claim(VolView vol, int s_hat
         const long long t = (long long)s * plane + (long long)v * vol.U + ri;
         if (!mask_svu[t])
             continue;
-        const float* e = vol.row(v, s, 0);
+        const float* e = vol.row(v, s);
         float df[C];
 #pragma unroll
         for (int c = 0; c < C; c++)
-            df[c] = e[(long long)c * vol.pitch + ri] - rb[c];
+            df[c] = e[ri * C + c] - rb[c];
         const float nr = (C == 1) ? norm1(df[0]) : norm3(df[0], df[C > 1 ? 1 : 0], df[C > 2 ? 2 : 0]);
         if (nr < prop_eps)   // core.hpp:1116
             atomicMin(&winner_svu[t], u);

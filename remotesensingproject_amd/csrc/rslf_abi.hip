@@ -98,7 +98,7 @@ static VolView view_of(const rslf_volume* vol)
     w.U = vol->U;
     w.C = vol->C;
     w.pitch = vol->pitch;
-    w.stride_s = (long long)vol->C * vol->pitch;
+    w.stride_s = (long long)vol->pitch * vol->C;
     w.stride_v = (long long)vol->S * w.stride_s;
     return w;
 }
@@ -313,7 +313,7 @@ extern "C" int rslf_volume_create(rslf_ctx* ctx, int V, int S, int U, int C, rsl
         return fail(RSLF_ERR_UNSUPPORTED, "V=%d / S=%d: the per-scanline kernels index scanlines and views with grid.y / grid.z "
                                           "(at most 65535)", V, S);
     if ((long long)S * C * (((long long)U + 1 + 63) / 64 * 64) > ((long long)1 << 29))
-        return fail(RSLF_ERR_UNSUPPORTED, "one EPI (S*C*pitch floats) must stay below 2 GiB: the scan addresses it with 32-bit byte offsets");
+        return fail(RSLF_ERR_UNSUPPORTED, "one EPI (S*pitch*C floats) must stay below 2 GiB: the scan addresses it with 32-bit byte offsets");
     HIP_TRY(hipSetDevice(ctx->device));
     rslf_volume* vol = new (std::nothrow) rslf_volume();
     if (!vol)
@@ -323,7 +323,7 @@ extern "C" int rslf_volume_create(rslf_ctx* ctx, int V, int S, int U, int C, rsl
     vol->S = S;
     vol->U = U;
     vol->C = C;
-    vol->pitch = ((U + 1 + 63) / 64) * 64;   // > U: the second lerp tap of u = U-1 lands on a zero
+    vol->pitch = ((U + 1 + 63) / 64) * 64;   // pixels per row, > U: the second lerp tap of u = U-1 lands on zeros
     vol->bytes = (size_t)V * S * C * vol->pitch * sizeof(float);
     hipError_t e = hipMalloc(&vol->base, vol->bytes);
     if (e != hipSuccess) {

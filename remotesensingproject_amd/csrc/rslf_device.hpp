@@ -14,16 +14,18 @@ namespace rslf {
 constexpr int kWave = 64;              // gfx950 wavefront
 constexpr float kSentinel = 1.0e30f;   // out-of-range sample marker of the register scan (see k2_scan.hpp)
 
-// The light-field slab in HBM: [V][S][C][pitch] float32, zero padded rows.
+// The light-field slab in HBM: [V][S][pitch][C] float32 -- one row of `pitch` pixels per (EPI v, view s),
+// channels interleaved as in the reference's cv::Mat rows, pixels U..pitch-1 zero.  Both lerp taps of a
+// sample, all channels, are 2*C consecutive floats; for C = 1 the layout is a plain pitched row.
 struct VolView {
     const float* base;
     int V, S, U, C;
-    int pitch;            // floats per row
-    long long stride_s;   // floats between views   = C * pitch
-    long long stride_v;   // floats between EPIs    = S * C * pitch
-    __device__ __forceinline__ const float* row(int v, int s, int c) const
+    int pitch;            // pixels per row (multiple of 64, > U)
+    long long stride_s;   // floats between views   = pitch * C
+    long long stride_v;   // floats between EPIs    = S * pitch * C
+    __device__ __forceinline__ const float* row(int v, int s) const
     {
-        return base + (long long)v * stride_v + (long long)s * stride_s + (long long)c * pitch;
+        return base + (long long)v * stride_v + (long long)s * stride_s;
     }
 };
 

@@ -138,7 +138,7 @@ def _ptr(t: Optional[torch.Tensor]) -> C.c_void_p:
 
 
 class Volume:
-    """The light-field slab in HBM, [V][S][C][pitch] float32 (rslf_volume)."""
+    """The light-field slab in HBM, [V][S][pitch][C] float32 (rslf_volume)."""
 
     def __init__(self, ctx: Context, V: int, S: int, U: int, C_: int):
         self.ctx = ctx
