@@ -8,7 +8,7 @@
 
 namespace rslf {
 
-// ---- K0: normalise + planarise into the slab ------------------------------
+// ---- K0: normalise + copy into the slab --------------------------------------
 // Replaces Depth1DComputer_pile's constructor copy/convertTo
 // (include/rslf_depth_computation.hpp:463-477) and, for the image-major source,
 // rslf::build_epis_from_imgs (src/rslf_io.cpp:194-227).
