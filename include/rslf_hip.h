@@ -145,6 +145,14 @@ int rslf_volume_upload_epis_u8(rslf_volume* vol, const uint8_t* const* h_epis, s
 int rslf_volume_upload_images_f32(rslf_volume* vol, const float* const* h_imgs, size_t row_stride_bytes,
                                   float epi_scale_factor, float* scale_used);
 int rslf_volume_upload_images_u8(rslf_volume* vol, const uint8_t* const* h_imgs, size_t row_stride_bytes);
+/* The same with the two per-EPI options of rslf::build_epis_from_imgs (src/rslf_io.cpp:194-227, arguments `transpose`,
+ * `rotate_180`): the EPI of scanline v is E[i][x] = h_imgs[i](v, x); transpose stores E^T -- the volume then has
+ * S = image columns and U = number of images, h_imgs holds vol->U images of V rows x vol->S columns -- and
+ * rotate_180 turns the (transposed) EPI by 180 degrees, i.e. reverses both of its axes. */
+int rslf_volume_upload_images_xf_f32(rslf_volume* vol, const float* const* h_imgs, size_t row_stride_bytes,
+                                     float epi_scale_factor, float* scale_used, int transpose, int rotate_180);
+int rslf_volume_upload_images_xf_u8(rslf_volume* vol, const uint8_t* const* h_imgs, size_t row_stride_bytes,
+                                    int transpose, int rotate_180);
 /* Device-resident dense [V][S][U][C] float32 (already on this GPU). */
 int rslf_volume_pack_device_f32(rslf_volume* vol, const float* d_vsuc, float epi_scale_factor, float* scale_used);
 

@@ -26,7 +26,7 @@ SYMBOLS = [
     "rslf_edge_confidence_2d", "rslf_depth_epi_2d", "rslf_depth2d_run",
     "rslf_depth_epi_scan", "rslf_depth1d_run",
     "rslf_f2c_level_dims", "rslf_downsample_epis_f32", "rslf_device_max_f32", "rslf_f2c_tighten_bounds", "rslf_f2c_fuse",
-    "rslf_depth2d_run_host", "rslf_fine_to_coarse_run_host", "rslf_kernel_columns_pile",
+    "rslf_depth2d_run_host", "rslf_fine_to_coarse_run_host", "rslf_kernel_columns_pile", "rslf_volume_upload_images_xf_f32", "rslf_volume_upload_images_xf_u8",
 ]
 
 
@@ -120,6 +120,8 @@ def lib():
     L.rslf_volume_upload_epis_u8.argtypes = [vp, C.POINTER(vp), C.c_size_t]
     L.rslf_volume_upload_images_f32.argtypes = [vp, C.POINTER(vp), C.c_size_t, cf, C.POINTER(cf)]
     L.rslf_volume_upload_images_u8.argtypes = [vp, C.POINTER(vp), C.c_size_t]
+    L.rslf_volume_upload_images_xf_f32.argtypes = [vp, C.POINTER(vp), C.c_size_t, cf, C.POINTER(cf), ci, ci]
+    L.rslf_volume_upload_images_xf_u8.argtypes = [vp, C.POINTER(vp), C.c_size_t, ci, ci]
     L.rslf_volume_pack_device_f32.argtypes = [vp, vp, cf, C.POINTER(cf)]
     L.rslf_edge_confidence_pile.argtypes = [vp, vp, ci, C.POINTER(RslfParams), vp, vp]
     L.rslf_depth_epi_pile.argtypes = [vp, vp, vp, vp, cf, cf, ci, ci, vp, vp, vp, vp, vp, C.POINTER(RslfParams),

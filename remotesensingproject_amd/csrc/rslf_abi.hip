@@ -499,6 +499,53 @@ static int upload_host(rslf_volume* vol, const SrcT* const* h_ptrs, size_t row_s
     return minmax_end(vol);
 }
 
+// Image-major upload with build_epis_from_imgs' transpose / rotate_180 options: n_imgs images of V rows x cols.
+template <typename SrcT>
+static int upload_images_xf(rslf_volume* vol, const SrcT* const* h_imgs, size_t row_stride_bytes, float scale, int transpose,
+                            int rotate_180)
+{
+    rslf_ctx* ctx = vol->ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const int n_imgs = transpose ? vol->U : vol->S;   // the slab holds E^T when transposed
+    const int cols = transpose ? vol->S : vol->U;
+    const size_t row_bytes = (size_t)cols * vol->C * sizeof(SrcT);
+    if (row_stride_bytes == 0)
+        row_stride_bytes = row_bytes;
+    if (row_stride_bytes < row_bytes)
+        return fail(RSLF_ERR_INVALID_ARG, "row_stride_bytes %zu < row size %zu", row_stride_bytes, row_bytes);
+    const size_t epi_bytes = row_bytes * n_imgs;
+    int chunk = (int)std::max<size_t>(1, ((size_t)256 << 20) / epi_bytes);
+    chunk = std::min(chunk, vol->V);
+    int rc = ensure_staging(ctx, (size_t)chunk * epi_bytes);
+    if (rc)
+        return rc;
+    rc = minmax_begin(ctx);
+    if (rc)
+        return rc;
+    for (int v0 = 0; v0 < vol->V; v0 += chunk) {
+        const int vn = std::min(chunk, vol->V - v0);
+        for (int i = 0; i < n_imgs; i++) {   // staging [n_imgs][vn][cols*C]
+            if (!h_imgs[i])
+                return fail(RSLF_ERR_INVALID_ARG, "h_imgs[%d] is NULL", i);
+            HIP_TRY(hipMemcpy2DAsync((char*)ctx->staging + (size_t)i * vn * row_bytes, row_bytes,
+                                     (const char*)h_imgs[i] + (size_t)v0 * row_stride_bytes, row_stride_bytes, row_bytes, vn,
+                                     hipMemcpyHostToDevice, ctx->stream));
+        }
+        const size_t rows = (size_t)vn * vol->S;
+        rc = ensure_partial(ctx, rows);
+        if (rc)
+            return rc;
+        hipLaunchKernelGGL((k0_pack_images_xf<SrcT>), dim3((unsigned)rows), dim3(256), 0, ctx->stream, (const SrcT*)ctx->staging,
+                           vol->base, v0, vn, n_imgs, cols, vol->S, vol->U, vol->C, vol->pitch, scale, transpose, rotate_180,
+                           ctx->partial);
+        HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(k0_minmax_final, dim3(1), dim3(256), 0, ctx->stream, ctx->partial, (int)rows, ctx->minmax);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(ctx->stream));   // the staging buffer is reused by the next chunk
+    }
+    return minmax_end(vol);
+}
+
 // dc.hpp:442-460: epi_scale_factor = max over every value of every EPI
 static float host_max_f32(const float* const* h_ptrs, int n_ptrs, int rows, size_t row_stride_bytes, size_t row_elems, float start)
 {
@@ -559,6 +606,29 @@ extern "C" int rslf_volume_upload_images_u8(rslf_volume* vol, const uint8_t* con
     if (!vol || !h_imgs)
         return fail(RSLF_ERR_INVALID_ARG, "vol/h_imgs is NULL");
     return upload_host<uint8_t>(vol, h_imgs, row_stride_bytes, true, (float)(1.0 / 255.0));
+}
+
+extern "C" int rslf_volume_upload_images_xf_f32(rslf_volume* vol, const float* const* h_imgs, size_t row_stride_bytes,
+                                                float epi_scale_factor, float* scale_used, int transpose, int rotate_180)
+{
+    if (!vol || !h_imgs)
+        return fail(RSLF_ERR_INVALID_ARG, "vol/h_imgs is NULL");
+    const int n_imgs = transpose ? vol->U : vol->S;
+    const size_t row_elems = (size_t)(transpose ? vol->S : vol->U) * vol->C;
+    const size_t stride = row_stride_bytes ? row_stride_bytes : row_elems * sizeof(float);
+    if (epi_scale_factor < 0)
+        epi_scale_factor = host_max_f32(h_imgs, n_imgs, vol->V, stride, row_elems, epi_scale_factor);
+    if (scale_used)
+        *scale_used = epi_scale_factor;
+    return upload_images_xf<float>(vol, h_imgs, stride, scale_of(epi_scale_factor), transpose != 0, rotate_180 != 0);
+}
+
+extern "C" int rslf_volume_upload_images_xf_u8(rslf_volume* vol, const uint8_t* const* h_imgs, size_t row_stride_bytes, int transpose,
+                                               int rotate_180)
+{
+    if (!vol || !h_imgs)
+        return fail(RSLF_ERR_INVALID_ARG, "vol/h_imgs is NULL");
+    return upload_images_xf<uint8_t>(vol, h_imgs, row_stride_bytes, (float)(1.0 / 255.0), transpose != 0, rotate_180 != 0);
 }
 
 extern "C" int rslf_volume_pack_device_f32(rslf_volume* vol, const float* d_vsuc, float epi_scale_factor, float* scale_used)

@@ -176,25 +176,37 @@ class Volume:
         return vol
 
     @staticmethod
-    def from_images(imgs: Sequence[np.ndarray], epi_scale_factor: float = -1.0, ctx: Context | None = None) -> "Volume":
-        """Image-major input, S images each [V,U] or [V,U,3] -- what
-        rslf::build_epis_from_imgs (rslf_io.cpp:194-227) consumes."""
+    def from_images(imgs: Sequence[np.ndarray], epi_scale_factor: float = -1.0, ctx: Context | None = None,
+                    transpose: bool = False, rotate_180: bool = False) -> "Volume":
+        """Image-major input, images each [V,U] or [V,U,3] -- what rslf::build_epis_from_imgs
+        (rslf_io.cpp:194-227) consumes, with its `transpose` / `rotate_180` options: transposed, the EPI of a
+        scanline has one row per image COLUMN and one column per image."""
         ctx = ctx or default_context()
         i0 = np.asarray(imgs[0])
-        V, U = i0.shape[:2]
+        V, cols = i0.shape[:2]
         C_ = 1 if i0.ndim == 2 else i0.shape[2]
-        vol = Volume(ctx, V, len(imgs), U, C_)
+        S, U = (cols, len(imgs)) if transpose else (len(imgs), cols)
+        vol = Volume(ctx, V, S, U, C_)
         is_u8 = i0.dtype == np.uint8
         arrs = [np.ascontiguousarray(e, dtype=np.uint8 if is_u8 else np.float32) for e in imgs]
         ptrs = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
         L = _lib.lib()
+        plain = not (transpose or rotate_180)
         if is_u8:
-            check(L.rslf_volume_upload_images_u8(vol._h, ptrs, 0), "rslf_volume_upload_images_u8")
+            if plain:
+                check(L.rslf_volume_upload_images_u8(vol._h, ptrs, 0), "rslf_volume_upload_images_u8")
+            else:
+                check(L.rslf_volume_upload_images_xf_u8(vol._h, ptrs, 0, int(transpose), int(rotate_180)),
+                      "rslf_volume_upload_images_xf_u8")
             vol.scale_used = 255.0
         else:
             su = C.c_float()
-            check(L.rslf_volume_upload_images_f32(vol._h, ptrs, 0, float(epi_scale_factor), C.byref(su)),
-                  "rslf_volume_upload_images_f32")
+            if plain:
+                check(L.rslf_volume_upload_images_f32(vol._h, ptrs, 0, float(epi_scale_factor), C.byref(su)),
+                      "rslf_volume_upload_images_f32")
+            else:
+                check(L.rslf_volume_upload_images_xf_f32(vol._h, ptrs, 0, float(epi_scale_factor), C.byref(su), int(transpose),
+                                                         int(rotate_180)), "rslf_volume_upload_images_xf_f32")
             vol.scale_used = float(su.value)
         return vol
 

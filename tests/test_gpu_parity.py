@@ -537,3 +537,36 @@ def test_kernel_columns_output(rs, oracle_mod, C_, S, U, planes, mode):
     got = tK.cpu().numpy()
     assert np.array_equal(got, want)
     assert ((got >= 0.0) & (got <= 1.0) | (got == -7.0)).all()
+
+
+@pytest.mark.parametrize("transpose,rotate", [(False, True), (True, False), (True, True)])
+@pytest.mark.parametrize("dtype,C_", [(np.float32, 1), (np.uint8, 3)])
+def test_image_stack_with_transpose_and_rotation(rs, oracle_mod, transpose, rotate, dtype, C_):
+    """rslf::build_epis_from_imgs(imgs, transpose, rotate_180) (rslf_io.cpp:194-227): the EPI of scanline v is
+    E[i][x] = img_i(v, x), optionally transposed and then turned by 180 degrees -- done by the upload kernel."""
+    rng = np.random.default_rng(33 + 2 * transpose + rotate)
+    n_imgs, V, cols = 7, 5, 60
+    if dtype == np.uint8:
+        imgs = [rng.integers(0, 256, size=(V, cols, C_), dtype=np.uint8) for _ in range(n_imgs)]
+    else:
+        imgs = [rng.uniform(1.0, 90.0, size=(V, cols)).astype(np.float32) for _ in range(n_imgs)]
+    # the reference's construction, per scanline
+    epis = []
+    for v in range(V):
+        epi = np.stack([im[v] for im in imgs])                    # [n_imgs, cols(, C)]
+        if transpose:
+            epi = np.swapaxes(epi, 0, 1)                           # cv::transpose
+        if rotate:
+            epi = epi[::-1, ::-1]                                  # cv::rotate(ROTATE_180)
+        epis.append(np.ascontiguousarray(epi))
+    raw = np.stack(epis)
+    if raw.ndim == 3:
+        raw = raw[..., None]
+    vol = oracle_mod.normalize_u8(raw) if dtype == np.uint8 else oracle_mod.normalize_f32(raw, -1.0)[0]
+    D = 9
+    ref = oracle_mod.depth1d_pile_run(vol, -1.0, 1.0, D)
+    v = rs.Volume.from_images(imgs, transpose=transpose, rotate_180=rotate)
+    assert (v.V, v.S, v.U) == vol.shape[:3]
+    comp = rs.Depth1DComputer_pile(v, -1.0, 1.0, D)
+    comp.run()
+    assert_pile_parity(comp.results(), ref, label="images_T%d_R%d" % (transpose, rotate))
