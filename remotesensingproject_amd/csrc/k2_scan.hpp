@@ -5,9 +5,14 @@
 // (include/rslf_interpolation.hpp:155-193) and BandwidthKernel
 // (src/rslf_kernels.cpp:16-54) inlined.
 //
-// Work mapping (both variants)
+// Variants: k2_scan_reg (samples held in registers; scalar, or packed fp32 at one wave per SIMD),
+// k2_scan_stream (samples re-gathered every pass), k2_scan_generic (any input, nearest-neighbour modes),
+// k2_kernel_column (the optional K output), k2_scan_combine (merges hypothesis groups).
+//
+// Work mapping (every variant)
 //   workgroup = one tile: 64 consecutive entries of one scanline's confident-pixel list
-//   wavefront = one quarter of the hypothesis range for that tile
+//               (sparse launches: of ONE list over all scanlines, and `groups` workgroups per tile)
+//   wavefront = one quarter of the tile's (or the group's) hypothesis range
 //   lane      = one pixel u; it walks its wave's hypotheses itself
 // A wave's 64 gathers per (s, d) are 64 neighbouring floats of one EPI row
 // (coalesced along u), and the sum over s is the reference's sequential float
