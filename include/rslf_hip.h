@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define RSLF_ABI_VERSION 2
+#define RSLF_ABI_VERSION 3
 
 typedef enum rslf_status {
     RSLF_OK = 0,
@@ -54,7 +54,7 @@ typedef enum rslf_status {
 typedef struct rslf_params {
     float edge_score_threshold;         /* 0.02 */
     float line_score_threshold;         /* 0.02  (unused by this path, kept for 1:1 layout) */
-    float disp_score_threshold;         /* 0.01  (unused by this path) */
+    float disp_score_threshold;         /* 0.01  (only with use_disp_confidence_score) */
     float raw_score_threshold;          /* 0 */
     float mean_shift_max_iter;          /* 10; a float in the reference (:115) */
     int   edge_confidence_filter_size;  /* 9 */
@@ -69,6 +69,9 @@ typedef struct rslf_params {
     float shadow_level;                 /* 0.05 * 1.73205080757 */
     float kernel_bandwidth;             /* 0.2 (_BANDWIDTH_KERNEL_PARAMETER, :26) */
     int   interpolation;                /* par_interpolation_class (:76-77, :108): RSLF_INTERP_*, default LINEAR */
+    int   use_disp_confidence_score;    /* the reference's commented-out build switch _USE_DISP_CONFIDENCE_SCORE (:35): the 2-D
+                                           sweep's propagation is gated by C_d > disp_score_threshold (:1097-1098) instead of the
+                                           edge mask (:1102).  0 = the default build */
 } rslf_params;
 
 /* par_interpolation_class.

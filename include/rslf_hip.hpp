@@ -61,6 +61,7 @@ struct Depth1DParameters {
     float par_shadow_level;
     float par_kernel_bandwidth;   // BandwidthKernel(_BANDWIDTH_KERNEL_PARAMETER), core.hpp:78
     int par_interpolation_class;  // RSLF_INTERP_*: stands for the Interpolation1DClass* of core.hpp:108 (default Linear, :76)
+    bool par_use_disp_confidence_score;   // the reference's build switch _USE_DISP_CONFIDENCE_SCORE (core.hpp:35), off by default
 
     Depth1DParameters()
     {
@@ -82,6 +83,7 @@ struct Depth1DParameters {
         par_shadow_level = p.shadow_level;
         par_kernel_bandwidth = p.kernel_bandwidth;
         par_interpolation_class = p.interpolation;
+        par_use_disp_confidence_score = p.use_disp_confidence_score != 0;
     }
 
     static Depth1DParameters& get_default()
@@ -109,6 +111,7 @@ struct Depth1DParameters {
         p.shadow_level = par_shadow_level;
         p.kernel_bandwidth = par_kernel_bandwidth;
         p.interpolation = par_interpolation_class;
+        p.use_disp_confidence_score = par_use_disp_confidence_score ? 1 : 0;
         return p;
     }
 };

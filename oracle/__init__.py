@@ -37,6 +37,8 @@ class OracleParams(C.Structure):
         ("interpolation", C.c_int),     # 0 linear, 1 nearest (interp.hpp:80-92), 2 nearest as built (interp.hpp:118)
         ("edge_confidence_opening_type", C.c_int),   # cv::MORPH_RECT 0 / CROSS 1 / ELLIPSE 2
         ("edge_confidence_opening_size", C.c_int),   # 1 = off
+        ("use_disp_confidence_score", C.c_int),      # _USE_DISP_CONFIDENCE_SCORE (core.hpp:35), 0 = default build
+        ("disp_score_threshold", C.c_float),         # 0.01
     ]
 
 

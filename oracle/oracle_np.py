@@ -36,6 +36,8 @@ def default_params() -> dict:
         interpolation=0,             # core.hpp:76: Interpolation1DLinear; 1 / 2 = nearest (see rslf_oracle.h)
         edge_confidence_opening_type=2,   # cv::MORPH_ELLIPSE, core.hpp:28
         edge_confidence_opening_size=1,   # core.hpp:29: 1 = no opening
+        use_disp_confidence_score=False,  # core.hpp:35 (_USE_DISP_CONFIDENCE_SCORE, commented out in the reference)
+        disp_score_threshold=F(0.01),     # core.hpp:22
     )
 
 
@@ -306,7 +308,10 @@ def depth2d_run(vol, dmin, dmax, D, p=None, propagation_epsilon=F(0.1)):
         filtered = selective_median(depth[s_hat], vol, s_hat, cm[s_hat], p["median_filter_size"], p["median_filter_epsilon"])
         for v in range(V):                                      # core.hpp:1088-1129
             for u in range(U):
-                if not cm[s_hat, v, u]:
+                if p.get("use_disp_confidence_score", False):       # core.hpp:1097-1098
+                    if not Cd[s_hat, v, u] > F(p["disp_score_threshold"]):
+                        continue
+                elif not cm[s_hat, v, u]:                            # core.hpp:1102
                     continue
                 cur = filtered[v, u]
                 for s in range(S):

@@ -38,6 +38,8 @@ void oracle_default_params(oracle_params* p)
     p->interpolation = ORACLE_INTERP_LINEAR;   /* core.hpp:76 */
     p->edge_confidence_opening_type = 2;       /* cv::MORPH_ELLIPSE, core.hpp:28 */
     p->edge_confidence_opening_size = 1;       /* core.hpp:29 */
+    p->use_disp_confidence_score = 0;          /* core.hpp:35: the #define is commented out */
+    p->disp_score_threshold = (float)0.01;     /* core.hpp:22 */
 }
 
 /* Interpolation1DNearestNeighbour::interpolate_mat (interp.hpp:94-131): the sample index for position x,
@@ -776,7 +778,8 @@ void oracle_depth_epi_2d(const float* vol, int V, int S, int U, int C,
 #pragma omp parallel for schedule(static)
         for (int v = 0; v < V; v++) {
             for (int u = 0; u < U; u++) {
-                if (!Cem[(size_t)v * U + u]) /* core.hpp:1103 */
+                /* core.hpp:1097-1103: what lets a pixel paint */
+                if (p->use_disp_confidence_score ? !(Cd[(size_t)v * U + u] > p->disp_score_threshold) : !Cem[(size_t)v * U + u])
                     continue;
                 const float cur = filtered[(size_t)v * U + u];
                 const float* rb = rbar + ((size_t)v * U + u) * C;

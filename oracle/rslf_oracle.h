@@ -55,6 +55,10 @@ typedef struct oracle_params {
     int   interpolation;             /* par_interpolation_class (core.hpp:76-77, :108): ORACLE_INTERP_* */
     int   edge_confidence_opening_type; /* cv::MORPH_RECT 0 / MORPH_CROSS 1 / MORPH_ELLIPSE 2 (default) core.hpp:28 */
     int   edge_confidence_opening_size; /* 1 = no opening (default)            core.hpp:29, :759     */
+    int   use_disp_confidence_score;    /* the reference's commented-out build switch _USE_DISP_CONFIDENCE_SCORE (core.hpp:35):
+                                           the 2-D sweep's propagation is gated by C_d > disp_score_threshold (core.hpp:1097-1098)
+                                           instead of the edge mask (:1102).  0 = default build */
+    float disp_score_threshold;         /* _DISP_SCORE_THRESHOLD 0.01                core.hpp:22       */
 } oracle_params;
 
 /* cv::getStructuringElement(shape, Size(k, k)) with the default anchor (k/2, k/2), as OpenCV 3.x builds it:

@@ -12,7 +12,7 @@ from . import build as _build
 
 _LIB = None
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # every symbol include/rslf_hip.h declares
 SYMBOLS = [
@@ -50,6 +50,7 @@ class RslfParams(C.Structure):
         ("shadow_level", C.c_float),
         ("kernel_bandwidth", C.c_float),
         ("interpolation", C.c_int),
+        ("use_disp_confidence_score", C.c_int),
     ]
 
 

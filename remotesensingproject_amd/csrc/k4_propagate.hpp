@@ -24,14 +24,17 @@ __global__ __launch_bounds__(256) void k4_propagate_claim(VolView vol, int s_hat
                                                          const uint8_t* __restrict__ edge_mask_vu,
                                                          const float* __restrict__ rbar_vu,
                                                          const uint8_t* __restrict__ mask_svu, int* __restrict__ winner_svu,
-                                                         float slope, float prop_eps)
+                                                         float slope, float prop_eps, const float* __restrict__ gate_Cd_vu,
+                                                         float disp_thr)
 {
     const int v = blockIdx.y;
     const int u = blockIdx.x * blockDim.x + threadIdx.x;
     if (u >= vol.U)
         return;
     const long long o = (long long)v * vol.U + u;
-    if (!edge_mask_vu[o])   // core.hpp:1103
+    // what lets a pixel paint: the edge mask (default build, core.hpp:1102) or, with the reference's
+    // _USE_DISP_CONFIDENCE_SCORE switch, C_d > par_disp_score_threshold (core.hpp:1097-1098)
+    if (gate_Cd_vu ? !(gate_Cd_vu[o] > disp_thr) : !edge_mask_vu[o])
         return;
     const float cur = filtered_vu[o];
     float rb[C];

@@ -177,6 +177,7 @@ extern "C" void rslf_default_params(rslf_params* p)
     p->shadow_level = (float)(0.05 * 1.73205080757);
     p->kernel_bandwidth = (float)0.2;
     p->interpolation = RSLF_INTERP_LINEAR;   // core.hpp:76
+    p->use_disp_confidence_score = 0;        // core.hpp:35: commented out in the reference
 }
 
 static ScanConsts make_scan_consts(const rslf_params* p)
@@ -1260,10 +1261,12 @@ extern "C" int rslf_depth_epi_2d(rslf_ctx* ctx, const rslf_volume* vol, const fl
         // core.hpp:1088-1129
         if (C == 1)
             hipLaunchKernelGGL(k4_propagate_claim<1>, grid_vu, dim3(256), 0, st, view_of(vol), s_hat, ctx->filtered, cem, rbar,
-                               mask_svu, ctx->winner, p->slope_factor, p->propagation_epsilon);
+                               mask_svu, ctx->winner, p->slope_factor, p->propagation_epsilon,
+                               p->use_disp_confidence_score ? Cd : nullptr, p->disp_score_threshold);
         else
             hipLaunchKernelGGL(k4_propagate_claim<3>, grid_vu, dim3(256), 0, st, view_of(vol), s_hat, ctx->filtered, cem, rbar,
-                               mask_svu, ctx->winner, p->slope_factor, p->propagation_epsilon);
+                               mask_svu, ctx->winner, p->slope_factor, p->propagation_epsilon,
+                               p->use_disp_confidence_score ? Cd : nullptr, p->disp_score_threshold);
         HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(k4_propagate_apply, dim3(apply_blocks), dim3(256), 0, st, S, V, U, s_hat, ctx->filtered, Cd,
                            d_depth_svu, d_Cd_svu, mask_svu, ctx->winner);

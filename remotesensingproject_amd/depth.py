@@ -62,6 +62,9 @@ class Depth1DParameters:
     # par_interpolation_class (core.hpp:76-77, :108): an Interpolation1DLinear / Interpolation1DNearestNeighbour
     # instance, or the RSLF_INTERP_* integer itself
     par_interpolation_class: object = 0
+    # the reference's commented-out build switch _USE_DISP_CONFIDENCE_SCORE (core.hpp:35): propagation gated by
+    # C_d > par_disp_score_threshold instead of the edge mask
+    par_use_disp_confidence_score: bool = False
 
     @staticmethod
     def get_default() -> "Depth1DParameters":

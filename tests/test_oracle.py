@@ -259,6 +259,29 @@ def test_sweep2d_numpy_restatement_agrees_bitwise(oracle_mod, C_):
     assert (r.scan_mask == 0).sum() > (r.edge_mask == 0).sum()   # propagation painted something
 
 
+@pytest.mark.parametrize("thr", [0.01, 0.2])
+def test_sweep2d_with_the_disp_confidence_gate(oracle_mod, thr):
+    """The reference's build switch _USE_DISP_CONFIDENCE_SCORE (core.hpp:35, :1097-1098): a pixel paints along its
+    line only if its C_d exceeds par_disp_score_threshold.  Both restatements agree, and the gate changes the result."""
+    from oracle import oracle_np as onp
+    from remotesensingproject_amd.synth import make_lightfield
+    vol, _ = make_lightfield(40, 4, 7, 1, seed=4, deltas=np.array([0, 1, -1, 1], np.float32))
+    rng = np.random.default_rng(6)
+    vol[2:] = (vol[2:] + rng.normal(0, 0.05, size=vol[2:].shape)).clip(0, 1).astype(np.float32)
+    pc = oracle_mod.default_params()
+    pc.use_disp_confidence_score, pc.disp_score_threshold = 1, thr
+    pn = onp.default_params()
+    pn["use_disp_confidence_score"], pn["disp_score_threshold"] = True, np.float32(thr)
+    r = oracle_mod.depth2d_run(vol, -1.0, 1.0, 9, params=pc)
+    n = onp.depth2d_run(vol, np.float32(-1.0), np.float32(1.0), 9, p=pn)
+    for a, k in (("edge_confidence", "Ce"), ("edge_mask", "Ce_mask"), ("disp_confidence", "Cd"), ("depth", "depth"),
+                 ("rbar", "rbar"), ("scan_mask", "scan_mask")):
+        assert np.array_equal(getattr(r, a), n[k]), a
+    if thr > 0.1:   # a threshold most confidences miss: fewer pixels paint than under the edge-mask gate
+        plain = oracle_mod.depth2d_run(vol, -1.0, 1.0, 9)
+        assert not np.array_equal(plain.scan_mask, r.scan_mask) or not np.array_equal(plain.depth, r.depth)
+
+
 def test_sweep2d_first_visit_is_the_pile_scan(oracle_mod):
     """The centre view's scan inside the 2-D sweep sees the untouched edge mask: its C_e, r_bar and C_d at
     scanned pixels equal Depth1DComputer_pile's (the stored depth differs: raw + painted, core.hpp:892)."""
