@@ -36,8 +36,8 @@ __global__ __launch_bounds__(256) void k0_pack(const SrcT* __restrict__ src, flo
         if (i < U * C) {
             // dc.hpp:470 / :474: convertTo with a float scale
             x = (float)in[i] * scale;
-            mn = fminf(mn, x);
-            mx = fmaxf(mx, x);
+            mn = (x != x) ? -INFINITY : fminf(mn, x);   // a NaN radiance sends the scan to the generic kernel,
+            mx = fmaxf(mx, x);                          // the only variant that keeps NaNs apart (fminf would skip it)
         }
         out[i] = x;
     }
@@ -87,8 +87,8 @@ __global__ __launch_bounds__(256) void k0_pack_images_xf(const SrcT* __restrict_
             const int img = transpose ? ur : sr;            // E^T[s][u] = E[u][s]
             const int col = transpose ? sr : ur;
             x = (float)src[(((long long)img * Vn + vl) * cols + col) * C + c] * scale;
-            mn = fminf(mn, x);
-            mx = fmaxf(mx, x);
+            mn = (x != x) ? -INFINITY : fminf(mn, x);   // a NaN radiance sends the scan to the generic kernel,
+            mx = fmaxf(mx, x);                          // the only variant that keeps NaNs apart (fminf would skip it)
         }
         out[i] = x;
     }

@@ -570,3 +570,20 @@ def test_image_stack_with_transpose_and_rotation(rs, oracle_mod, transpose, rota
     comp = rs.Depth1DComputer_pile(v, -1.0, 1.0, D)
     comp.run()
     assert_pile_parity(comp.results(), ref, label="images_T%d_R%d" % (transpose, rotate))
+
+
+def test_nan_radiances_take_the_generic_kernel(rs, oracle_mod):
+    """A NaN in the input must not reach the sentinel arithmetic of the register / streaming kernels (NaN * 0 is
+    NaN): the pack kernel records it and the scan falls back to the generic variant, which treats it as the
+    reference does (cv::max(R, 0) -> 0, K -> 0)."""
+    rng = np.random.default_rng(12)
+    vol = rng.uniform(0.0, 1.0, size=(3, 9, 80, 1)).astype(np.float32)
+    vol[1, 3, 40, 0] = np.nan
+    vol[2, 0, 5, 0] = np.nan
+    ref = oracle_mod.depth1d_pile_run(vol, -1.0, 1.0, 10)
+    comp, got = _run(rs, vol, -1.0, 1.0, 10)
+    assert comp.stats.scan_kernel == 0
+    for k in ("edge_mask", "depth_idx"):
+        assert np.array_equal(got[k], getattr(ref, k)), k
+    for k in ("score", "depth", "rbar", "edge_confidence"):
+        assert np.array_equal(got[k], getattr(ref, k), equal_nan=True), k
