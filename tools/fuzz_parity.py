@@ -70,6 +70,9 @@ def make_volume(c, rng):
             vol[-1] = np.float32(0.5)                   # flat: C_e = 0
     if c["negative"]:
         vol = vol - np.float32(0.3)                     # negative radiances: generic kernel only
+        if rng.uniform() < 0.3 and vol.size > 4:        # and now and then a NaN (generic kernel as well)
+            flat = vol.reshape(-1)
+            flat[rng.integers(0, flat.size)] = np.nan
     return np.ascontiguousarray(vol, np.float32)
 
 

@@ -52,8 +52,27 @@ def sweep_case(i, rng):
     lo = float(rng.choice([-1.0, -2.0, -0.5]))
     hi = lo + float(rng.choice([2.0, 1.0, 3.5]))
     vol = make_scene(rng, U, V, S, Cn, kind)
-    ref = oracle.depth2d_run(vol, lo, hi, D)
-    comp = rs.Depth2DComputer(vol, lo, hi, D, epi_scale_factor=1.0)
+    # parameters: mostly the defaults, sometimes the optional paths (opening, disparity-confidence gate, nearest
+    # sampling, other thresholds / window / bandwidth)
+    po = oracle.default_params()
+    pr = rs.Depth1DParameters()
+    if rng.uniform() < 0.4:
+        for name, val in (("edge_score_threshold", float(rng.choice([0.02, 0.0, 0.1]))),
+                          ("median_filter_size", int(rng.choice([5, 3, 7, 1]))),
+                          ("kernel_bandwidth", float(rng.choice([0.2, 0.1, 0.4]))),
+                          ("mean_shift_max_iter", float(rng.choice([10.0, 3.0]))),
+                          ("cut_shadows", int(rng.uniform() < 0.8)),
+                          ("edge_confidence_opening_size", int(rng.choice([1, 1, 3, 5]))),
+                          ("edge_confidence_opening_type", int(rng.choice([0, 1, 2]))),
+                          ("use_disp_confidence_score", int(rng.uniform() < 0.3)),
+                          ("disp_score_threshold", float(rng.choice([0.01, 0.1])))):
+            setattr(po, name, val)
+            setattr(pr, "par_" + name, val)
+        mode = int(rng.choice([0, 0, 1]))
+        po.interpolation = mode
+        pr.par_interpolation_class = mode
+    ref = oracle.depth2d_run(vol, lo, hi, D, params=po)
+    comp = rs.Depth2DComputer(vol, lo, hi, D, epi_scale_factor=1.0, parameters=pr)
     comp.run()
     label = "sweep%d %s" % (i, (Cn, S, U, V, D, kind, lo, hi))
     check_sweep(comp.results(), ref, label)
@@ -61,7 +80,7 @@ def sweep_case(i, rng):
     n = S * V * U
     hCe = np.empty((S, V, U), np.float32); hcm = np.empty((S, V, U), np.uint8); hCd = np.empty((S, V, U), np.float32)
     hdep = np.empty((S, V, U), np.float32); hrb = np.empty((S, V, U, Cn), np.float32)
-    p = rs.Depth1DParameters().to_c()
+    p = pr.to_c()
     vp = lambda a: a.ctypes.data_as(C.c_void_p)
     _lib.check(_lib.lib().rslf_depth2d_run_host(comp.m_epis.ctx._h, comp.m_epis._h, lo, hi, D, C.byref(p), vp(hCe), vp(hcm), vp(hCd), vp(hdep),
                                                 vp(hrb), None), "rslf_depth2d_run_host")
