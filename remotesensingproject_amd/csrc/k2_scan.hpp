@@ -478,7 +478,16 @@ __global__ __launch_bounds__(256) void k2_kernel_column(ScanArgs a, const int32_
 // Per (sample, pass): ~9 + 3C gather and 7 / 19 mean-shift instructions; the 2C-float loads per
 // sample make it L1-bandwidth bound at about half the register variant's rate.
 // ---------------------------------------------------------------------------
-template <int C, bool BORDER, bool UNIFORM_D>
+// Resident prefix: the first NRES samples of a unit are gathered ONCE per hypothesis and stay in registers
+// over the mean-shift passes (as in the register variant); only the samples behind them are re-gathered every
+// pass.  The kernel is bound by its gathers (the texture-address unit is 85-93 % busy, PMC), so every resident
+// sample is a gather saved in nine of ten passes: c5 slice 98 -> 67 ms with 48 of 201 RGB samples resident.
+// The counts are what two waves per SIMD hold (a few spilled registers included -- more residents still won);
+// one wave per SIMD with far more residents measured slower (profiles/r01_k2_variants.md).  Volumes with
+// fewer views than that take NRES = 0.
+__host__ __device__ constexpr int stream_resident(int C) { return C == 1 ? 112 : 48; }
+
+template <int C, bool BORDER, bool UNIFORM_D, int NRES>
 __device__ __forceinline__ void scan_stream_body(const ScanArgs& a, int v, int u, int d0, int d1, Best<C>& best,
                                                  float* __restrict__ otab)
 {
@@ -516,20 +525,100 @@ __device__ __forceinline__ void scan_stream_body(const ScanArgs& a, int v, int u
             rbar[c] = centre[c];                         // core.hpp:577
         float B = 0.0f;
         int card = BORDER ? 0 : S;
+        // resident prefix: samples [0, NRES) (the kernel picks NRES = 0 when S < stream_resident(C))
+        float Rres[C][NRES > 0 ? NRES : 1];
+        int card_res = 0;
+        if constexpr (NRES > 0) {
+            constexpr int GR = (C == 1) ? 8 : 4;
+            unsigned rowb = 0;
+#pragma unroll
+            for (int g = 0; g < NRES / GR; g++) {
+                float tt[GR], e0[C][GR], e1[C][GR];
+                bool ok[GR];
+#pragma unroll
+                for (int j = 0; j < GR; j++) {
+                    const int s = g * GR + j;
+                    float x;
+                    if (UNIFORM_D) {
+                        x = otab[s];
+                    } else {
+                        x = (float)(a.s_hat - s) * Dd;
+                        x = x * slope;
+                    }
+                    x = x + uf;
+                    tt[j] = lerp_weight(x);
+                    int i0 = floor_to_int(x);
+                    ok[j] = true;
+                    if (BORDER) {
+                        ok[j] = __float_as_uint(x) <= Um1_bits;
+                        i0 = ok[j] ? i0 : 0;
+                    }
+                    const float* p = (const float*)((const char*)epi + (((unsigned)(i0 * C) << 2) + rowb));
+                    rowb += stride_b;
+#pragma unroll
+                    for (int c = 0; c < C; c++) {
+                        e0[c][j] = p[c];
+                        e1[c][j] = p[C + c];
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < GR; j++) {
+                    const float omt = 1.0f - tt[j];
+#pragma unroll
+                    for (int c = 0; c < C; c++) {
+                        const float m0 = omt * e0[c][j];
+                        const float m1 = tt[j] * e1[c][j];
+                        const float r = m0 + m1;
+                        Rres[c][g * GR + j] = ok[j] ? r : kSentinel;
+                    }
+                    if (BORDER)
+                        card_res += ok[j] ? 1 : 0;
+                }
+#pragma unroll
+                for (int c = 0; c < C; c++)
+#pragma unroll
+                    for (int j = 0; j < GR; j++)
+                        asm volatile("" : "+v"(Rres[c][g * GR + j]));
+                asm volatile("" : "+s"(rowb));
+            }
+        }
         for (int it = 0; it < a.k.n_iter; it++) {        // core.hpp:584-610
             float A[C];
 #pragma unroll
             for (int c = 0; c < C; c++)
                 A[c] = 0.0f;
             B = 0.0f;
-            int ncard = 0;
-            unsigned rowb = 0;
+            int ncard = card_res;
+            if constexpr (NRES > 0)
+#pragma unroll
+            for (int s = 0; s < NRES; s++) {
+                float q[C];
+#pragma unroll
+                for (int c = 0; c < C; c++) {
+                    const float delta = Rres[c][s] - rbar[c];
+                    const float tq = kq * delta;
+                    q[c] = tq * delta;
+                }
+                float qs = q[0];
+                if (C == 3) {
+                    qs = q[0] + q[C - 1];
+                    qs = qs + q[C > 1 ? 1 : 0];
+                }
+                const float K = kernel_weight(qs);
+#pragma unroll
+                for (int c = 0; c < C; c++) {
+                    const float pr = Rres[c][s] * K;
+                    A[c] = A[c] + pr;
+                }
+                B = B + K;
+            }
+            unsigned rowb = (unsigned)NRES * stride_b;
             // G samples per trip, hand-unrolled: all G address computations and loads are issued before
             // the first blend, so G*C loads are in flight per wave (hipcc does not unroll this loop itself
             // and would otherwise wait for every single load).  Slots past S in the last trip are sentinels.
             constexpr int G = (C == 1) ? 8 : 4;
 #pragma unroll 1
-            for (int s0 = 0; s0 < S; s0 += G) {
+            for (int s0 = NRES; s0 < S; s0 += G) {
                 float tt[G], e0[C][G], e1[C][G];
                 bool ok[G];
 #pragma unroll
@@ -621,25 +710,30 @@ __device__ __forceinline__ bool wave_is_interior(const ScanArgs& a, int u)
     return __all((uf - reach >= 0.0f) && (uf + reach <= (float)(a.vol.U - 1)));
 }
 
-template <int C>
+template <int C, int NRES>
 __device__ __forceinline__ void scan_stream_rows(const ScanArgs& a, int v, int u, int d0, int d1, Best<C>& best, float* otab)
 {
     if (wave_is_interior(a, u))
-        scan_stream_body<C, false, true>(a, v, u, d0, d1, best, otab);
+        scan_stream_body<C, false, true, NRES>(a, v, u, d0, d1, best, otab);
     else if (!a.dmin_vu)
-        scan_stream_body<C, true, true>(a, v, u, d0, d1, best, otab);
+        scan_stream_body<C, true, true, NRES>(a, v, u, d0, d1, best, otab);
     else
-        scan_stream_body<C, true, false>(a, v, u, d0, d1, best, otab);
+        scan_stream_body<C, true, false, NRES>(a, v, u, d0, d1, best, otab);
 }
 
 template <int C>
-__global__ __launch_bounds__(64 * kScanWaves) void k2_scan_stream(ScanArgs a)
+__global__ __launch_bounds__(64 * kScanWaves) __attribute__((amdgpu_waves_per_eu(2, 8))) void k2_scan_stream(ScanArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float s_stream_otab[];   // [kScanWaves][S]
     float* otab = s_stream_otab + (size_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * a.vol.S;
     // packed tiles: lanes sit on different scanlines, offsets are per lane (the <true, false> body)
-    RSLF_SCAN_KERNEL_BODY((scan_stream_rows<C>(a, v, u, d0, d1, best, otab)),
-                          (scan_stream_body<C, true, false>(a, v, u, d0, d1, best, otab)))
+    if (a.vol.S >= stream_resident(C)) {
+        RSLF_SCAN_KERNEL_BODY((scan_stream_rows<C, stream_resident(C)>(a, v, u, d0, d1, best, otab)),
+                              (scan_stream_body<C, true, false, stream_resident(C)>(a, v, u, d0, d1, best, otab)))
+    } else {
+        RSLF_SCAN_KERNEL_BODY((scan_stream_rows<C, 0>(a, v, u, d0, d1, best, otab)),
+                              (scan_stream_body<C, true, false, 0>(a, v, u, d0, d1, best, otab)))
+    }
 }
 
 // ---------------------------------------------------------------------------
