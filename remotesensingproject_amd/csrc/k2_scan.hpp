@@ -66,6 +66,9 @@ struct ScanArgs {
     // the device knows how many there are.
     int packed;
     const int* packed_n;
+    // streaming kernel: samples per lane parked in LDS behind the register-resident prefix (a multiple of the
+    // gather batch; 0 = none), sized by the host to what the dynamic-LDS limit leaves after the offset table
+    int stream_park;
 };
 
 struct Partial {   // one lane's merged result over one group's hypotheses
@@ -582,6 +585,58 @@ __device__ __forceinline__ void scan_stream_body(const ScanArgs& a, int v, int u
                 asm volatile("" : "+s"(rowb));
             }
         }
+        // parked samples [NRES, NRES + npark): gathered once per hypothesis like the resident ones, kept in LDS
+        // ([sample][channel][lane], conflict-free) -- one LDS read instead of one gather per pass
+        const int npark = (NRES > 0) ? a.stream_park : 0;
+        float* park = otab + S;
+        if (NRES > 0 && npark > 0) {
+            constexpr int GP = (C == 1) ? 8 : 4;
+            unsigned rowb = (unsigned)NRES * stride_b;
+#pragma unroll 1
+            for (int s0 = NRES; s0 < NRES + npark; s0 += GP) {
+                float tt[GP], e0[C][GP], e1[C][GP];
+                bool ok[GP];
+#pragma unroll
+                for (int j = 0; j < GP; j++) {
+                    const int s = s0 + j;
+                    float x;
+                    if (UNIFORM_D) {
+                        x = otab[s];
+                    } else {
+                        x = (float)(a.s_hat - s) * Dd;
+                        x = x * slope;
+                    }
+                    x = x + uf;
+                    tt[j] = lerp_weight(x);
+                    int i0 = floor_to_int(x);
+                    ok[j] = true;
+                    if (BORDER) {
+                        ok[j] = __float_as_uint(x) <= Um1_bits;
+                        i0 = ok[j] ? i0 : 0;
+                    }
+                    const float* p = (const float*)((const char*)epi + (((unsigned)(i0 * C) << 2) + rowb));
+                    rowb += stride_b;
+#pragma unroll
+                    for (int c = 0; c < C; c++) {
+                        e0[c][j] = p[c];
+                        e1[c][j] = p[C + c];
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < GP; j++) {
+                    const float omt = 1.0f - tt[j];
+#pragma unroll
+                    for (int c = 0; c < C; c++) {
+                        const float m0 = omt * e0[c][j];
+                        const float m1 = tt[j] * e1[c][j];
+                        const float r = m0 + m1;
+                        park[((s0 - NRES + j) * C + c) * 64 + lane] = ok[j] ? r : kSentinel;
+                    }
+                    if (BORDER)
+                        card_res += ok[j] ? 1 : 0;
+                }
+            }
+        }
         for (int it = 0; it < a.k.n_iter; it++) {        // core.hpp:584-610
             float A[C];
 #pragma unroll
@@ -612,13 +667,47 @@ __device__ __forceinline__ void scan_stream_body(const ScanArgs& a, int v, int u
                 }
                 B = B + K;
             }
-            unsigned rowb = (unsigned)NRES * stride_b;
+            if (NRES > 0 && npark > 0) {
+                constexpr int GP = (C == 1) ? 8 : 4;
+#pragma unroll 1
+                for (int sp = 0; sp < npark; sp += GP) {
+                    float Rp[C][GP];
+#pragma unroll
+                    for (int j = 0; j < GP; j++)
+#pragma unroll
+                        for (int c = 0; c < C; c++)
+                            Rp[c][j] = park[((sp + j) * C + c) * 64 + lane];
+#pragma unroll
+                    for (int j = 0; j < GP; j++) {
+                        float q[C];
+#pragma unroll
+                        for (int c = 0; c < C; c++) {
+                            const float delta = Rp[c][j] - rbar[c];
+                            const float tq = kq * delta;
+                            q[c] = tq * delta;
+                        }
+                        float qs = q[0];
+                        if (C == 3) {
+                            qs = q[0] + q[C - 1];
+                            qs = qs + q[C > 1 ? 1 : 0];
+                        }
+                        const float K = kernel_weight(qs);
+#pragma unroll
+                        for (int c = 0; c < C; c++) {
+                            const float pr = Rp[c][j] * K;
+                            A[c] = A[c] + pr;
+                        }
+                        B = B + K;
+                    }
+                }
+            }
+            unsigned rowb = (unsigned)(NRES + npark) * stride_b;
             // G samples per trip, hand-unrolled: all G address computations and loads are issued before
             // the first blend, so G*C loads are in flight per wave (hipcc does not unroll this loop itself
             // and would otherwise wait for every single load).  Slots past S in the last trip are sentinels.
             constexpr int G = (C == 1) ? 8 : 4;
 #pragma unroll 1
-            for (int s0 = NRES; s0 < S; s0 += G) {
+            for (int s0 = NRES + npark; s0 < S; s0 += G) {
                 float tt[G], e0[C][G], e1[C][G];
                 bool ok[G];
 #pragma unroll
@@ -724,8 +813,8 @@ __device__ __forceinline__ void scan_stream_rows(const ScanArgs& a, int v, int u
 template <int C>
 __global__ __launch_bounds__(64 * kScanWaves) __attribute__((amdgpu_waves_per_eu(2, 8))) void k2_scan_stream(ScanArgs a)
 {
-    extern __shared__ __attribute__((aligned(16))) float s_stream_otab[];   // [kScanWaves][S]
-    float* otab = s_stream_otab + (size_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * a.vol.S;
+    extern __shared__ __attribute__((aligned(16))) float s_stream_otab[];   // [kScanWaves][S + stream_park * C * 64]
+    float* otab = s_stream_otab + (size_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * (a.vol.S + a.stream_park * C * 64);
     // packed tiles: lanes sit on different scanlines, offsets are per lane (the <true, false> body)
     if (a.vol.S >= stream_resident(C)) {
         RSLF_SCAN_KERNEL_BODY((scan_stream_rows<C, stream_resident(C)>(a, v, u, d0, d1, best, otab)),

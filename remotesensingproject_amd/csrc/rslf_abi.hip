@@ -893,6 +893,7 @@ extern "C" int rslf_depth_epi_scan(rslf_ctx* ctx, const rslf_volume* vol, const 
     a.groups = groups;
     a.packed = packed ? 1 : 0;
     a.packed_n = packed_n;
+    a.stream_park = 0;
     a.partial = nullptr;
     if (groups > 1) {
         const size_t recs = (size_t)tiles * groups * 64;
@@ -940,7 +941,20 @@ extern "C" int rslf_depth_epi_scan(rslf_ctx* ctx, const rslf_volume* vol, const 
             return rc;
     } else if (stream_ok) {
         // too many samples for the register file: re-gather every pass (k2_scan_stream)
-        const size_t lds = (size_t)kScanWaves * vol->S * sizeof(float);
+        // LDS per wave: the S view offsets + the parked samples; as many batches of parked samples as the 64 KiB
+        // of dynamic LDS leave room for (and never past the end of the views)
+        const int batch = vol->C == 1 ? 8 : 4;
+        const int nres = stream_resident(vol->C);
+        int park = 0;
+        if (vol->S >= nres) {
+            const size_t room = ((size_t)64 << 10) / kScanWaves / sizeof(float);   // floats per wave
+            if (room > (size_t)vol->S)
+                park = (int)((room - vol->S) / ((size_t)vol->C * 64));
+            park = std::min(park, vol->S - nres);
+            park -= park % batch;
+        }
+        a.stream_park = park;
+        const size_t lds = (size_t)kScanWaves * ((size_t)vol->S + (size_t)park * vol->C * 64) * sizeof(float);
         if (vol->C == 1)
             hipLaunchKernelGGL(k2_scan_stream<1>, grid, dim3(64 * kScanWaves), lds, st, a);
         else
