@@ -929,6 +929,12 @@ extern "C" int rslf_depth_epi_scan(rslf_ctx* ctx, const rslf_volume* vol, const 
         stream_ok = false;
     } else if (force && strcmp(force, "stream") == 0) {
         spad = 0;
+    } else if (spad && stream_ok && vol->C == 3 && vol->S > 48 && vol->S <= 76) {
+        // RGB with 49..76 views: the register variant needs one wave per SIMD (packed math, 45-46 TFLOP/s); the
+        // streaming kernel holds 48 samples in registers and the rest in LDS at two waves per SIMD -- nothing is
+        // re-gathered, and it runs at 51-55 TFLOP/s (profiles/r01_k2_variants.md).  From ~80 views on the
+        // register variant wins again.
+        spad = 0;
     }
 
     HIP_TRY(hipGetLastError());   // anything an earlier enqueue left behind is not this launch's fault
