@@ -165,6 +165,8 @@ def test_stream_kernel_per_pixel_ranges(rs, oracle_mod, monkeypatch):
     (16, None, 1, 12, 64, 31),       # more groups than D allows: halved until every slice has work
     (2, None, 3, 88, 100, 16),       # one-wave-per-SIMD variants (packed fp32 math) under both tile forms
     (2, None, 1, 210, 80, 16),
+    (2, "stream", 3, 60, 100, 16),   # streaming kernel with its resident prefix + parked samples, both tile forms
+    (2, "stream", 1, 130, 80, 16),
 ])
 def test_sparse_launch_shapes(rs, oracle_mod, monkeypatch, packed, groups, force, C_, S, U, D):
     """Sparse visits of the 2-D sweep split each tile's hypotheses over several workgroups (records merged
