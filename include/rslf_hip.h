@@ -109,7 +109,7 @@ typedef struct rslf_stats {
 
 #define RSLF_SCAN_GENERIC   0  /* any S, C in {1,3}, any sign: re-gathers every mean-shift pass */
 #define RSLF_SCAN_STREAM    2  /* volume >= 0, any S: a resident prefix of the samples (registers + LDS), the rest re-gathered every pass */
-#define RSLF_SCAN_REG       1  /* volume >= 0 and C=1, S<=256 or C=3, S<=48 / 77..104: samples held in VGPRs/AGPRs */
+#define RSLF_SCAN_REG       1  /* volume >= 0 and C=1, S<=192 or C=3, S<=48: every sample held in registers */
 
 int         rslf_abi_version(void);
 const char* rslf_status_string(int status);

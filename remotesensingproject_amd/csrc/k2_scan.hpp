@@ -485,10 +485,17 @@ __global__ __launch_bounds__(256) void k2_kernel_column(ScanArgs a, const int32_
 // over the mean-shift passes (as in the register variant); only the samples behind them are re-gathered every
 // pass.  The kernel is bound by its gathers (the texture-address unit is 85-93 % busy, PMC), so every resident
 // sample is a gather saved in nine of ten passes: c5 slice 98 -> 67 ms with 48 of 201 RGB samples resident.
-// The counts are what two waves per SIMD hold (a few spilled registers included -- more residents still won);
-// one wave per SIMD with far more residents measured slower (profiles/r01_k2_variants.md).  Volumes with
-// fewer views than that take NRES = 0.
-__host__ __device__ constexpr int stream_resident(int C) { return C == 1 ? 112 : 48; }
+// One wave per SIMD with far more residents measured slower.  Volumes with fewer views than the shortest prefix
+// take NRES = 0.
+// Resident-prefix lengths compiled in: the largest one not above S is used.  They exceed what the registers of
+// two waves per SIMD hold -- the compiler keeps the overflow in scratch, whose per-lane accesses are coalesced and
+// far cheaper than a gather (measured: more residents won up to these counts, profiles/r01_k2_variants.md).
+__host__ __device__ constexpr int stream_resident_hi(int C) { return C == 1 ? 192 : 64; }
+__host__ __device__ constexpr int stream_resident_lo(int C) { return C == 1 ? 0 : 48; }
+__host__ __device__ constexpr int stream_resident_for(int S, int C)
+{
+    return S >= stream_resident_hi(C) ? stream_resident_hi(C) : (stream_resident_lo(C) > 0 && S >= stream_resident_lo(C)) ? stream_resident_lo(C) : 0;
+}
 
 template <int C, bool BORDER, bool UNIFORM_D, int NRES>
 __device__ __forceinline__ void scan_stream_body(const ScanArgs& a, int v, int u, int d0, int d1, Best<C>& best,
@@ -528,7 +535,7 @@ __device__ __forceinline__ void scan_stream_body(const ScanArgs& a, int v, int u
             rbar[c] = centre[c];                         // core.hpp:577
         float B = 0.0f;
         int card = BORDER ? 0 : S;
-        // resident prefix: samples [0, NRES) (the kernel picks NRES = 0 when S < stream_resident(C))
+        // resident prefix: samples [0, NRES) (the kernel picks NRES = stream_resident_for(S, C))
         float Rres[C][NRES > 0 ? NRES : 1];
         int card_res = 0;
         if constexpr (NRES > 0) {
@@ -816,9 +823,12 @@ __global__ __launch_bounds__(64 * kScanWaves) __attribute__((amdgpu_waves_per_eu
     extern __shared__ __attribute__((aligned(16))) float s_stream_otab[];   // [kScanWaves][S + stream_park * C * 64]
     float* otab = s_stream_otab + (size_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * (a.vol.S + a.stream_park * C * 64);
     // packed tiles: lanes sit on different scanlines, offsets are per lane (the <true, false> body)
-    if (a.vol.S >= stream_resident(C)) {
-        RSLF_SCAN_KERNEL_BODY((scan_stream_rows<C, stream_resident(C)>(a, v, u, d0, d1, best, otab)),
-                              (scan_stream_body<C, true, false, stream_resident(C)>(a, v, u, d0, d1, best, otab)))
+    if (a.vol.S >= stream_resident_hi(C)) {
+        RSLF_SCAN_KERNEL_BODY((scan_stream_rows<C, stream_resident_hi(C)>(a, v, u, d0, d1, best, otab)),
+                              (scan_stream_body<C, true, false, stream_resident_hi(C)>(a, v, u, d0, d1, best, otab)))
+    } else if (stream_resident_lo(C) > 0 && a.vol.S >= stream_resident_lo(C)) {
+        RSLF_SCAN_KERNEL_BODY((scan_stream_rows<C, stream_resident_lo(C)>(a, v, u, d0, d1, best, otab)),
+                              (scan_stream_body<C, true, false, stream_resident_lo(C)>(a, v, u, d0, d1, best, otab)))
     } else {
         RSLF_SCAN_KERNEL_BODY((scan_stream_rows<C, 0>(a, v, u, d0, d1, best, otab)),
                               (scan_stream_body<C, true, false, 0>(a, v, u, d0, d1, best, otab)))

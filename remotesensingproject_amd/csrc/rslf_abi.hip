@@ -747,16 +747,16 @@ extern "C" int rslf_selective_median(rslf_ctx* ctx, const rslf_volume* vol, cons
     return RSLF_OK;
 }
 
-// Register-variant slot counts compiled into this library (multiples of 8), per channel count.
-// C*SPAD + working registers must fit the 512 (256 VGPR + 256 AGPR) a lane can own without scratch:
-// C=1 up to 256 slots (2 waves/SIMD up to 192, then 1), C=3 up to 104 slots (1 wave/SIMD from 56 on;
-// 112 and more spill to scratch and lose to the generic kernel, so they are not built).
+// Register-variant slot counts compiled into this library (multiples of 8), per channel count: those that run at
+// two or more waves per SIMD (C*SPAD + working registers <= 256).  Beyond them -- C=1 above 192 views, RGB above 48
+// -- the streaming kernel with its resident prefix is faster than a one-wave register variant (55-61 vs 44-47
+// TFLOP/s, profiles/r01_k2_variants.md), so none is built.
 #ifndef RSLF_SPAD_LIST_1CH
 #define RSLF_SPAD_LIST_1CH(X) X(8) X(16) X(24) X(32) X(40) X(48) X(56) X(64) X(72) X(80) X(88) X(96) X(104) X(112) X(120) X(128) \
-    X(144) X(160) X(176) X(192) X(208) X(224) X(240) X(256)
+    X(144) X(160) X(176) X(192)
 #endif
 #ifndef RSLF_SPAD_LIST_3CH
-#define RSLF_SPAD_LIST_3CH(X) X(8) X(16) X(24) X(32) X(40) X(48) X(56) X(64) X(72) X(80) X(88) X(96) X(104)
+#define RSLF_SPAD_LIST_3CH(X) X(8) X(16) X(24) X(32) X(40) X(48)
 #endif
 
 static int launch_scan_reg(int spad, int C, const ScanArgs& a, dim3 grid, hipStream_t stream)
@@ -929,12 +929,6 @@ extern "C" int rslf_depth_epi_scan(rslf_ctx* ctx, const rslf_volume* vol, const 
         stream_ok = false;
     } else if (force && strcmp(force, "stream") == 0) {
         spad = 0;
-    } else if (spad && stream_ok && vol->C == 3 && vol->S > 48 && vol->S <= 76) {
-        // RGB with 49..76 views: the register variant needs one wave per SIMD (packed math, 45-46 TFLOP/s); the
-        // streaming kernel holds 48 samples in registers and the rest in LDS at two waves per SIMD -- nothing is
-        // re-gathered, and it runs at 51-55 TFLOP/s (profiles/r01_k2_variants.md).  From ~80 views on the
-        // register variant wins again.
-        spad = 0;
     }
 
     HIP_TRY(hipGetLastError());   // anything an earlier enqueue left behind is not this launch's fault
@@ -950,9 +944,9 @@ extern "C" int rslf_depth_epi_scan(rslf_ctx* ctx, const rslf_volume* vol, const 
         // LDS per wave: the S view offsets + the parked samples; as many batches of parked samples as the 64 KiB
         // of dynamic LDS leave room for (and never past the end of the views)
         const int batch = vol->C == 1 ? 8 : 4;
-        const int nres = stream_resident(vol->C);
+        const int nres = stream_resident_for(vol->S, vol->C);
         int park = 0;
-        if (vol->S >= nres) {
+        if (nres > 0) {
             const size_t room = ((size_t)64 << 10) / kScanWaves / sizeof(float);   // floats per wave
             if (room > (size_t)vol->S)
                 park = (int)((room - vol->S) / ((size_t)vol->C * 64));
