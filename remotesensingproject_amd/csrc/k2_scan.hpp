@@ -472,14 +472,13 @@ __global__ __launch_bounds__(256) void k2_kernel_column(ScanArgs a, const int32_
 }
 
 // ---------------------------------------------------------------------------
-// Streaming variant: any S, C in {1,3}, radiances in [0, 1e6].  For shapes whose samples do not
-// fit the register file (C = 1 beyond 256 views, RGB beyond 104 -- BASELINE.json's 201-view RGB
-// config).  Like the generic kernel it re-gathers the samples on every mean-shift pass, but with the
-// register variant's economies: hypothesis-uniform view offsets come from an LDS table (one
-// broadcast read per sample), validity is one unsigned compare, invalid samples are the 1e30
-// sentinel (K = 0, P = 0 exactly), K is one clamp instruction, and four samples are in flight.
-// Per (sample, pass): ~9 + 3C gather and 7 / 19 mean-shift instructions; the 2C-float loads per
-// sample make it L1-bandwidth bound at about half the register variant's rate.
+// Streaming variant: any S, C in {1,3}, radiances in [0, 1e6].  For view counts beyond the register variants
+// (C = 1 above 192 views, RGB above 48 -- 100-view RGB fields, BASELINE.json's 201-view RGB config).  A unit's
+// samples are split three ways: a resident prefix held in registers (and compiler scratch) over the passes,
+// samples parked in LDS behind it, and a tail that is re-gathered on every mean-shift pass with the register
+// variant's economies: hypothesis-uniform view offsets from an LDS table (one broadcast read per sample),
+// validity as one unsigned compare, invalid samples as the 1e30 sentinel (K = 0, P = 0 exactly), K as one
+// clamp instruction, four / eight samples in flight.  The re-gathered tail is what costs.
 // ---------------------------------------------------------------------------
 // Resident prefix: the first NRES samples of a unit are gathered ONCE per hypothesis and stay in registers
 // over the mean-shift passes (as in the register variant); only the samples behind them are re-gathered every
