@@ -867,7 +867,9 @@ template <int SPAD, int C, bool BORDER, bool UNIFORM_D, bool PK>
 __device__ __forceinline__ void scan_reg_body(const ScanArgs& a, int v, int u, int d0, int d1, Best<C>& best,
                                               float* __restrict__ otab)
 {
-    constexpr int kGatherBatch = gather_batch(C);
+    // 104 slots (the c3 shape) have 15 registers to spare at three waves per SIMD: 13 loads in flight instead of 8
+    // (8 batches instead of 13 per hypothesis) measured 0.5 % faster
+    constexpr int kGatherBatch = (C == 1 && !PK && SPAD == 104) ? 13 : gather_batch(C);
     static_assert(SPAD % 8 == 0, "slot counts are multiples of 8");
     const VolView& vol = a.vol;
     const float* epi = vol.row(v, 0);
@@ -1002,6 +1004,10 @@ __device__ __forceinline__ void scan_reg_body(const ScanArgs& a, int v, int u, i
                         asm volatile("" : "+v"(R2[c][b / 2]), "+v"(R2[c][b / 2 + 1]));
                         if (kGatherBatch == 8)
                             asm volatile("" : "+v"(R2[c][b / 2 + 2]), "+v"(R2[c][b / 2 + 3]));
+                    } else if (kGatherBatch == 13) {
+#pragma unroll
+                        for (int j = 0; j < kGatherBatch; j++)
+                            asm volatile("" : "+v"(R[c][b + j]));
                     } else {
                         asm volatile("" : "+v"(R[c][b + 0]), "+v"(R[c][b + 1]), "+v"(R[c][b + 2]), "+v"(R[c][b + 3]));
                         if (kGatherBatch == 8)
