@@ -215,6 +215,9 @@ def main() -> None:
         # synthetic light field: every rank draws the same textures and keeps its scanlines (+halo)
         host, _ = make_lightfield(U, V, S, C, seed=cfg["seed"], dmin=cfg["dmin"], dmax=cfg["dmax"], rows=shard.rows)
     ctx = rs.default_context(dev)
+    if os.environ.get("RSLF_BENCH_HOOKS"):   # developer A/B runs only, e.g. "stage=0,groups=8,lds=64" (never a result)
+        names = {"share": "stream_share", "groups": "stream_groups", "lds": "stream_lds_kib"}
+        ctx.set_debug(**{names.get(k, k): int(v) for k, v in (kv.split("=") for kv in os.environ["RSLF_BENCH_HOOKS"].split(",")) if not k.startswith("_")})
     vol = rs.Volume.from_dense(torch.from_numpy(host).to(dev), 1.0, ctx)
     del host
     comp = rs.Depth1DComputer_pile(vol, cfg["dmin"], cfg["dmax"], D, parameters=params)

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define RSLF_ABI_VERSION 3
+#define RSLF_ABI_VERSION 4
 
 typedef enum rslf_status {
     RSLF_OK = 0,
@@ -123,6 +123,15 @@ int rslf_ctx_create(int device, rslf_ctx** out);
 int rslf_ctx_destroy(rslf_ctx* ctx);
 int rslf_ctx_set_stream(rslf_ctx* ctx, void* hip_stream);   /* NULL = default stream */
 int rslf_ctx_synchronize(rslf_ctx* ctx);
+/* Test and tuning hooks of ONE context (nothing process-global, no environment variable is read):
+ *   "force_scan"     0 automatic | 1 generic scan kernel | 2 streaming scan kernel
+ *   "force_groups"   0 automatic | 1..64 hypothesis groups per tile
+ *   "force_packed"   -1 automatic | 0 row tiles | 1 one packed pixel list
+ *   "stream_share"   1 (default) 63-pixel tiles sharing taps between lanes in the streaming kernel | 0 off
+ *   "stream_groups"  0 automatic | hypothesis groups per tile of the streaming kernel's dense launches
+ *   "stream_lds_kib" dynamic LDS of one streaming workgroup, KiB (default 72)
+ * Results never depend on these (the parity tests drive every combination); speed does. */
+int rslf_ctx_set_debug(rslf_ctx* ctx, const char* key, int value);
 
 /* ---- volume: replaces Depth1DComputer_pile's constructor --------------- */
 /* include/rslf_depth_computation.hpp:425-477: the constructor copies the

@@ -12,12 +12,12 @@ from . import build as _build
 
 _LIB = None
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # every symbol include/rslf_hip.h declares
 SYMBOLS = [
     "rslf_abi_version", "rslf_status_string", "rslf_last_error", "rslf_device_count", "rslf_default_params",
-    "rslf_ctx_create", "rslf_ctx_destroy", "rslf_ctx_set_stream", "rslf_ctx_synchronize",
+    "rslf_ctx_create", "rslf_ctx_destroy", "rslf_ctx_set_stream", "rslf_ctx_synchronize", "rslf_ctx_set_debug",
     "rslf_volume_create", "rslf_volume_destroy", "rslf_volume_describe",
     "rslf_volume_upload_epis_f32", "rslf_volume_upload_epis_u8",
     "rslf_volume_upload_images_f32", "rslf_volume_upload_images_u8", "rslf_volume_pack_device_f32",
@@ -113,6 +113,7 @@ def lib():
     L.rslf_ctx_create.argtypes = [ci, C.POINTER(vp)]
     L.rslf_ctx_destroy.argtypes = [vp]
     L.rslf_ctx_set_stream.argtypes = [vp, vp]
+    L.rslf_ctx_set_debug.argtypes = [vp, C.c_char_p, C.c_int]
     L.rslf_ctx_synchronize.argtypes = [vp]
     L.rslf_volume_create.argtypes = [vp, ci, ci, ci, ci, C.POINTER(vp)]
     L.rslf_volume_destroy.argtypes = [vp]

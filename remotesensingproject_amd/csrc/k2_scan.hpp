@@ -28,6 +28,8 @@
 // memory instruction.
 #pragma once
 
+#include <type_traits>
+
 #include "rslf_device.hpp"
 
 namespace rslf {
@@ -50,7 +52,8 @@ struct ScanArgs {
     float* rbar;            // [V][U][C]
     int32_t* idx;           // nullable
     float* score;           // nullable
-    int tiles_per_row;      // ceil(U / 64)
+    int tile_w;             // list entries per row tile: 64, or 63 where lane 63 only carries its neighbour's right tap
+    int tiles_per_row;      // ceil(U / tile_w)
     int logical_blocks;     // V * tiles_per_row * groups
     int per_xcd;            // ceil(logical_blocks / 8)
     // Hypothesis groups: `groups` workgroups share one tile, each taking a contiguous slice of the
@@ -60,6 +63,7 @@ struct ScanArgs {
     // them in hypothesis order.
     int groups;
     struct Partial* partial;   // [tile][group][64]
+    int v0;                    // row tiles: first scanline of this launch (grouped dense launches go by row blocks)
     // Packed tiles (sparse launches): `list` is ONE list of pixel indices v*U + u over all scanlines,
     // *packed_n long, and a tile is 64 consecutive entries of it -- lanes of a wave then sit on different
     // scanlines.  The grid is fixed and every workgroup strides over the (tile, group) items, because only
@@ -69,6 +73,11 @@ struct ScanArgs {
     // streaming kernel: samples per lane parked in LDS behind the register-resident prefix (a multiple of the
     // gather batch; 0 = none), sized by the host to what the dynamic-LDS limit leaves after the offset table
     int stream_park;
+    // streaming kernel: floats of dynamic LDS per wave = [view offsets, S rounded up to 4][parked samples]
+    int stream_wave_floats;
+    // streaming kernel, shared-tap tail: a view offset whose fraction is above this could round a position up to
+    // the next integer in some lanes and not in others (1 - ulp of the largest position, host-computed)
+    float stream_frac_max;
 };
 
 struct Partial {   // one lane's merged result over one group's hypotheses
@@ -119,15 +128,16 @@ __device__ __forceinline__ bool scan_tile(const ScanArgs& a, int lb, int& v, int
     if (lb >= a.logical_blocks)
         return false;
     const int tile = lb / a.groups;
-    v = tile / a.tiles_per_row;
-    const int j = tile - v * a.tiles_per_row;
+    const int vr = tile / a.tiles_per_row;
+    const int j = tile - vr * a.tiles_per_row;
+    v = vr + a.v0;
     const int n = a.count[v];
-    if (j * 64 >= n)
+    if (j * a.tile_w >= n)
         return false;
-    const int e = j * 64 + lane;
-    active = e < n;
-    // idle lanes of a scanline's last tile shadow its last pixel so their addresses stay valid
-    u = a.list[(long long)v * a.vol.U + (active ? e : n - 1)];
+    const int e = j * a.tile_w + lane;
+    active = lane < a.tile_w && e < n;
+    // idle lanes shadow the tile's last pixel so their addresses stay valid
+    u = a.list[(long long)v * a.vol.U + (active ? e : min(j * a.tile_w + a.tile_w, n) - 1)];
     return true;
 }
 
@@ -216,7 +226,9 @@ __device__ __forceinline__ void scan_epilogue(const ScanArgs& a, int lb, int v, 
     for (int w = 1; w < kScanWaves; w++) {
         const float sc = s_score[w][lane];
         sum += s_sum[w][lane];
-        if (sc > best) {   // a wave that scored nothing holds -1 and never wins
+        // first maximum in hypothesis order: the lower wave holds the lower hypotheses (the index settles a tie
+        // all the same).  A wave that scored nothing holds -1 and never wins
+        if (sc > best || (sc == best && s_d[w][lane] < best_d)) {
             best = sc;
             best_d = s_d[w][lane];
             best_D = s_D[w][lane];
@@ -283,11 +295,12 @@ __global__ __launch_bounds__(64) void k2_scan_combine(ScanArgs a)
         return;
     }
     const int tile = blockIdx.x;
-    const int v = tile / a.tiles_per_row;
-    const int j = tile - v * a.tiles_per_row;
+    const int vr = tile / a.tiles_per_row;
+    const int j = tile - vr * a.tiles_per_row;
+    const int v = vr + a.v0;
     const int n = a.count[v];
-    const int e = j * 64 + (int)threadIdx.x;
-    if (e >= n)
+    const int e = j * a.tile_w + (int)threadIdx.x;
+    if ((int)threadIdx.x >= a.tile_w || e >= n)
         return;
     combine_tile<C>(a, tile, v, a.list[(long long)v * a.vol.U + e]);
 }
@@ -409,7 +422,9 @@ __device__ __forceinline__ void scan_generic_body(const ScanArgs& a, int v, int 
 // in scanline order.  Packed tiles: a fixed grid strides over the items the device-side count yields;
 // every wave of a workgroup makes the same trips, and the barrier separates one item's merge in LDS
 // from the next item's.
-#define RSLF_SCAN_PACKED_LOOP(PACKED_CALL)                                               \
+#define RSLF_SCAN_PACKED_LOOP(PACKED_CALL) RSLF_SCAN_PACKED_LOOP_(scan_chunk, PACKED_CALL)
+#define RSLF_SCAN_ROW_TILE(ROWS_CALL) RSLF_SCAN_ROW_TILE_(scan_chunk, ROWS_CALL)
+#define RSLF_SCAN_PACKED_LOOP_(CHUNK, PACKED_CALL)                                      \
     {                                                                                   \
         Best<C> best;                                                                   \
         int v, u, d0, d1;                                                               \
@@ -418,14 +433,14 @@ __device__ __forceinline__ void scan_generic_body(const ScanArgs& a, int v, int 
         const int items = ((n + 63) >> 6) * a.groups;                                   \
         for (int item = blockIdx.x; item < items; item += gridDim.x) {                  \
             scan_tile_packed(a, item, n, v, u, active);                                 \
-            scan_chunk(a, item % a.groups, d0, d1);                                     \
+            CHUNK(a, item % a.groups, d0, d1);                                          \
             best.init();                                                                \
             PACKED_CALL;                                                                \
             scan_epilogue<C>(a, item, v, u, active, best);                              \
             __syncthreads();                                                            \
         }                                                                               \
     }
-#define RSLF_SCAN_ROW_TILE(ROWS_CALL)                                                   \
+#define RSLF_SCAN_ROW_TILE_(CHUNK, ROWS_CALL)                                           \
     {                                                                                   \
         Best<C> best;                                                                   \
         int v, u, d0, d1;                                                               \
@@ -433,17 +448,18 @@ __device__ __forceinline__ void scan_generic_body(const ScanArgs& a, int v, int 
         const int lb = xcd_logical_block(blockIdx.x, a.per_xcd);                        \
         if (!scan_tile(a, lb, v, u, active))                                            \
             return;                                                                     \
-        scan_chunk(a, lb % a.groups, d0, d1);                                           \
+        CHUNK(a, lb % a.groups, d0, d1);                                                \
         best.init();                                                                    \
         ROWS_CALL;                                                                      \
         scan_epilogue<C>(a, lb, v, u, active, best);                                    \
     }
-#define RSLF_SCAN_KERNEL_BODY(ROWS_CALL, PACKED_CALL)                                   \
+#define RSLF_SCAN_KERNEL_BODY_(CHUNK, ROWS_CALL, PACKED_CALL)                           \
     if (a.packed) {                                                                     \
-        RSLF_SCAN_PACKED_LOOP(PACKED_CALL)                                              \
+        RSLF_SCAN_PACKED_LOOP_(CHUNK, PACKED_CALL)                                      \
         return;                                                                         \
     }                                                                                   \
-    RSLF_SCAN_ROW_TILE(ROWS_CALL)
+    RSLF_SCAN_ROW_TILE_(CHUNK, ROWS_CALL)
+#define RSLF_SCAN_KERNEL_BODY(ROWS_CALL, PACKED_CALL) RSLF_SCAN_KERNEL_BODY_(scan_chunk, ROWS_CALL, PACKED_CALL)
 
 template <int C>
 __global__ __launch_bounds__(64 * kScanWaves) void k2_scan_generic(ScanArgs a)
@@ -489,17 +505,35 @@ __global__ __launch_bounds__(256) void k2_kernel_column(ScanArgs a, const int32_
 // Resident-prefix lengths compiled in: the largest one not above S is used.  They exceed what the registers of
 // two waves per SIMD hold -- the compiler keeps the overflow in scratch, whose per-lane accesses are coalesced and
 // far cheaper than a gather (measured: more residents won up to these counts, profiles/r01_k2_variants.md).
-__host__ __device__ constexpr int stream_resident_hi(int C) { return C == 1 ? 192 : 64; }
+#ifndef RSLF_STREAM_WAVES
+#define RSLF_STREAM_WAVES 2   // waves per SIMD the streaming kernel is compiled for
+#endif
+#ifndef RSLF_STREAM_GS
+#define RSLF_STREAM_GS 8      // samples per batch of the shared-tap tail (a multiple of 4)
+#endif
+#ifndef RSLF_STREAM_NRES_RGB
+#define RSLF_STREAM_NRES_RGB 64
+#endif
+#ifndef RSLF_STREAM_NRES_1CH
+#define RSLF_STREAM_NRES_1CH 192
+#endif
+__host__ __device__ constexpr int stream_resident_hi(int C) { return C == 1 ? RSLF_STREAM_NRES_1CH : RSLF_STREAM_NRES_RGB; }
 __host__ __device__ constexpr int stream_resident_lo(int C) { return C == 1 ? 0 : 48; }
 __host__ __device__ constexpr int stream_resident_for(int S, int C)
 {
     return S >= stream_resident_hi(C) ? stream_resident_hi(C) : (stream_resident_lo(C) > 0 && S >= stream_resident_lo(C)) ? stream_resident_lo(C) : 0;
 }
 
-template <int C, bool BORDER, bool UNIFORM_D, int NRES>
+// DENSE: the tile is 63 consecutive pixels of one scanline in lanes 0..62 and lane 63 stands on the pixel after them
+// (scan_stream_rows): a lane's right tap is then its neighbour's left tap, so the re-gathered tail loads ONE texel
+// per lane and sample and takes the other from lane + 1 (v_mov_b32 wave_shl:1) -- half the vector-memory
+// instructions of the tail, which is what bounds it (the CU's texture data path takes ~17 clocks per multi-dword
+// wave-instruction whatever its width, tools/ubench_ta.hip; PMC: TD_BUSY 90 %).
+template <int C, bool BORDER, bool UNIFORM_D, int NRES, bool DENSE = false>
 __device__ __forceinline__ void scan_stream_body(const ScanArgs& a, int v, int u, int d0, int d1, Best<C>& best,
                                                  float* __restrict__ otab)
 {
+    static_assert(!DENSE || (UNIFORM_D && !BORDER), "shared taps need a common hypothesis grid and no border lane");
     const VolView& vol = a.vol;
     const float* epi = vol.row(v, 0);
     const float uf = (float)u;
@@ -521,12 +555,21 @@ __device__ __forceinline__ void scan_stream_body(const ScanArgs& a, int v, int u
 
     for (int d = d0; d < d1; d++) {
         const float Dd = hypothesis(dmin, range, denom, d);
+        bool shared_taps = false;
         if (UNIFORM_D) {
+            bool odd = false;
             for (int s = lane; s < S; s += 64) {
                 float off = (float)(a.s_hat - s) * Dd;   // core.hpp:542,550
-                otab[s] = off * slope;                   // core.hpp:551
+                off = off * slope;                       // core.hpp:551
+                otab[s] = off;
+                // positions are off + (integer u): all lanes floor alike unless the sum rounds up to the next
+                // integer in some of them, which takes a fraction within one ulp of 1
+                if (DENSE)
+                    odd |= __builtin_amdgcn_fractf(off) > a.stream_frac_max;
             }
             __builtin_amdgcn_wave_barrier();
+            if (DENSE)
+                shared_taps = !__any(odd);               // wave-uniform, per hypothesis
         }
         float rbar[C];
 #pragma unroll
@@ -594,7 +637,7 @@ __device__ __forceinline__ void scan_stream_body(const ScanArgs& a, int v, int u
         // parked samples [NRES, NRES + npark): gathered once per hypothesis like the resident ones, kept in LDS
         // ([sample][channel][lane], conflict-free) -- one LDS read instead of one gather per pass
         const int npark = (NRES > 0) ? a.stream_park : 0;
-        float* park = otab + S;
+        float* park = otab + ((S + 3) & ~3);
         if (NRES > 0 && npark > 0) {
             constexpr int GP = (C == 1) ? 8 : 4;
             unsigned rowb = (unsigned)NRES * stride_b;
@@ -707,38 +750,42 @@ __device__ __forceinline__ void scan_stream_body(const ScanArgs& a, int v, int u
                     }
                 }
             }
-            unsigned rowb = (unsigned)(NRES + npark) * stride_b;
-            // G samples per trip, hand-unrolled: all G address computations and loads are issued before
-            // the first blend, so G*C loads are in flight per wave (hipcc does not unroll this loop itself
-            // and would otherwise wait for every single load).  Slots past S in the last trip are sentinels.
+            // The re-gathered tail, G samples per batch: all G address computations and loads are issued before the
+            // first blend.  The wave's instruction stream is what this tail costs (two waves per SIMD: a wave gets an
+            // issue slot every ~4.4 clocks whatever the instruction, PMC in DESIGN.md), so the loop is kept lean: the
+            // G view offsets of a batch come from ONE broadcast LDS read issued a batch ahead, the gather address is
+            // one v_mad_u32_u24 off a scalar row offset, and only the last, partial batch tests for slots past S.
             constexpr int G = (C == 1) ? 8 : 4;
-#pragma unroll 1
-            for (int s0 = NRES + npark; s0 < S; s0 += G) {
+            typedef float f4v __attribute__((ext_vector_type(4)));
+            auto batch = [&](auto full_tag, int s0, const float (&xoff)[G]) {
+                constexpr bool FULL = decltype(full_tag)::value;
                 float tt[G], e0[C][G], e1[C][G];
                 bool ok[G];
+                unsigned rowb = (unsigned)s0 * stride_b;     // scalar
 #pragma unroll
                 for (int j = 0; j < G; j++) {
-                    const int s = s0 + j;
-                    const bool live = s < S;             // wave-uniform
-                    const int sc = live ? s : S - 1;
+                    const bool live = FULL || s0 + j < S;    // wave-uniform
                     float x;
                     if (UNIFORM_D) {
-                        x = otab[sc];
+                        x = xoff[j];
                     } else {
-                        x = (float)(a.s_hat - sc) * Dd;
+                        x = (float)(a.s_hat - min(s0 + j, S - 1)) * Dd;
                         x = x * slope;
                     }
-                    x = x + uf;                          // core.hpp:552
-                    tt[j] = lerp_weight(x);              // interp.hpp:181
-                    int i0 = floor_to_int(x);            // interp.hpp:179
+                    x = x + uf;                              // core.hpp:552
+                    tt[j] = lerp_weight(x);                  // interp.hpp:181
+                    int i0 = floor_to_int(x);                // interp.hpp:179
                     ok[j] = live;
                     if (BORDER) {
                         ok[j] = live && (__float_as_uint(x) <= Um1_bits);   // interp.hpp:182 (x is never -0)
                         i0 = ok[j] ? i0 : 0;
                     }
-                    const unsigned byteoff = ((unsigned)(i0 * C) << 2) + (live ? rowb : 0u);
+                    if (!FULL)
+                        i0 = live ? i0 : 0;                  // a slot past S: its offset is whatever follows the table
+                    // both taps of every channel are 2*C consecutive floats of the row (interleaved slab); positions
+                    // are below 2^24, so the 24-bit multiply-add is exact
+                    const unsigned byteoff = __umul24((unsigned)i0, 4u * C) + (live ? rowb : 0u);
                     rowb += stride_b;
-                    // both taps of every channel are 2*C consecutive floats of the row (interleaved slab)
                     const float* p = (const float*)((const char*)epi + byteoff);
 #pragma unroll
                     for (int c = 0; c < C; c++) {
@@ -755,7 +802,8 @@ __device__ __forceinline__ void scan_stream_body(const ScanArgs& a, int v, int u
                         const float m0 = omt * e0[c][j];     // interp.hpp:184
                         const float m1 = tt[j] * e1[c][j];
                         float r = m0 + m1;
-                        r = ok[j] ? r : kSentinel;           // interp.hpp:189 stand-in: K = 0 and r * K = 0 exactly
+                        if (BORDER || !FULL)
+                            r = ok[j] ? r : kSentinel;       // interp.hpp:189 stand-in: K = 0 and r * K = 0 exactly
                         R[c] = r;
                         const float delta = r - rbar[c];     // core.hpp:591
                         const float tq = kq * delta;         // kernels.cpp:21 / :43
@@ -776,7 +824,106 @@ __device__ __forceinline__ void scan_stream_body(const ScanArgs& a, int v, int u
                     if (BORDER)
                         ncard += ok[j] ? 1 : 0;
                 }
+            };
+            // Shared taps (DENSE, every offset of this hypothesis regular): one 12/4-byte load per lane and sample,
+            // the right tap from lane + 1.  Lane 63 computes on its own left tap twice; it is never written.
+            constexpr int GS = RSLF_STREAM_GS;   // samples per batch of the shared-tap form: their loads are all in flight before the first blend
+            auto issue_shared = [&](int s0, const float (&xoff)[GS], float (&tt)[GS], float (&e0)[C][GS]) {
+                unsigned rowb = (unsigned)s0 * stride_b;     // scalar
+#pragma unroll
+                for (int j = 0; j < GS; j++) {
+                    const float x = xoff[j] + uf;            // core.hpp:552
+                    tt[j] = lerp_weight(x);                  // interp.hpp:181
+                    const int i0 = floor_to_int(x);          // interp.hpp:179
+                    const unsigned byteoff = __umul24((unsigned)i0, 4u * C) + rowb;
+                    rowb += stride_b;
+                    const float* p = (const float*)((const char*)epi + byteoff);
+                    if constexpr (C == 3) {
+                        typedef float f3u __attribute__((ext_vector_type(3), aligned(4)));
+                        const f3u t3 = *(const f3u*)p;
+                        e0[0][j] = t3.x, e0[1][j] = t3.y, e0[C - 1][j] = t3.z;
+                    } else {
+                        e0[0][j] = p[0];
+                    }
+                }
+            };
+            auto consume_shared = [&](const float (&tt)[GS], const float (&e0)[C][GS]) {
+#pragma unroll
+                for (int j = 0; j < GS; j++) {
+                    const float omt = 1.0f - tt[j];
+                    float R[C], q[C];
+#pragma unroll
+                    for (int c = 0; c < C; c++) {
+                        // 0x130 = wave_shl:1: lane i reads lane i + 1, the owner of this lane's right tap
+                        const float e1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(e0[c][j]), 0x130, 0xf, 0xf, false));
+                        const float m0 = omt * e0[c][j];     // interp.hpp:184
+                        const float m1 = tt[j] * e1;
+                        const float r = m0 + m1;
+                        R[c] = r;
+                        const float delta = r - rbar[c];     // core.hpp:591
+                        const float tq = kq * delta;         // kernels.cpp:21 / :43
+                        q[c] = tq * delta;
+                    }
+                    float qs = q[0];
+                    if (C == 3) {
+                        qs = q[0] + q[C - 1];                // OpenCV 3.x reduceC_: (q0 + q2) + q1
+                        qs = qs + q[C > 1 ? 1 : 0];
+                    }
+                    const float K = kernel_weight(qs);       // kernels.cpp:23-25 / :51-53
+#pragma unroll
+                    for (int c = 0; c < C; c++) {
+                        const float pr = R[c] * K;           // core.cpp:28 / :36
+                        A[c] = A[c] + pr;                    // core.hpp:602
+                    }
+                    B = B + K;                               // core.hpp:603
+                }
+            };
+            // the table is 16-byte aligned and padded to a multiple of 4 floats; s_begin is a multiple of G
+            auto offsets = [&](int s0, float (&xoff)[G]) {
+                if (UNIFORM_D) {
+#pragma unroll
+                    for (int j4 = 0; j4 < G; j4 += 4) {
+                        const f4v v4 = *(const f4v*)(otab + s0 + j4);
+                        xoff[j4] = v4.x, xoff[j4 + 1] = v4.y, xoff[j4 + 2] = v4.z, xoff[j4 + 3] = v4.w;
+                    }
+                }
+            };
+            const int s_begin = NRES + npark;
+            const int s_full = s_begin + (S - s_begin) / G * G;      // end of the full batches
+            int s_gen = s_begin;   // where the general form takes over
+            if (DENSE && shared_taps) {
+                // With half the loads (shared taps) the memory pipeline keeps up; what is left is latency -- a wave
+                // alone on its SIMD issues no faster than one instruction per four clocks, so its waits are never made
+                // up for by the partner wave.  Eight samples per batch: the loads of all eight are in flight before
+                // the first blend, and nothing is carried from one batch to the next (loop-carried prefetch registers
+                // cost hipcc a copy of every loaded value right behind the loads, i.e. the wait it was meant to hide).
+                const int s_full8 = s_begin + (S - s_begin) / GS * GS;
+#pragma unroll 1
+                for (int s0 = s_begin; s0 < s_full8; s0 += GS) {
+                    float xo[GS], tt8[GS], e8[C][GS];
+#pragma unroll
+                    for (int j4 = 0; j4 < GS; j4 += 4) {
+                        const f4v v4 = *(const f4v*)(otab + s0 + j4);
+                        xo[j4] = v4.x, xo[j4 + 1] = v4.y, xo[j4 + 2] = v4.z, xo[j4 + 3] = v4.w;
+                    }
+                    issue_shared(s0, xo, tt8, e8);
+                    consume_shared(tt8, e8);
+                }
+                s_gen = s_full8;
             }
+            float xnext[G];
+            offsets(s_gen < S ? s_gen : 0, xnext);
+#pragma unroll 1
+            for (int s0 = s_gen; s0 < s_full; s0 += G) {
+                float xcur[G];
+#pragma unroll
+                for (int j = 0; j < G; j++)
+                    xcur[j] = xnext[j];
+                offsets(s0 + G < S ? s0 + G : s0, xnext);            // the next batch's offsets, a batch ahead
+                batch(std::true_type{}, s0, xcur);
+            }
+            if (s_full < S)
+                batch(std::false_type{}, s_full, xnext);
             if (BORDER)
                 card = ncard;
 #pragma unroll
@@ -808,19 +955,28 @@ __device__ __forceinline__ bool wave_is_interior(const ScanArgs& a, int u)
 template <int C, int NRES>
 __device__ __forceinline__ void scan_stream_rows(const ScanArgs& a, int v, int u, int d0, int d1, Best<C>& best, float* otab)
 {
-    if (wave_is_interior(a, u))
-        scan_stream_body<C, false, true, NRES>(a, v, u, d0, d1, best, otab);
-    else if (!a.dmin_vu)
+    if (wave_is_interior(a, u)) {
+        // 63 consecutive pixels in lanes 0..62 (lane 63 is idle and shadows lane 62): lane 63 moves one pixel on --
+        // still inside the row for every sample, wave_is_interior leaves two pixels of margin -- and the tail
+        // shares taps between neighbours
+        const int u0 = __builtin_amdgcn_readfirstlane(u), u62 = __builtin_amdgcn_readlane(u, 62);
+        if (a.tile_w == 63 && u62 - u0 == 62 && NRES + a.stream_park < a.vol.S) {
+            const int ud = ((threadIdx.x & 63) == 63) ? u62 + 1 : u;
+            scan_stream_body<C, false, true, NRES, true>(a, v, ud, d0, d1, best, otab);
+        } else {
+            scan_stream_body<C, false, true, NRES>(a, v, u, d0, d1, best, otab);
+        }
+    } else if (!a.dmin_vu)
         scan_stream_body<C, true, true, NRES>(a, v, u, d0, d1, best, otab);
     else
         scan_stream_body<C, true, false, NRES>(a, v, u, d0, d1, best, otab);
 }
 
 template <int C>
-__global__ __launch_bounds__(64 * kScanWaves) __attribute__((amdgpu_waves_per_eu(2, 8))) void k2_scan_stream(ScanArgs a)
+__global__ __launch_bounds__(64 * kScanWaves) __attribute__((amdgpu_waves_per_eu(RSLF_STREAM_WAVES, 8))) void k2_scan_stream(ScanArgs a)
 {
-    extern __shared__ __attribute__((aligned(16))) float s_stream_otab[];   // [kScanWaves][S + stream_park * C * 64]
-    float* otab = s_stream_otab + (size_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * (a.vol.S + a.stream_park * C * 64);
+    extern __shared__ __attribute__((aligned(16))) float s_stream_otab[];   // [kScanWaves][stream_wave_floats]
+    float* otab = s_stream_otab + (size_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * a.stream_wave_floats;
     // packed tiles: lanes sit on different scanlines, offsets are per lane (the <true, false> body)
     if (a.vol.S >= stream_resident_hi(C)) {
         RSLF_SCAN_KERNEL_BODY((scan_stream_rows<C, stream_resident_hi(C)>(a, v, u, d0, d1, best, otab)),

@@ -43,6 +43,15 @@ static int fail(int code, const char* fmt, ...)
 
 // ---- objects --------------------------------------------------------------
 
+// Streaming scan kernel: two workgroups per CU (two waves per SIMD) share the CU's 160 KiB of LDS; each has
+// 8 KiB of static LDS (the merge of the four waves' results), so 72 KiB of dynamic LDS per workgroup.
+static constexpr size_t kStreamLdsBytes = (size_t)72 << 10;
+// Dense launches of the streaming kernel: this many workgroups share one tile's hypotheses.  The workgroups an
+// XCD runs together then sit on two or three tiles instead of a whole scanline, and what they gather from
+// stays inside the XCD's 4 MiB L2 (k2_scan.hpp)
+static constexpr int kStreamGroups = 16;
+static constexpr size_t kPartialBudget = (size_t)256 << 20;   // bytes of (tile, group, lane) records per grouped scan launch
+
 struct rslf_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -65,6 +74,14 @@ struct rslf_ctx {
     bool keep_total = false;   // the 2-D sweep sums the scanned pixels of all its visits
     int scan_groups = 1;       // hypothesis groups per tile for the next scan launches (the 2-D sweep raises it)
     bool scan_packed = false;  // next scan launches use one packed pixel list (sparse visits of the 2-D sweep)
+    // test / tuning hooks (rslf_ctx_set_debug), per context: 0 / -1 = automatic
+    int force_scan = 0;        // 1 generic kernel, 2 streaming kernel
+    int force_groups = 0;      // hypothesis groups per tile
+    int force_packed = -1;     // 0 / 1
+    int stream_groups = 0;     // streaming kernel, dense launches: hypothesis groups per tile (0 = kStreamGroups)
+    bool stream_share = true;  // streaming kernel: 63-pixel row tiles whose tail shares taps between neighbouring lanes
+    size_t stream_lds_bytes = kStreamLdsBytes;   // dynamic LDS of one streaming workgroup
+    bool stream_attr_set = false;
     Partial* scan_partial = nullptr;   // [tile][group][64] records of grouped scan launches
     size_t partial_rec_cap = 0;
     // 2-D sweep scratch
@@ -287,6 +304,28 @@ extern "C" int rslf_ctx_set_stream(rslf_ctx* ctx, void* hip_stream)
     if (!ctx)
         return fail(RSLF_ERR_INVALID_ARG, "ctx is NULL");
     ctx->stream = (hipStream_t)hip_stream;
+    return RSLF_OK;
+}
+
+extern "C" int rslf_ctx_set_debug(rslf_ctx* ctx, const char* key, int value)
+{
+    if (!ctx || !key)
+        return fail(RSLF_ERR_INVALID_ARG, "ctx/key is NULL");
+    if (strcmp(key, "force_scan") == 0 && value >= 0 && value <= 2)
+        ctx->force_scan = value;
+    else if (strcmp(key, "force_groups") == 0 && value >= 0 && value <= 64)
+        ctx->force_groups = value;
+    else if (strcmp(key, "force_packed") == 0 && value >= -1 && value <= 1)
+        ctx->force_packed = value;
+    else if (strcmp(key, "stream_share") == 0 && (value == 0 || value == 1))
+        ctx->stream_share = value != 0;
+    else if (strcmp(key, "stream_groups") == 0 && value >= 0 && value <= 64)
+        ctx->stream_groups = value;
+    else if (strcmp(key, "stream_lds_kib") == 0 && value >= 16 && value <= 152) {
+        ctx->stream_lds_bytes = (size_t)value << 10;
+        ctx->stream_attr_set = false;
+    } else
+        return fail(RSLF_ERR_INVALID_ARG, "rslf_ctx_set_debug: unknown key or value out of range: %s = %d", key, value);
     return RSLF_OK;
 }
 
@@ -844,13 +883,36 @@ extern "C" int rslf_depth_epi_scan(rslf_ctx* ctx, const rslf_volume* vol, const 
     if (!ctx->keep_total)
         HIP_TRY(hipMemsetAsync(ctx->total, 0, sizeof(unsigned long long), st));
 
-    // hypothesis groups per tile and packed tiles: 1 / off unless the caller expects a sparse launch
+    // Which kernel?  Register variant: S within the compiled slot counts, and radiances in [0, 1e6] so that
+    // max(R,0) == R and the 1e30 sentinel dwarfs them.  Streaming variant: same precondition, any S whose
+    // offset table fits the LDS.  Otherwise the generic kernel.
+    int spad = 0;
+    if (vol->min_value >= 0.0f && vol->max_value <= 1.0e6f)
+        spad = pick_spad(vol->S, vol->C);
+    bool stream_ok = vol->min_value >= 0.0f && vol->max_value <= 1.0e6f &&
+                     (size_t)kScanWaves * vol->S * sizeof(float) <= (size_t)48 << 10;
+    if (p->interpolation != RSLF_INTERP_LINEAR) {      // nearest-neighbour sampling: generic kernel only
+        spad = 0;
+        stream_ok = false;
+    } else if (ctx->force_scan == 1) {                 // parity tests exercise every variant on small cases
+        spad = 0;
+        stream_ok = false;
+    } else if (ctx->force_scan == 2) {
+        spad = 0;
+    }
+    const bool use_stream = !spad && stream_ok;
+
+    // hypothesis groups per tile and packed tiles: 1 / off unless the caller expects a sparse launch ...
     int groups = std::max(1, ctx->scan_groups);
     bool packed = ctx->scan_packed;
-    if (const char* fg = getenv("RSLF_FORCE_GROUPS"))   // parity tests: sparse-launch shapes on the pile path too
-        groups = std::min(64, std::max(1, atoi(fg)));
-    if (const char* fp = getenv("RSLF_FORCE_PACKED"))
-        packed = atoi(fp) != 0;
+    // ... or the streaming kernel runs a dense launch: its workgroups then share tiles so that what an XCD's
+    // workgroups gather from at any one time fits its L2 (kStreamGroups)
+    if (use_stream && groups == 1 && !packed)
+        groups = ctx->stream_groups > 0 ? ctx->stream_groups : kStreamGroups;
+    if (ctx->force_groups > 0)   // parity tests: sparse-launch shapes on the pile path too (rslf_ctx_set_debug)
+        groups = std::min(64, ctx->force_groups);
+    if (ctx->force_packed >= 0)
+        packed = ctx->force_packed != 0;
     while (groups > 1 && dim_d < 2 * kScanWaves * groups)   // enough hypotheses to share out?
         groups /= 2;
     if (n > (size_t)INT32_MAX)
@@ -885,18 +947,39 @@ extern "C" int rslf_depth_epi_scan(rslf_ctx* ctx, const rslf_volume* vol, const 
     a.rbar = d_rbar_vu;
     a.idx = d_idx_vu;
     a.score = d_score_vu;
-    a.tiles_per_row = (vol->U + 63) / 64;
-    // row tiles: ceil(U/64) per scanline; packed tiles: at most ceil(V*U/64), the device knows how many
-    const long long tiles = packed ? (long long)((n + 63) / 64) : (long long)vol->V * a.tiles_per_row;
-    if (tiles * groups > (long long)1 << 30)
-        return fail(RSLF_ERR_UNSUPPORTED, "%lld tiles x %d groups exceeds the grid limit", tiles, groups);
-    a.groups = groups;
+    // the streaming kernel's row tiles leave lane 63 to its neighbour's right tap (k2_scan.hpp, DENSE)
+    a.tile_w = (use_stream && !packed && ctx->stream_share) ? 63 : 64;
+    a.tiles_per_row = (vol->U + a.tile_w - 1) / a.tile_w;
+    {
+        // largest position the scan can form, and one ulp of it below 1
+        int e = 0;
+        (void)frexpf((float)vol->U + 2.0f, &e);            // U + 2 < 2^e
+        a.stream_frac_max = 1.0f - ldexpf(1.0f, std::max(e - 24, -24));
+    }
     a.packed = packed ? 1 : 0;
     a.packed_n = packed_n;
     a.stream_park = 0;
+    a.stream_wave_floats = 0;
     a.partial = nullptr;
+    a.v0 = 0;
+
+    // Grouped launches leave one 32-byte record per (tile, group, lane) for k2_scan_combine.  The records are
+    // bounded by kPartialBudget: packed launches (at most ceil(V*U/64) tiles, the device knows how many) halve
+    // their groups until they fit; row-tile launches go by blocks of scanlines.
+    int rows_per_launch = vol->V;
     if (groups > 1) {
-        const size_t recs = (size_t)tiles * groups * 64;
+        const size_t rec = 64 * sizeof(Partial);
+        if (packed) {
+            while (groups > 1 && ((n + 63) / 64) * groups * rec > kPartialBudget)
+                groups /= 2;
+        } else {
+            const size_t per_row = (size_t)a.tiles_per_row * groups * rec;
+            rows_per_launch = (int)std::min<size_t>((size_t)vol->V, std::max<size_t>(1, kPartialBudget / per_row));
+        }
+    }
+    a.groups = groups;
+    if (groups > 1) {
+        const size_t recs = (packed ? (n + 63) / 64 : (size_t)rows_per_launch * a.tiles_per_row) * groups * 64;
         if (recs > ctx->partial_rec_cap) {
             HIP_TRY(hipFree(ctx->scan_partial));
             ctx->scan_partial = nullptr;
@@ -906,71 +989,75 @@ extern "C" int rslf_depth_epi_scan(rslf_ctx* ctx, const rslf_volume* vol, const 
         }
         a.partial = ctx->scan_partial;
     }
-    a.logical_blocks = (int)(tiles * groups);   // `groups` workgroups per tile, their waves split the hypotheses
-    a.per_xcd = (a.logical_blocks + 7) / 8;
-    // packed: a fixed grid strides over the items (k2_scan.hpp); ~4 workgroups per CU cover any occupancy
-    const dim3 grid(packed ? (unsigned)std::min<long long>(tiles * groups, 1024) : (unsigned)(a.per_xcd * 8));
-    const dim3 combine_grid(packed ? (unsigned)std::min<long long>(tiles, 1024) : (unsigned)tiles);
 
-    // Register variant: one channel, S within the compiled slot counts, and
-    // radiances in [0, 1e6] so that max(R,0) == R and the 1e30 sentinel dwarfs them.
-    int spad = 0;
-    if (vol->min_value >= 0.0f && vol->max_value <= 1.0e6f)
-        spad = pick_spad(vol->S, vol->C);
-    // Streaming variant: same non-negativity precondition, any S that fits the LDS offset table.
-    bool stream_ok = vol->min_value >= 0.0f && vol->max_value <= 1.0e6f &&
-                     (size_t)kScanWaves * vol->S * sizeof(float) <= (size_t)48 << 10;
-    const char* force = getenv("RSLF_FORCE_SCAN");   // parity tests exercise every variant on small cases
-    if (p->interpolation != RSLF_INTERP_LINEAR) {      // nearest-neighbour sampling: generic kernel only
-        spad = 0;
-        stream_ok = false;
-    } else if (force && strcmp(force, "generic") == 0) {
-        spad = 0;
-        stream_ok = false;
-    } else if (force && strcmp(force, "stream") == 0) {
-        spad = 0;
+    size_t lds = 0;
+    if (use_stream) {
+        // too many samples for the register file (k2_scan_stream).  LDS per wave: the S view offsets, the parked
+        // samples and the staging slots of the re-gathered tail; as many batches of parked samples as the
+        // workgroup's LDS share leaves room for (and never past the end of the views)
+        const int batch = vol->C == 1 ? 8 : 4;
+        const int nres = stream_resident_for(vol->S, vol->C);
+        const size_t s4 = ((size_t)vol->S + 3) & ~(size_t)3;
+        int park = 0;
+        if (nres > 0) {
+            size_t room = ctx->stream_lds_bytes / kScanWaves / sizeof(float);   // floats per wave
+            room -= std::min(room, s4);
+            park = (int)(room / ((size_t)vol->C * 64));
+            park = std::min(park, vol->S - nres);
+            park -= park % batch;
+        }
+        a.stream_park = park;
+        a.stream_wave_floats = (int)(s4 + (size_t)park * vol->C * 64);
+        lds = (size_t)kScanWaves * a.stream_wave_floats * sizeof(float);
+        if (!ctx->stream_attr_set) {   // more than the 64 KiB a kernel gets without asking
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k2_scan_stream<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)ctx->stream_lds_bytes));
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k2_scan_stream<3>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)ctx->stream_lds_bytes));
+            ctx->stream_attr_set = true;
+        }
     }
 
     HIP_TRY(hipGetLastError());   // anything an earlier enqueue left behind is not this launch's fault
     ctx->last_spad = spad;
     ctx->last_kernel = spad ? RSLF_SCAN_REG : (stream_ok ? RSLF_SCAN_STREAM : RSLF_SCAN_GENERIC);
     HIP_TRY(hipEventRecord(ctx->ev0, st));
-    if (spad) {
-        rc = launch_scan_reg(spad, vol->C, a, grid, st);
-        if (rc)
-            return rc;
-    } else if (stream_ok) {
-        // too many samples for the register file: re-gather every pass (k2_scan_stream)
-        // LDS per wave: the S view offsets + the parked samples; as many batches of parked samples as the 64 KiB
-        // of dynamic LDS leave room for (and never past the end of the views)
-        const int batch = vol->C == 1 ? 8 : 4;
-        const int nres = stream_resident_for(vol->S, vol->C);
-        int park = 0;
-        if (nres > 0) {
-            const size_t room = ((size_t)64 << 10) / kScanWaves / sizeof(float);   // floats per wave
-            if (room > (size_t)vol->S)
-                park = (int)((room - vol->S) / ((size_t)vol->C * 64));
-            park = std::min(park, vol->S - nres);
-            park -= park % batch;
+    for (int v0 = 0; v0 < vol->V; v0 += rows_per_launch) {
+        const int rows = std::min(rows_per_launch, vol->V - v0);
+        // row tiles: ceil(U/64) per scanline; packed tiles: at most ceil(V*U/64), the device knows how many
+        const long long tiles = packed ? (long long)((n + 63) / 64) : (long long)rows * a.tiles_per_row;
+        if (tiles * groups > (long long)1 << 30)
+            return fail(RSLF_ERR_UNSUPPORTED, "%lld tiles x %d groups exceeds the grid limit", tiles, groups);
+        a.v0 = v0;
+        a.logical_blocks = (int)(tiles * groups);   // `groups` workgroups per tile, their waves split the hypotheses
+        a.per_xcd = (a.logical_blocks + 7) / 8;
+        // packed: a fixed grid strides over the items (k2_scan.hpp); ~4 workgroups per CU cover any occupancy
+        const dim3 grid(packed ? (unsigned)std::min<long long>(tiles * groups, 1024) : (unsigned)(a.per_xcd * 8));
+        const dim3 combine_grid(packed ? (unsigned)std::min<long long>(tiles, 1024) : (unsigned)tiles);
+        if (spad) {
+            rc = launch_scan_reg(spad, vol->C, a, grid, st);
+            if (rc)
+                return rc;
+        } else if (use_stream) {
+            if (vol->C == 1)
+                hipLaunchKernelGGL(k2_scan_stream<1>, grid, dim3(64 * kScanWaves), lds, st, a);
+            else
+                hipLaunchKernelGGL(k2_scan_stream<3>, grid, dim3(64 * kScanWaves), lds, st, a);
+        } else if (vol->C == 1) {
+            hipLaunchKernelGGL(k2_scan_generic<1>, grid, dim3(64 * kScanWaves), 0, st, a);
+        } else {
+            hipLaunchKernelGGL(k2_scan_generic<3>, grid, dim3(64 * kScanWaves), 0, st, a);
         }
-        a.stream_park = park;
-        const size_t lds = (size_t)kScanWaves * ((size_t)vol->S + (size_t)park * vol->C * 64) * sizeof(float);
-        if (vol->C == 1)
-            hipLaunchKernelGGL(k2_scan_stream<1>, grid, dim3(64 * kScanWaves), lds, st, a);
-        else
-            hipLaunchKernelGGL(k2_scan_stream<3>, grid, dim3(64 * kScanWaves), lds, st, a);
-    } else if (vol->C == 1) {
-        hipLaunchKernelGGL(k2_scan_generic<1>, grid, dim3(64 * kScanWaves), 0, st, a);
-    } else {
-        hipLaunchKernelGGL(k2_scan_generic<3>, grid, dim3(64 * kScanWaves), 0, st, a);
-    }
-    HIP_TRY(hipGetLastError());
-    if (groups > 1) {
-        if (vol->C == 1)
-            hipLaunchKernelGGL(k2_scan_combine<1>, combine_grid, dim3(64), 0, st, a);
-        else
-            hipLaunchKernelGGL(k2_scan_combine<3>, combine_grid, dim3(64), 0, st, a);
         HIP_TRY(hipGetLastError());
+        if (groups > 1) {
+            if (vol->C == 1)
+                hipLaunchKernelGGL(k2_scan_combine<1>, combine_grid, dim3(64), 0, st, a);
+            else
+                hipLaunchKernelGGL(k2_scan_combine<3>, combine_grid, dim3(64), 0, st, a);
+            HIP_TRY(hipGetLastError());
+        }
+        if (packed)
+            break;   // one launch covers the packed list
     }
     HIP_TRY(hipEventRecord(ctx->ev1, st));
     ctx->ev_valid = true;

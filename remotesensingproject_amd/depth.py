@@ -100,6 +100,20 @@ class Context:
     def synchronize(self) -> None:
         check(_lib.lib().rslf_ctx_synchronize(self._h), "rslf_ctx_synchronize")
 
+    _DEBUG_DEFAULTS = dict(force_scan=0, force_groups=0, force_packed=-1, stream_share=1, stream_groups=0, stream_lds_kib=72)
+    _FORCE_SCAN = {None: 0, "auto": 0, "generic": 1, "stream": 2}
+
+    def set_debug(self, **hooks) -> None:
+        """rslf_ctx_set_debug: test / tuning hooks of THIS context (kernel variant, launch shape).  force_scan also
+        takes "generic" / "stream" / None."""
+        for k, v in hooks.items():
+            if k == "force_scan" and not isinstance(v, int):
+                v = self._FORCE_SCAN[v or None]
+            check(_lib.lib().rslf_ctx_set_debug(self._h, k.encode(), int(v)), "rslf_ctx_set_debug(%s)" % k)
+
+    def reset_debug(self) -> None:
+        self.set_debug(**self._DEBUG_DEFAULTS)
+
     def last_scan_kernel_ms(self) -> float:
         ms = C.c_float()
         check(_lib.lib().rslf_last_scan_kernel_ms(self._h, C.byref(ms)), "rslf_last_scan_kernel_ms")

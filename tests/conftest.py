@@ -18,3 +18,12 @@ def oracle_mod():
     oracle.build()
     oracle.set_num_threads(min(oracle.usable_cpus(), 16))   # the GPU box shares a 256-CPU host
     return oracle
+
+
+@pytest.fixture
+def hooks():
+    """Per-context test hooks (rslf_ctx_set_debug) on the default context of cuda:0, reset after the test."""
+    from remotesensingproject_amd import depth as rs
+    ctx = rs.default_context(0)
+    yield ctx.set_debug
+    ctx.reset_debug()

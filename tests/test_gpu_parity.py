@@ -90,8 +90,8 @@ def test_pile_3ch(rs, oracle_mod, kind, S):
     assert comp.stats.scan_kernel == (1 if S <= 48 else 2)
 
 
-def test_generic_kernel_matches_on_3ch(rs, oracle_mod, monkeypatch):
-    monkeypatch.setenv("RSLF_FORCE_SCAN", "generic")
+def test_generic_kernel_matches_on_3ch(rs, oracle_mod, hooks):
+    hooks(force_scan="generic")
     vol = _vol("noise", 90, 4, 17, 3, 78, -1.0, 2.0)
     ref = oracle_mod.depth1d_pile_run(vol, -1.0, 2.0, 20)
     comp, got = _run(rs, vol, -1.0, 2.0, 20)
@@ -99,9 +99,9 @@ def test_generic_kernel_matches_on_3ch(rs, oracle_mod, monkeypatch):
     assert_pile_parity(got, ref, label="forced_generic_3ch")
 
 
-def test_generic_kernel_matches_on_1ch(rs, oracle_mod, monkeypatch):
+def test_generic_kernel_matches_on_1ch(rs, oracle_mod, hooks):
     """The fallback scan (any S, any sign) must agree with the register scan's oracle too."""
-    monkeypatch.setenv("RSLF_FORCE_SCAN", "generic")
+    hooks(force_scan="generic")
     U, V, S, D = 130, 4, 33, 24
     vol = _vol("noise", U, V, S, 1, 5, -2.0, 2.0)
     ref = oracle_mod.depth1d_pile_run(vol, -2.0, 2.0, D)
@@ -112,10 +112,10 @@ def test_generic_kernel_matches_on_1ch(rs, oracle_mod, monkeypatch):
 
 @pytest.mark.parametrize("C_,S,U,kind", [(1, 33, 130, "noise"), (1, 9, 70, "struct"), (3, 17, 90, "noise"), (3, 21, 200, "struct"),
                                          (1, 300, 150, "noise")])
-def test_stream_kernel(rs, oracle_mod, monkeypatch, C_, S, U, kind):
+def test_stream_kernel(rs, oracle_mod, hooks, C_, S, U, kind):
     """The re-gather variant used beyond the register file (e.g. 201-view RGB), forced on small shapes:
     border and interior tiles, both channel counts, S beyond every register variant."""
-    monkeypatch.setenv("RSLF_FORCE_SCAN", "stream")
+    hooks(force_scan="stream")
     V, D = 4, 10
     dm = 2.0 if S < 100 else 0.4
     vol = _vol(kind, U, V, S, C_, 300 + S, -1.0, dm)
@@ -125,9 +125,9 @@ def test_stream_kernel(rs, oracle_mod, monkeypatch, C_, S, U, kind):
     assert_pile_parity(got, ref, label="stream_C%d_S%d" % (C_, S))
 
 
-def test_stream_kernel_per_pixel_ranges(rs, oracle_mod, monkeypatch):
+def test_stream_kernel_per_pixel_ranges(rs, oracle_mod, hooks):
     import torch
-    monkeypatch.setenv("RSLF_FORCE_SCAN", "stream")
+    hooks(force_scan="stream")
     rng = np.random.default_rng(51)
     V, S, U, D = 3, 13, 110, 9
     vol = rng.uniform(0.0, 1.0, size=(V, S, U, 3)).astype(np.float32)
@@ -167,14 +167,14 @@ def test_stream_kernel_per_pixel_ranges(rs, oracle_mod, monkeypatch):
     (2, "stream", 3, 60, 100, 16),   # streaming kernel with its resident prefix + parked samples, both tile forms
     (2, "stream", 1, 130, 80, 16),
 ])
-def test_sparse_launch_shapes(rs, oracle_mod, monkeypatch, packed, groups, force, C_, S, U, D):
+def test_sparse_launch_shapes(rs, oracle_mod, hooks, packed, groups, force, C_, S, U, D):
     """Sparse visits of the 2-D sweep split each tile's hypotheses over several workgroups (records merged
     by k2_scan_combine) and pack the pixels of all scanlines into one list, so that a wave's lanes sit on
     different scanlines: arg-max (first maximum), mean and r-bar must not depend on either."""
-    monkeypatch.setenv("RSLF_FORCE_GROUPS", str(groups))
-    monkeypatch.setenv("RSLF_FORCE_PACKED", str(packed))
+    hooks(force_groups=groups)
+    hooks(force_packed=packed)
     if force:
-        monkeypatch.setenv("RSLF_FORCE_SCAN", force)
+        hooks(force_scan=force)
     vol = _vol("noise" if C_ == 1 else "struct", U, 5, S, C_, 900 + D, -1.5, 2.5)
     ref = oracle_mod.depth1d_pile_run(vol, -1.5, 2.5, D)
     comp, got = _run(rs, vol, -1.5, 2.5, D)
@@ -182,12 +182,12 @@ def test_sparse_launch_shapes(rs, oracle_mod, monkeypatch, packed, groups, force
     assert_pile_parity(got, ref, label="groups%d_packed%d_%s_C%d_D%d" % (groups, packed, force, C_, D))
 
 
-def test_packed_tiles_with_per_pixel_ranges_and_sparse_mask(rs, oracle_mod, monkeypatch):
+def test_packed_tiles_with_per_pixel_ranges_and_sparse_mask(rs, oracle_mod, hooks):
     """The fine-to-coarse shape of a sparse visit: per-pixel [dmin, dmax] planes, a caller mask that leaves
     a few pixels per scanline (some scanlines none), packed tiles x 4 groups."""
     import torch
-    monkeypatch.setenv("RSLF_FORCE_GROUPS", "4")
-    monkeypatch.setenv("RSLF_FORCE_PACKED", "1")
+    hooks(force_groups=4)
+    hooks(force_packed=1)
     rng = np.random.default_rng(77)
     V, S, U, D = 9, 13, 150, 37
     vol = rng.uniform(0.0, 1.0, size=(V, S, U, 1)).astype(np.float32)
@@ -234,11 +234,11 @@ def test_nearest_neighbour_interpolation(rs, oracle_mod, mode, C_, S, U, D, kind
 
 
 @pytest.mark.parametrize("force", [None, "stream", "generic"])
-def test_degenerate_shapes(rs, oracle_mod, monkeypatch, force):
+def test_degenerate_shapes(rs, oracle_mod, hooks, force):
     """One pixel / one view / two hypotheses / dmin == dmax / U below the edge filter's width."""
     from tests.test_oracle import DEGENERATE
     if force:
-        monkeypatch.setenv("RSLF_FORCE_SCAN", force)
+        hooks(force_scan=force)
     for V, S, U, C_, D, dmin, dmax in DEGENERATE:
         vol = np.random.default_rng(3 + U).uniform(0.0, 1.0, size=(V, S, U, C_)).astype(np.float32)
         ref = oracle_mod.depth1d_pile_run(vol, dmin, dmax, D)
@@ -454,7 +454,7 @@ def test_errors_do_not_throw_across_abi(rs):
         rs.Volume(rs.default_context(), 2, 5, 70, 2)               # C = 2 unsupported
 
 
-def test_randomised_campaign_subset(monkeypatch):
+def test_randomised_campaign_subset(hooks):
     """A fixed-seed slice of tools/fuzz_parity.py: random shapes, parameters, per-pixel ranges, masks, kernel
     variants and launch shapes; every plane bit-identical to the oracle (profiles/r01_fuzz_parity.txt holds a
     3000-case run)."""
@@ -463,13 +463,11 @@ def test_randomised_campaign_subset(monkeypatch):
     spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(os.path.dirname(__file__), "..", "tools", "fuzz_parity.py"))
     fz = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fz)
-    for k in ("RSLF_FORCE_SCAN", "RSLF_FORCE_PACKED", "RSLF_FORCE_GROUPS"):
-        monkeypatch.setenv(k, os.environ.get(k, ""))   # restored after the test: run_case sets them per case
+    # run_case sets the context's hooks per case; the `hooks` fixture resets them after the test
     rng = np.random.default_rng(7)
     for i in range(150):
         c = fz.draw_case(rng)
         fz.run_case(i, c, rng)
-    monkeypatch.delenv("RSLF_FORCE_SCAN", raising=False)
 
 
 def test_sharded_rows_with_opening_match_unsharded(rs, oracle_mod):

@@ -77,11 +77,8 @@ def make_volume(c, rng):
 
 
 def run_case(i, c, rng):
-    os.environ.pop("RSLF_FORCE_SCAN", None)
-    if c["force"]:
-        os.environ["RSLF_FORCE_SCAN"] = c["force"]
-    os.environ["RSLF_FORCE_PACKED"] = str(c["packed"])
-    os.environ["RSLF_FORCE_GROUPS"] = str(c["groups"])
+    # per-context hooks (rslf_ctx_set_debug)
+    rs.default_context(0).set_debug(force_scan=c["force"], force_packed=c["packed"], force_groups=c["groups"])
     vol = make_volume(c, rng)
     V, S, U, C = vol.shape
     po = oracle.default_params()
