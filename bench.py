@@ -75,6 +75,25 @@ def cpu_baseline(cfg: dict, budget_s: float = 12.0) -> dict:
     }
 
 
+def end_to_end(rs, host: np.ndarray, cfg: dict, units: int, device: int) -> dict:
+    """BASELINE.md section 3's second figure: the drop-in signature is host buffers in, host planes out
+    (dc.hpp:97-122).  One call of the pipelined host path (rslf_multi_*: scanline chunks, upload of chunk k+1 and
+    download of chunk k-1 behind the kernels of chunk k), PCIe included, pageable memory on both sides.  Never `value`."""
+    epis = list(host[..., 0]) if cfg["C"] == 1 else list(host)
+    m = rs.MultiDevice([device])
+    ts = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        m.depth1d_pile(epis, cfg["dmin"], cfg["dmax"], cfg["D"], epi_scale_factor=1.0)
+        ts.append(time.perf_counter() - t0)
+    m.close()
+    t = sorted(ts)[1]
+    return {"ms": t * 1e3, "value": units / t / 1e6, "unit": "Mpixel*hyp/s",
+            "what": "host EPIs (Vec<Mat>-style, pageable) in -> host planes out, one call; upload, kernels and download "
+                    "overlap in scanline chunks with a recomputed halo (rslf_multi_depth1d_pile_f32); median of 3",
+            "input_gb": host.nbytes / 1e9}
+
+
 def bench_sweep2d(args) -> None:
     """Depth2DComputer::run() (dc.hpp:748-805) on a synthetic field: a step = edge confidence of every view
     + one visit per view (scan on the running mask, median, propagation).  Units = pixels actually scanned,
@@ -153,6 +172,23 @@ def bench_f2c(args) -> None:
     }), flush=True)
 
 
+def launch_ranks(n: int) -> None:
+    """`python bench.py --gpus N` typed as is: this process never touches the GPU; it starts N fresh rank
+    processes (one per GPU) through torch.distributed.run with the same arguments, lets rank 0's JSON line
+    through, and exits with their return code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    sys.exit(subprocess.run(cmd, env=env).returncode)
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -161,10 +197,13 @@ def main() -> None:
     ap.add_argument("--config", default="c3", help="synthetic config of BASELINE.md section 4 (c2, c3, c5)")
     ap.add_argument("--rows", type=int, default=0, help="override the number of scanlines (developer runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the host-in / host-out figure (the `e2e` key)")
     ap.add_argument("--path", default="pile", choices=["pile", "sweep2d", "f2c"],
                     help="pile = Depth1DComputer_pile::run (the headline path); sweep2d = Depth2DComputer::run, the 'next' row "
                          "(all views, centre outwards, with propagation), 1 GPU only")
     args = ap.parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        return launch_ranks(args.gpus)
     if args.path == "sweep2d":
         return bench_sweep2d(args)
     if args.path == "f2c":
@@ -180,8 +219,6 @@ def main() -> None:
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs the torch.distributed.run launcher (WORLD_SIZE=%d)" % (args.gpus, world))
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     # RSLF_DIST_BACKEND=gloo + RSLF_ONE_DEVICE=1 rehearse the N > 1 path on a one-GPU box (never a result)
     backend = os.environ.get("RSLF_DIST_BACKEND", "nccl")
@@ -219,7 +256,9 @@ def main() -> None:
         names = {"share": "stream_share", "groups": "stream_groups", "lds": "stream_lds_kib"}
         ctx.set_debug(**{names.get(k, k): int(v) for k, v in (kv.split("=") for kv in os.environ["RSLF_BENCH_HOOKS"].split(",")) if not k.startswith("_")})
     vol = rs.Volume.from_dense(torch.from_numpy(host).to(dev), 1.0, ctx)
-    del host
+    want_e2e = world == 1 and not args.no_e2e and host.nbytes <= (4 << 30)
+    if not want_e2e:
+        del host
     comp = rs.Depth1DComputer_pile(vol, cfg["dmin"], cfg["dmax"], D, parameters=params)
 
     def planes():
@@ -335,6 +374,8 @@ def main() -> None:
                 "note": "compulsory-byte model; this path is VALU-bound, not HBM-bound (SURVEY 8d)",
             },
         }
+        if want_e2e:
+            line["e2e"] = end_to_end(rs, host, cfg, units_per_step, local_rank)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(line), flush=True)

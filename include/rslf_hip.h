@@ -252,6 +252,34 @@ int rslf_depth1d_pile_run_host(rslf_ctx* ctx, const rslf_volume* vol, float dmin
                                float* h_rbar_vu, int32_t* h_idx_vu, float* h_score_vu, float* h_depth_raw_vu,
                                rslf_stats* stats);
 
+/* ---- the hot path from host buffers, pipelined, over one or several devices --------------------------------- */
+/* Depth1DComputer_pile<T>'s constructor + run() + result Mats (include/rslf_depth_computation.hpp:425-565) in ONE
+ * call on host buffers: h_epis[v] is EPI v (S rows of U pixels, C channels interleaved, rows row_stride_bytes apart,
+ * 0 = dense), the h_* planes are the caller's [V][U] result planes (any may be NULL).
+ *
+ * The V EPIs are cut into one contiguous block of scanlines per device of the rslf_multi (K1 and K2 are
+ * independent per scanline, core.hpp:743-757 / :799-854; the median reads +-2 rows, core.hpp:686 -- those rows are
+ * recomputed, not exchanged), every block into chunks, and per device the upload of chunk k+1, the kernels of chunk k
+ * and the download of chunk k-1 overlap.  Each device's rows land directly at their offset in the caller's planes:
+ * there is no collective.  The float input's default scale (epi_scale_factor < 0: the maximum over ALL EPIs,
+ * dc.hpp:442-460) is taken once over the whole input, never per block.  Results are bit-identical to
+ * rslf_volume_upload_epis_* + rslf_depth1d_pile_run_host on one device.
+ *
+ * devices may name the same GPU more than once (two workers on one GPU); NULL / 0 = device 0 alone. */
+typedef struct rslf_multi rslf_multi;
+int rslf_multi_create(const int* devices, int n_devices, rslf_multi** out);
+int rslf_multi_destroy(rslf_multi* m);
+int rslf_multi_device_count(const rslf_multi* m);
+int rslf_multi_set_chunk_rows(rslf_multi* m, int rows);   /* scanlines per chunk; 0 = automatic (about 8 chunks per device) */
+int rslf_multi_depth1d_pile_f32(rslf_multi* m, const float* const* h_epis, size_t row_stride_bytes, int V, int S, int U, int C,
+                                float epi_scale_factor, float dmin, float dmax, int dim_d, int s_hat, const rslf_params* p,
+                                float* h_Ce_vu, uint8_t* h_Ce_mask_vu, float* h_Cd_vu, float* h_depth_vu, float* h_rbar_vu,
+                                int32_t* h_idx_vu, float* h_score_vu, float* h_depth_raw_vu, rslf_stats* stats, float* scale_used);
+int rslf_multi_depth1d_pile_u8(rslf_multi* m, const uint8_t* const* h_epis, size_t row_stride_bytes, int V, int S, int U, int C,
+                               float dmin, float dmax, int dim_d, int s_hat, const rslf_params* p,
+                               float* h_Ce_vu, uint8_t* h_Ce_mask_vu, float* h_Cd_vu, float* h_depth_vu, float* h_rbar_vu,
+                               int32_t* h_idx_vu, float* h_score_vu, float* h_depth_raw_vu, rslf_stats* stats);
+
 /* ---- "next" row: the 2-D sweep over all views ------ */
 /* Planes here are [S][V][U] (the reference's Vec<Mat> indexed by s, dc.hpp:208-215),
  * d_rbar_svu is [S][V][U][C]. */

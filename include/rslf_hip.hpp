@@ -137,6 +137,26 @@ private:
     rslf_ctx* h_;
 };
 
+// Several devices (or several workers on one device) behind one handle: the pile path then cuts the scanlines into one
+// block per device and overlaps upload, kernels and download chunk by chunk (rslf_hip.h, rslf_multi_*).
+class MultiContext {
+public:
+    MultiContext() : h_(nullptr) { check(rslf_multi_create(nullptr, 0, &h_), "rslf_multi_create"); }
+    explicit MultiContext(const std::vector<int>& devices) : h_(nullptr)
+    {
+        check(rslf_multi_create(devices.empty() ? nullptr : devices.data(), (int)devices.size(), &h_), "rslf_multi_create");
+    }
+    ~MultiContext() { rslf_multi_destroy(h_); }
+    MultiContext(const MultiContext&) = delete;
+    MultiContext& operator=(const MultiContext&) = delete;
+    rslf_multi* get() const { return h_; }
+    int device_count() const { return rslf_multi_device_count(h_); }
+    void set_chunk_rows(int rows) { check(rslf_multi_set_chunk_rows(h_, rows), "rslf_multi_set_chunk_rows"); }
+
+private:
+    rslf_multi* h_;
+};
+
 // rslf::Depth1DComputer_pile<DataType>.  DataType is float (1 channel) or a
 // 3-float pixel (cv::Vec3f in the reference, dc.hpp:149-154): only its channel
 // count matters here.
@@ -150,16 +170,43 @@ public:
     Depth1DComputer_pile(Context& ctx, const void* const* epis, bool is_u8, int dim_v, int dim_s, int dim_u,
                          size_t row_stride_bytes, float dmin, float dmax, int dim_d, int s_hat = -1,
                          float epi_scale_factor = -1, const Depth1DParameters& parameters = Depth1DParameters::get_default())
-        : ctx_(ctx), vol_(nullptr), m_parameters(parameters)
+        : ctx_(&ctx), multi_(nullptr), vol_(nullptr), m_parameters(parameters)
     {
         init(epis, is_u8, dim_v, dim_s, dim_u, row_stride_bytes, dmin, dmax, dim_d, s_hat, epi_scale_factor);
     }
 
+    // The same on a MultiContext: the scanlines are shared out over its devices and the host copies overlap the kernels.
+    // Here the EPIs are read by run(), not copied by the constructor: the buffers must outlive it (they do in the
+    // reference's demos, where the Vec<Mat> lives next to the computer).
+    Depth1DComputer_pile(MultiContext& multi, const void* const* epis, bool is_u8, int dim_v, int dim_s, int dim_u,
+                         size_t row_stride_bytes, float dmin, float dmax, int dim_d, int s_hat = -1,
+                         float epi_scale_factor = -1, const Depth1DParameters& parameters = Depth1DParameters::get_default())
+        : ctx_(nullptr), multi_(&multi), vol_(nullptr), m_parameters(parameters)
+    {
+        init_multi(epis, is_u8, dim_v, dim_s, dim_u, row_stride_bytes, dmin, dmax, dim_d, s_hat, epi_scale_factor);
+    }
+
 #ifdef RSLFX_HAVE_OPENCV
+    Depth1DComputer_pile(MultiContext& multi, const std::vector<cv::Mat>& epis, float dmin, float dmax, int dim_d, int s_hat = -1,
+                         float epi_scale_factor = -1, const Depth1DParameters& parameters = Depth1DParameters::get_default())
+        : ctx_(nullptr), multi_(&multi), vol_(nullptr), m_parameters(parameters)
+    {
+        bool is_u8 = false;
+        const std::vector<const void*> ptrs = mat_pointers(epis, is_u8);
+        init_multi(ptrs.data(), is_u8, (int)epis.size(), epis[0].rows, epis[0].cols, epis[0].step[0], dmin, dmax, dim_d, s_hat,
+                   epi_scale_factor);
+    }
     // Exactly the reference's signature: Vec<Mat> in (dc.hpp:97-106).
     Depth1DComputer_pile(Context& ctx, const std::vector<cv::Mat>& epis, float dmin, float dmax, int dim_d, int s_hat = -1,
                          float epi_scale_factor = -1, const Depth1DParameters& parameters = Depth1DParameters::get_default())
-        : ctx_(ctx), vol_(nullptr), m_parameters(parameters)
+        : ctx_(&ctx), multi_(nullptr), vol_(nullptr), m_parameters(parameters)
+    {
+        bool is_u8 = false;
+        const std::vector<const void*> ptrs = mat_pointers(epis, is_u8);
+        init(ptrs.data(), is_u8, (int)epis.size(), epis[0].rows, epis[0].cols, epis[0].step[0], dmin, dmax, dim_d, s_hat,
+             epi_scale_factor);
+    }
+    static std::vector<const void*> mat_pointers(const std::vector<cv::Mat>& epis, bool& is_u8)
     {
         if (epis.empty())
             throw std::invalid_argument("Depth1DComputer_pile: no EPIs");
@@ -171,11 +218,10 @@ public:
                 throw std::invalid_argument("Depth1DComputer_pile: EPIs differ in size or type");
             ptrs[v] = epis[v].data;
         }
-        const bool is_u8 = epis[0].depth() == CV_8U;
+        is_u8 = epis[0].depth() == CV_8U;
         if (!is_u8 && epis[0].depth() != CV_32F)
             throw std::invalid_argument("Depth1DComputer_pile: EPIs must be CV_8U or CV_32F");
-        init(ptrs.data(), is_u8, (int)epis.size(), epis[0].rows, epis[0].cols, epis[0].step[0], dmin, dmax, dim_d, s_hat,
-             epi_scale_factor);
+        return ptrs;
     }
     cv::Mat get_edge_confidence() const { return cv::Mat(dim_v_, dim_u_, CV_32FC1, (void*)m_edge_confidence_v_u.data()).clone(); }
     cv::Mat get_edge_confidence_mask() const { return cv::Mat(dim_v_, dim_u_, CV_8UC1, (void*)m_edge_confidence_mask_v_u.data()).clone(); }
@@ -201,7 +247,24 @@ public:
         m_depth_idx_v_u.assign(n, -1);
         m_score_v_u.assign(n, 0.f);
         const rslf_params p = m_parameters.to_c();
-        check(rslf_depth1d_pile_run_host(ctx_.get(), vol_, m_dmin, m_dmax, m_dim_d, m_s_hat, &p, m_edge_confidence_v_u.data(),
+        if (multi_) {
+            if (is_u8_)
+                check(rslf_multi_depth1d_pile_u8(multi_->get(), (const uint8_t* const*)epis_.data(), row_stride_bytes_, dim_v_, dim_s_,
+                                                 dim_u_, CHANNELS, m_dmin, m_dmax, m_dim_d, m_s_hat, &p, m_edge_confidence_v_u.data(),
+                                                 m_edge_confidence_mask_v_u.data(), m_disp_confidence_v_u.data(),
+                                                 m_best_depth_v_u.data(), m_rbar_v_u.data(), m_depth_idx_v_u.data(),
+                                                 m_score_v_u.data(), nullptr, &stats),
+                      "rslf_multi_depth1d_pile_u8");
+            else
+                check(rslf_multi_depth1d_pile_f32(multi_->get(), (const float* const*)epis_.data(), row_stride_bytes_, dim_v_, dim_s_,
+                                                  dim_u_, CHANNELS, epi_scale_arg_, m_dmin, m_dmax, m_dim_d, m_s_hat, &p,
+                                                  m_edge_confidence_v_u.data(), m_edge_confidence_mask_v_u.data(),
+                                                  m_disp_confidence_v_u.data(), m_best_depth_v_u.data(), m_rbar_v_u.data(),
+                                                  m_depth_idx_v_u.data(), m_score_v_u.data(), nullptr, &stats, &scale_used_),
+                      "rslf_multi_depth1d_pile_f32");
+            return;
+        }
+        check(rslf_depth1d_pile_run_host(ctx_->get(), vol_, m_dmin, m_dmax, m_dim_d, m_s_hat, &p, m_edge_confidence_v_u.data(),
                                          m_edge_confidence_mask_v_u.data(), m_disp_confidence_v_u.data(),
                                          m_best_depth_v_u.data(), m_rbar_v_u.data(), m_depth_idx_v_u.data(),
                                          m_score_v_u.data(), nullptr, &stats),
@@ -236,7 +299,7 @@ private:
         // dc.hpp:490-498
         m_s_hat = (s_hat < 0 || s_hat > dim_s - 1) ? (int)std::floor((0.0 + dim_s) / 2) : s_hat;
         stats = rslf_stats();
-        check(rslf_volume_create(ctx_.get(), dim_v, dim_s, dim_u, CHANNELS, &vol_), "rslf_volume_create");
+        check(rslf_volume_create(ctx_->get(), dim_v, dim_s, dim_u, CHANNELS, &vol_), "rslf_volume_create");
         scale_used_ = 255.f;
         if (is_u8)
             check(rslf_volume_upload_epis_u8(vol_, (const uint8_t* const*)epis, row_stride_bytes), "rslf_volume_upload_epis_u8");
@@ -244,8 +307,30 @@ private:
             check(rslf_volume_upload_epis_f32(vol_, (const float* const*)epis, row_stride_bytes, epi_scale_factor, &scale_used_),
                   "rslf_volume_upload_epis_f32");
     }
+    void init_multi(const void* const* epis, bool is_u8, int dim_v, int dim_s, int dim_u, size_t row_stride_bytes, float dmin,
+                    float dmax, int dim_d, int s_hat, float epi_scale_factor)
+    {
+        dim_v_ = dim_v;
+        dim_s_ = dim_s;
+        dim_u_ = dim_u;
+        m_dmin = dmin;
+        m_dmax = dmax;
+        m_dim_d = dim_d;
+        m_s_hat = (s_hat < 0 || s_hat > dim_s - 1) ? (int)std::floor((0.0 + dim_s) / 2) : s_hat;   // dc.hpp:490-498
+        stats = rslf_stats();
+        epis_.assign(epis, epis + dim_v);
+        is_u8_ = is_u8;
+        row_stride_bytes_ = row_stride_bytes;
+        epi_scale_arg_ = epi_scale_factor;
+        scale_used_ = 255.f;
+    }
 
-    Context& ctx_;
+    Context* ctx_;
+    MultiContext* multi_;
+    std::vector<const void*> epis_;   // multi path: the caller's buffers, read by run()
+    bool is_u8_;
+    size_t row_stride_bytes_;
+    float epi_scale_arg_;
     rslf_volume* vol_;
     int dim_v_, dim_s_, dim_u_;
     int m_dim_d;

@@ -18,6 +18,8 @@ ABI_VERSION = 4
 SYMBOLS = [
     "rslf_abi_version", "rslf_status_string", "rslf_last_error", "rslf_device_count", "rslf_default_params",
     "rslf_ctx_create", "rslf_ctx_destroy", "rslf_ctx_set_stream", "rslf_ctx_synchronize", "rslf_ctx_set_debug",
+    "rslf_multi_create", "rslf_multi_destroy", "rslf_multi_device_count", "rslf_multi_set_chunk_rows",
+    "rslf_multi_depth1d_pile_f32", "rslf_multi_depth1d_pile_u8",
     "rslf_volume_create", "rslf_volume_destroy", "rslf_volume_describe",
     "rslf_volume_upload_epis_f32", "rslf_volume_upload_epis_u8",
     "rslf_volume_upload_images_f32", "rslf_volume_upload_images_u8", "rslf_volume_pack_device_f32",
@@ -137,6 +139,14 @@ def lib():
                                         C.POINTER(RslfStats)]
     L.rslf_depth1d_pile_run_host.argtypes = L.rslf_depth1d_pile_run.argtypes
     L.rslf_last_scan_kernel_ms.argtypes = [vp, C.POINTER(cf)]
+    L.rslf_multi_create.argtypes = [C.POINTER(ci), ci, C.POINTER(vp)]
+    L.rslf_multi_destroy.argtypes = [vp]
+    L.rslf_multi_device_count.argtypes = [vp]
+    L.rslf_multi_set_chunk_rows.argtypes = [vp, ci]
+    L.rslf_multi_depth1d_pile_f32.argtypes = [vp, C.POINTER(vp), C.c_size_t, ci, ci, ci, ci, cf, cf, cf, ci, ci, C.POINTER(RslfParams),
+                                              vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(RslfStats), C.POINTER(cf)]
+    L.rslf_multi_depth1d_pile_u8.argtypes = [vp, C.POINTER(vp), C.c_size_t, ci, ci, ci, ci, cf, cf, ci, ci, C.POINTER(RslfParams),
+                                             vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(RslfStats)]
     L.rslf_kernel_columns_pile.argtypes = [vp, vp, vp, vp, cf, cf, ci, ci, C.POINTER(RslfParams), vp, vp]
     L.rslf_depth2d_run_host.argtypes = [vp, vp, cf, cf, ci, C.POINTER(RslfParams), vp, vp, vp, vp, vp, C.POINTER(RslfStats)]
     L.rslf_fine_to_coarse_run_host.argtypes = [vp, C.POINTER(vp), ci, ci, ci, ci, ci, C.c_size_t, cf, cf, ci, cf, C.POINTER(RslfParams),

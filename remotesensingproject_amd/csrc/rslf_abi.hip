@@ -1784,3 +1784,414 @@ extern "C" int rslf_last_scan_kernel_ms(rslf_ctx* ctx, float* ms)
     HIP_TRY(hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
     return RSLF_OK;
 }
+
+// ---- host pointers in, host planes out: pipelined, over one or several devices ------------------------------
+//
+// Depth1DComputer_pile's constructor + run() + getters (dc.hpp:425-565) in ONE call on host buffers (cv::Mat::data in,
+// cv::Mat::data out).  Scanlines are independent up to the median's halo (DESIGN.md "Multi-GPU"), so the V EPIs are cut
+// into blocks, one per device, and every block into chunks; a chunk is computed with `halo` recomputed rows either
+// side and only its own rows are copied out, straight to their place in the caller's planes -- no collective.  Per
+// device one host thread keeps three things in flight: the kernels of chunk k, the upload of chunk k+1 and the download
+// of chunk k-1 (two volumes and two sets of result planes; copies to and from pageable host memory hold the host
+// thread, never the GPU).  The result is bit-identical to the one-volume run.
+
+#include <mutex>
+#include <string>
+#include <thread>
+
+struct rslf_multi {
+    struct Dev {
+        rslf_ctx* ctx = nullptr;
+        hipStream_t s_up = nullptr, s_comp = nullptr, s_down = nullptr;
+        hipEvent_t done[2] = {nullptr, nullptr};
+        rslf_volume* vol[2] = {nullptr, nullptr};
+        int vol_rows[2] = {0, 0}, vol_S = 0, vol_U = 0, vol_C = 0;
+        char* planes[2] = {nullptr, nullptr};
+        size_t planes_cap = 0;
+    };
+    std::vector<Dev> devs;
+    int chunk_rows = 0;   // 0 = automatic
+};
+
+static void multi_free_dev(rslf_multi::Dev& d)
+{
+    if (!d.ctx)
+        return;
+    (void)hipSetDevice(d.ctx->device);
+    for (int i = 0; i < 2; i++) {
+        if (d.vol[i])
+            (void)rslf_volume_destroy(d.vol[i]);
+        (void)hipFree(d.planes[i]);
+        if (d.done[i])
+            (void)hipEventDestroy(d.done[i]);
+    }
+    if (d.s_up)
+        (void)hipStreamDestroy(d.s_up);
+    if (d.s_comp)
+        (void)hipStreamDestroy(d.s_comp);
+    if (d.s_down)
+        (void)hipStreamDestroy(d.s_down);
+    (void)rslf_ctx_destroy(d.ctx);
+    d = rslf_multi::Dev();
+}
+
+extern "C" int rslf_multi_destroy(rslf_multi* m)
+{
+    if (!m)
+        return RSLF_OK;
+    for (auto& d : m->devs)
+        multi_free_dev(d);
+    delete m;
+    return RSLF_OK;
+}
+
+extern "C" int rslf_multi_create(const int* devices, int n_devices, rslf_multi** out)
+{
+    if (!out)
+        return fail(RSLF_ERR_INVALID_ARG, "out is NULL");
+    *out = nullptr;
+    if (n_devices < 0 || n_devices > 64 || (n_devices > 0 && !devices))
+        return fail(RSLF_ERR_INVALID_ARG, "bad device list");
+    rslf_multi* m = new (std::nothrow) rslf_multi();
+    if (!m)
+        return fail(RSLF_ERR_ALLOC, "out of host memory");
+    const int n = n_devices > 0 ? n_devices : 1;
+    m->devs.resize(n);
+    for (int i = 0; i < n; i++) {
+        rslf_multi::Dev& d = m->devs[i];
+        int rc = rslf_ctx_create(n_devices > 0 ? devices[i] : 0, &d.ctx);   // a device may appear more than once
+        hipError_t e = hipSuccess;
+        if (rc == RSLF_OK) {
+            e = hipStreamCreateWithFlags(&d.s_up, hipStreamNonBlocking);
+            if (e == hipSuccess) e = hipStreamCreateWithFlags(&d.s_comp, hipStreamNonBlocking);
+            if (e == hipSuccess) e = hipStreamCreateWithFlags(&d.s_down, hipStreamNonBlocking);
+            for (int k = 0; k < 2 && e == hipSuccess; k++)
+                e = hipEventCreateWithFlags(&d.done[k], hipEventDisableTiming);
+            if (e != hipSuccess)
+                rc = fail(RSLF_ERR_HIP, "stream / event creation failed: %s", hipGetErrorString(e));
+        }
+        if (rc != RSLF_OK) {
+            const std::string msg = g_err;
+            (void)rslf_multi_destroy(m);
+            return fail(rc, "%s", msg.c_str());
+        }
+    }
+    *out = m;
+    return RSLF_OK;
+}
+
+extern "C" int rslf_multi_device_count(const rslf_multi* m) { return m ? (int)m->devs.size() : 0; }
+
+extern "C" int rslf_multi_set_chunk_rows(rslf_multi* m, int rows)
+{
+    if (!m || rows < 0)
+        return fail(RSLF_ERR_INVALID_ARG, "bad argument");
+    m->chunk_rows = rows;
+    return RSLF_OK;
+}
+
+namespace {
+
+struct MultiJob {
+    const void* const* h_epis;
+    bool is_u8;
+    size_t row_stride_bytes;
+    int V, S, U, C;
+    float scale_arg;      // f32: the divisor (already resolved, > 0 or as given); u8: unused
+    float dmin, dmax;
+    int dim_d, s_hat;
+    const rslf_params* p;
+    float* h_Ce;
+    uint8_t* h_mask;
+    float* h_Cd;
+    float* h_depth;
+    float* h_rbar;
+    int32_t* h_idx;
+    float* h_score;
+    float* h_raw;
+    int halo;
+};
+
+struct Chunk {
+    int a, b;     // owned rows [a, b) of the whole field
+    int lo, hi;   // computed rows: owned + halo, clipped
+};
+
+struct PlanePtrs {
+    float *Ce, *Cd, *depth, *raw, *score, *rbar;
+    int32_t* idx;
+    uint8_t* mask;
+};
+
+PlanePtrs carve(char* blk, size_t n, int C)
+{
+    PlanePtrs q;
+    q.Ce = (float*)blk;
+    q.Cd = q.Ce + n;
+    q.depth = q.Cd + n;
+    q.raw = q.depth + n;
+    q.score = q.raw + n;
+    q.rbar = q.score + n;
+    q.idx = (int32_t*)(q.rbar + n * C);
+    q.mask = (uint8_t*)(q.idx + n);
+    return q;
+}
+
+// One device's share: rows [r0, r1) of the field, chunk by chunk.  Returns an rslf status; `err` receives the message.
+int multi_worker(rslf_multi::Dev& d, const MultiJob& j, int r0, int r1, int chunk_rows, long long* scanned, int* kernel,
+                 int* spad, std::string* err)
+{
+#define MW_FAIL(rc_)                  \
+    do {                              \
+        *err = g_err;                 \
+        return (rc_);                 \
+    } while (0)
+#define MW_HIP(expr)                                                                                        \
+    do {                                                                                                    \
+        hipError_t e_ = (expr);                                                                             \
+        if (e_ != hipSuccess) {                                                                             \
+            (void)fail(RSLF_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            MW_FAIL(RSLF_ERR_HIP);                                                                          \
+        }                                                                                                   \
+    } while (0)
+    *scanned = 0;
+    if (r1 <= r0)
+        return RSLF_OK;
+    rslf_ctx* ctx = d.ctx;
+    MW_HIP(hipSetDevice(ctx->device));
+    std::vector<Chunk> chunks;
+    for (int a = r0; a < r1; a += chunk_rows) {
+        Chunk c;
+        c.a = a;
+        c.b = std::min(a + chunk_rows, r1);
+        c.lo = std::max(0, c.a - j.halo);
+        c.hi = std::min(j.V, c.b + j.halo);
+        chunks.push_back(c);
+    }
+    int max_rows = 0;
+    for (const Chunk& c : chunks)
+        max_rows = std::max(max_rows, c.hi - c.lo);
+    // two volumes and two sets of result planes, kept from call to call while the shape allows
+    for (int k = 0; k < 2; k++) {
+        if (d.vol[k] && (d.vol_rows[k] < max_rows || d.vol_S != j.S || d.vol_U != j.U || d.vol_C != j.C)) {
+            (void)rslf_volume_destroy(d.vol[k]);
+            d.vol[k] = nullptr;
+        }
+    }
+    d.vol_S = j.S, d.vol_U = j.U, d.vol_C = j.C;
+    for (int k = 0; k < 2; k++) {
+        if (!d.vol[k]) {
+            int rc = rslf_volume_create(ctx, max_rows, j.S, j.U, j.C, &d.vol[k]);
+            if (rc)
+                MW_FAIL(rc);
+            d.vol_rows[k] = max_rows;
+        }
+    }
+    const size_t n_max = (size_t)max_rows * j.U;
+    // result planes of one chunk + a copy of the scan's per-scanline pixel counts (the context's own array is
+    // rewritten by the next chunk's kernels, which are already queued when this chunk is collected)
+    const size_t plane_bytes = (n_max * ((5 + (size_t)j.C) * sizeof(float) + sizeof(int32_t) + 1) + 15) & ~(size_t)15;
+    const size_t bytes = plane_bytes + (size_t)max_rows * sizeof(int);
+    if (bytes > d.planes_cap) {
+        for (int k = 0; k < 2; k++) {
+            (void)hipFree(d.planes[k]);
+            d.planes[k] = nullptr;
+        }
+        d.planes_cap = 0;
+        for (int k = 0; k < 2; k++)
+            MW_HIP(hipMalloc(&d.planes[k], bytes));
+        d.planes_cap = bytes;
+    }
+    std::vector<int> counts((size_t)max_rows);
+
+    // a volume object of the chunk's height over the (larger or equal) allocation: rows beyond are simply unused
+    auto upload = [&](int k) -> int {
+        const Chunk& c = chunks[k];
+        rslf_volume* vol = d.vol[k & 1];
+        vol->V = c.hi - c.lo;
+        vol->bytes = (size_t)vol->V * vol->S * vol->C * vol->pitch * sizeof(float);
+        ctx->stream = d.s_up;
+        int rc;
+        if (j.is_u8)
+            rc = upload_host<uint8_t>(vol, (const uint8_t* const*)j.h_epis + c.lo, j.row_stride_bytes, false, (float)(1.0 / 255.0));
+        else
+            rc = upload_host<float>(vol, (const float* const*)j.h_epis + c.lo, j.row_stride_bytes, false, scale_of(j.scale_arg));
+        return rc;   // upload_host ends with a synchronisation of its stream (minmax_end)
+    };
+    auto compute = [&](int k) -> int {
+        const Chunk& c = chunks[k];
+        const size_t n = (size_t)(c.hi - c.lo) * j.U;
+        const PlanePtrs q = carve(d.planes[k & 1], n, j.C);
+        ctx->stream = d.s_comp;
+        int rc = rslf_depth1d_pile_run(ctx, d.vol[k & 1], j.dmin, j.dmax, j.dim_d, j.s_hat, j.p, q.Ce, q.mask, q.Cd, q.depth, q.rbar,
+                                       q.idx, q.score, q.raw, nullptr);
+        if (rc)
+            return rc;
+        *kernel = ctx->last_kernel;
+        *spad = ctx->last_spad;
+        hipError_t e = hipMemcpyAsync(d.planes[k & 1] + plane_bytes, ctx->count, (size_t)(c.hi - c.lo) * sizeof(int),
+                                      hipMemcpyDeviceToDevice, d.s_comp);
+        if (e == hipSuccess)
+            e = hipEventRecord(d.done[k & 1], d.s_comp);
+        return e == hipSuccess ? RSLF_OK : fail(RSLF_ERR_HIP, "queueing the chunk's completion failed: %s", hipGetErrorString(e));
+    };
+    auto download = [&](int k) -> int {
+        const Chunk& c = chunks[k];
+        const int rows = c.hi - c.lo;
+        const size_t n = (size_t)rows * j.U;
+        const PlanePtrs q = carve(d.planes[k & 1], n, j.C);
+        const size_t off = (size_t)(c.a - c.lo) * j.U, cnt = (size_t)(c.b - c.a) * j.U, dst = (size_t)c.a * j.U;
+        hipError_t e = hipStreamWaitEvent(d.s_down, d.done[k & 1], 0);
+        auto pull = [&](void* h, const void* dv, size_t esz, size_t mult) {
+            if (e == hipSuccess && h)
+                e = hipMemcpyAsync((char*)h + dst * esz * mult, (const char*)dv + off * esz * mult, cnt * esz * mult, hipMemcpyDeviceToHost,
+                                   d.s_down);
+        };
+        pull(j.h_Ce, q.Ce, 4, 1);
+        pull(j.h_mask, q.mask, 1, 1);
+        pull(j.h_Cd, q.Cd, 4, 1);
+        pull(j.h_depth, q.depth, 4, 1);
+        pull(j.h_rbar, q.rbar, 4, (size_t)j.C);
+        pull(j.h_idx, q.idx, 4, 1);
+        pull(j.h_score, q.score, 4, 1);
+        pull(j.h_raw, q.raw, 4, 1);
+        // pixels scanned on the owned rows: the per-scanline counts of the scan's pixel lists
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(counts.data(), d.planes[k & 1] + plane_bytes, (size_t)rows * sizeof(int), hipMemcpyDeviceToHost, d.s_down);
+        if (e == hipSuccess)
+            e = hipStreamSynchronize(d.s_down);
+        if (e != hipSuccess)
+            return fail(RSLF_ERR_HIP, "result download failed: %s", hipGetErrorString(e));
+        for (int r = c.a - c.lo; r < c.b - c.lo; r++)
+            *scanned += counts[(size_t)r];
+        return RSLF_OK;
+    };
+
+    hipStream_t saved = ctx->stream;
+    int rc = upload(0);
+    if (rc == RSLF_OK)
+        rc = compute(0);
+    for (int k = 0; rc == RSLF_OK && k < (int)chunks.size(); k++) {
+        // chunk k's kernels are queued: feed the next chunk, then collect this one
+        if (k + 1 < (int)chunks.size()) {
+            rc = upload(k + 1);            // volume (k+1)&1 was last read by chunk k-1, whose download has completed
+            if (rc == RSLF_OK)
+                rc = compute(k + 1);       // planes (k+1)&1 likewise; queued behind chunk k on the compute stream
+        }
+        if (rc == RSLF_OK)
+            rc = download(k);              // waits for chunk k's kernels; chunk k+1 runs meanwhile
+    }
+    if (rc != RSLF_OK) {
+        *err = g_err;
+        (void)hipDeviceSynchronize();
+    }
+    ctx->stream = saved;
+    for (int k = 0; k < 2; k++) {   // restore the volumes' full height for the next call's reuse test
+        d.vol[k]->V = d.vol_rows[k];
+        d.vol[k]->bytes = (size_t)d.vol[k]->V * d.vol[k]->S * d.vol[k]->C * d.vol[k]->pitch * sizeof(float);
+    }
+    return rc;
+#undef MW_FAIL
+#undef MW_HIP
+}
+
+float host_max_f32_parallel(const float* const* h_epis, int V, int S, size_t stride, size_t row_elems, float start)
+{
+    const int nt = std::max(1, std::min<int>(8, std::min<int>((int)std::thread::hardware_concurrency(), V / 8)));
+    std::vector<float> part((size_t)nt, start);
+    std::vector<std::thread> th;
+    for (int t = 0; t < nt; t++)
+        th.emplace_back([&, t] {
+            const int v0 = (int)((long long)V * t / nt), v1 = (int)((long long)V * (t + 1) / nt);
+            part[(size_t)t] = host_max_f32(h_epis + v0, v1 - v0, S, stride, row_elems, start);
+        });
+    float m = start;
+    for (int t = 0; t < nt; t++) {
+        th[(size_t)t].join();
+        m = std::max(m, part[(size_t)t]);
+    }
+    return m;
+}
+
+int multi_run(rslf_multi* m, MultiJob j, rslf_stats* stats)
+{
+    if (!m || !j.h_epis)
+        return fail(RSLF_ERR_INVALID_ARG, "NULL argument");
+    if (j.V < 1 || j.S < 1 || j.U < 1 || (j.C != 1 && j.C != 3))
+        return fail(RSLF_ERR_INVALID_ARG, "bad dimensions V=%d S=%d U=%d C=%d", j.V, j.S, j.U, j.C);
+    int rc = check_params(j.p);
+    if (rc)
+        return rc;
+    for (int v = 0; v < j.V; v++)
+        if (!j.h_epis[v])
+            return fail(RSLF_ERR_INVALID_ARG, "h_epis[%d] is NULL", v);
+    j.s_hat = resolve_s_hat(j.s_hat, j.S);
+    // rows either side of a chunk that must be recomputed for the chunk's own rows to come out exact: the median
+    // reads +-(size-1)/2 rows (core.hpp:686), and through the optional opening +-2*(k/2) rows more (core.hpp:759-768)
+    j.halo = (j.p->median_filter_size - 1) / 2 + (j.p->edge_confidence_opening_size > 1 ? 2 * (j.p->edge_confidence_opening_size / 2) : 0);
+    const int nd = (int)m->devs.size();
+    std::vector<long long> scanned((size_t)nd, 0);
+    std::vector<int> rcs((size_t)nd, RSLF_OK), kern((size_t)nd, 0), spads((size_t)nd, 0);
+    std::vector<std::string> errs((size_t)nd);
+    std::vector<std::thread> th;
+    for (int i = 0; i < nd; i++) {
+        const int r0 = (int)((long long)j.V * i / nd), r1 = (int)((long long)j.V * (i + 1) / nd);
+        // chunks: enough of them to overlap the copies with the kernels, large enough to keep the halo's share small
+        int chunk = m->chunk_rows > 0 ? m->chunk_rows : std::max(32, (r1 - r0 + 7) / 8);
+        chunk = std::max(1, std::min(chunk, std::max(1, r1 - r0)));
+        th.emplace_back([&, i, r0, r1, chunk] {
+            rcs[(size_t)i] = multi_worker(m->devs[(size_t)i], j, r0, r1, chunk, &scanned[(size_t)i], &kern[(size_t)i], &spads[(size_t)i],
+                                          &errs[(size_t)i]);
+        });
+    }
+    for (auto& t : th)
+        t.join();
+    for (int i = 0; i < nd; i++)
+        if (rcs[(size_t)i] != RSLF_OK)
+            return fail(rcs[(size_t)i], "device %d: %s", m->devs[(size_t)i].ctx->device, errs[(size_t)i].c_str());
+    if (stats) {
+        long long tot = 0;
+        for (long long s : scanned)
+            tot += s;
+        stats->pixels_scanned = tot;
+        stats->units = tot * j.dim_d;
+        stats->scan_kernel = kern[0];
+        stats->s_pad = spads[0];
+    }
+    return RSLF_OK;
+}
+
+}  // namespace
+
+extern "C" int rslf_multi_depth1d_pile_f32(rslf_multi* m, const float* const* h_epis, size_t row_stride_bytes, int V, int S, int U,
+                                           int C, float epi_scale_factor, float dmin, float dmax, int dim_d, int s_hat,
+                                           const rslf_params* p, float* h_Ce_vu, uint8_t* h_Ce_mask_vu, float* h_Cd_vu,
+                                           float* h_depth_vu, float* h_rbar_vu, int32_t* h_idx_vu, float* h_score_vu,
+                                           float* h_depth_raw_vu, rslf_stats* stats, float* scale_used)
+{
+    if (!m || !h_epis || V < 1)
+        return fail(RSLF_ERR_INVALID_ARG, "NULL argument");
+    const size_t row_elems = (size_t)U * C;
+    const size_t stride = row_stride_bytes ? row_stride_bytes : row_elems * sizeof(float);
+    for (int v = 0; v < V; v++)
+        if (!h_epis[v])
+            return fail(RSLF_ERR_INVALID_ARG, "h_epis[%d] is NULL", v);
+    // dc.hpp:442-460: the default scale is the maximum over ALL EPIs -- taken once here, never per block
+    if (epi_scale_factor < 0)
+        epi_scale_factor = host_max_f32_parallel(h_epis, V, S, stride, row_elems, epi_scale_factor);
+    if (scale_used)
+        *scale_used = epi_scale_factor;
+    MultiJob j = {(const void* const*)h_epis, false, stride, V, S, U, C, epi_scale_factor, dmin, dmax, dim_d, s_hat, p,
+                  h_Ce_vu, h_Ce_mask_vu, h_Cd_vu, h_depth_vu, h_rbar_vu, h_idx_vu, h_score_vu, h_depth_raw_vu, 0};
+    return multi_run(m, j, stats);
+}
+
+extern "C" int rslf_multi_depth1d_pile_u8(rslf_multi* m, const uint8_t* const* h_epis, size_t row_stride_bytes, int V, int S, int U,
+                                          int C, float dmin, float dmax, int dim_d, int s_hat, const rslf_params* p, float* h_Ce_vu,
+                                          uint8_t* h_Ce_mask_vu, float* h_Cd_vu, float* h_depth_vu, float* h_rbar_vu, int32_t* h_idx_vu,
+                                          float* h_score_vu, float* h_depth_raw_vu, rslf_stats* stats)
+{
+    MultiJob j = {(const void* const*)h_epis, true, row_stride_bytes, V, S, U, C, 255.0f, dmin, dmax, dim_d, s_hat, p,
+                  h_Ce_vu, h_Ce_mask_vu, h_Cd_vu, h_depth_vu, h_rbar_vu, h_idx_vu, h_score_vu, h_depth_raw_vu, 0};
+    return multi_run(m, j, stats);
+}

@@ -396,6 +396,70 @@ class Depth1DComputer_pile:
         )
 
 
+class MultiDevice:
+    """rslf_multi: Depth1DComputer_pile's constructor + run() + result Mats in one call on HOST arrays, the scanlines cut
+    into one block per device (and every block into chunks whose upload, kernels and download overlap).  Host planes
+    come back as numpy arrays; no collective is involved (each device writes its rows of the caller's planes)."""
+
+    def __init__(self, devices: Sequence[int] | None = None):
+        devs = list(devices) if devices else []
+        arr = (C.c_int * max(1, len(devs)))(*devs) if devs else None
+        h = C.c_void_p()
+        check(_lib.lib().rslf_multi_create(arr, len(devs), C.byref(h)), "rslf_multi_create")
+        self._h = h
+
+    def device_count(self) -> int:
+        return int(_lib.lib().rslf_multi_device_count(self._h))
+
+    def set_chunk_rows(self, rows: int) -> None:
+        check(_lib.lib().rslf_multi_set_chunk_rows(self._h, int(rows)), "rslf_multi_set_chunk_rows")
+
+    def depth1d_pile(self, epis: Sequence[np.ndarray], dmin: float, dmax: float, dim_d: int, s_hat: int = -1,
+                     epi_scale_factor: float = -1.0, parameters: Depth1DParameters | None = None) -> dict:
+        """epis: the reference's Vec<Mat> -- V arrays [S,U] or [S,U,3], all uint8 or all float32."""
+        first = np.asarray(epis[0])
+        dt = first.dtype
+        if dt not in (np.uint8, np.float32):
+            raise TypeError("EPIs must be uint8 or float32 (dc.hpp:149-154)")
+        keep = [np.ascontiguousarray(e, dtype=dt) for e in epis]   # keeps the buffers alive over the call
+        V = len(keep)
+        S, U = keep[0].shape[0], keep[0].shape[1]
+        C_ = 1 if keep[0].ndim == 2 else keep[0].shape[2]
+        ptrs = (C.c_void_p * V)(*[e.ctypes.data for e in keep])
+        out = dict(edge_confidence=np.empty((V, U), np.float32), edge_mask=np.empty((V, U), np.uint8),
+                   disp_confidence=np.empty((V, U), np.float32), depth=np.empty((V, U), np.float32),
+                   rbar=np.empty((V, U, C_), np.float32), depth_idx=np.empty((V, U), np.int32),
+                   score=np.empty((V, U), np.float32), depth_raw=np.empty((V, U), np.float32))
+        hp = [out[k].ctypes.data_as(C.c_void_p) for k in ("edge_confidence", "edge_mask", "disp_confidence", "depth", "rbar",
+                                                         "depth_idx", "score", "depth_raw")]
+        p = (parameters or Depth1DParameters()).to_c()
+        st = RslfStats()
+        L = _lib.lib()
+        if dt == np.uint8:
+            check(L.rslf_multi_depth1d_pile_u8(self._h, ptrs, 0, V, S, U, C_, float(dmin), float(dmax), int(dim_d), int(s_hat),
+                                               C.byref(p), *hp, C.byref(st)), "rslf_multi_depth1d_pile_u8")
+            self.scale_used = 255.0
+        else:
+            su = C.c_float()
+            check(L.rslf_multi_depth1d_pile_f32(self._h, ptrs, 0, V, S, U, C_, float(epi_scale_factor), float(dmin), float(dmax),
+                                                int(dim_d), int(s_hat), C.byref(p), *hp, C.byref(st), C.byref(su)),
+                  "rslf_multi_depth1d_pile_f32")
+            self.scale_used = float(su.value)
+        self.stats = st
+        return out
+
+    def close(self) -> None:
+        if getattr(self, "_h", None) and not sys.is_finalizing():
+            _lib.lib().rslf_multi_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+
 # ---- "next" row: the 2-D sweep (SURVEY.md 8f rank 2) -------------------------
 
 def compute_2D_edge_confidence(vol: Volume, a_edge_confidence_s_v_u: torch.Tensor,

@@ -83,6 +83,31 @@ def make_shard(V: int, rank: int, world: int, median_filter_size: int = 5, openi
     return Shard(rank, world, V, v0, v1, max(0, v0 - halo), min(V, v1 + halo))
 
 
+def global_epi_scale(local_max: float, epi_scale_factor: float, group=None) -> float:
+    """The scale every rank must normalise its rows with so that the stitched planes equal the unsharded run.
+
+    The constructor's default (epi_scale_factor < 0) divides by the maximum over ALL EPIs (dc.hpp:442-460, :474); a rank
+    that built its volume from its own rows alone would divide by its block's maximum, and every threshold of the path
+    would then act on differently scaled radiances from block to block.  So: one scalar all-reduce (MAX) of the raw
+    maxima -- the only collective besides the reassembly, and exact in any order.  `local_max` is the maximum of this
+    rank's raw rows (block + halo); a given scale (>= 0) is returned unchanged."""
+    if epi_scale_factor >= 0:
+        return float(epi_scale_factor)
+    m = torch.tensor([float(local_max)], dtype=torch.float32)
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        if dist.get_backend(group) == "nccl":
+            m = m.cuda()
+        dist.all_reduce(m, op=dist.ReduceOp.MAX, group=group)
+    return float(m.item())
+
+
+def require_explicit_scale(epi_scale_factor: float, world: int) -> None:
+    """A sharded run must not be built with the 'max over my own rows' default: see global_epi_scale."""
+    if world > 1 and epi_scale_factor < 0:
+        raise ValueError("a sharded run needs one scale for all ranks: pass sharding.global_epi_scale(local_max, %g) "
+                         "instead of epi_scale_factor=%g" % (epi_scale_factor, epi_scale_factor))
+
+
 def _row_bytes(U: int, C: int) -> int:
     n = 0
     for _, dt, per_c in PLANES:

@@ -105,6 +105,50 @@ static int run_sweeps(rslfx::Context& ctx, const std::string& dir)
     return f2c.pyramid_depth() == 3 ? 0 : 8;   // 44x64 -> 22x32 -> 11x16, then 6x8 stops the pyramid
 }
 
+// The multi-device form (rslfx::MultiContext): two workers on ONE GPU, three scanlines per chunk -- every plane must
+// equal the single-context run bit for bit, default normalisation (the maximum over ALL EPIs) included.
+template <int C>
+static int run_multi(rslfx::Context& ctx, bool u8)
+{
+    const int V = 29, S = 9, U = 96, D = 14;
+    std::vector<std::vector<float> > epis_f(V);
+    std::vector<std::vector<unsigned char> > epis_u8(V);
+    std::vector<const void*> ptrs(V);
+    unsigned state = 4242u + (unsigned)C;
+    for (int v = 0; v < V; v++) {
+        epis_f[v].resize((size_t)S * U * C);
+        epis_u8[v].resize((size_t)S * U * C);
+        for (size_t i = 0; i < epis_f[v].size(); i++) {
+            state = state * 1664525u + 1013904223u;
+            const unsigned r = (state >> 8) & 0xffffu;
+            epis_u8[v][i] = (unsigned char)(r & 0xffu);
+            // the brightest rows are the last ones: a block-local maximum would rescale the first block
+            epis_f[v][i] = (v < V / 2 ? 40.0f : 3.0f) + (v < V / 2 ? 60.0f : 250.0f) * (float)r / 65535.0f;
+        }
+        ptrs[v] = u8 ? (const void*)epis_u8[v].data() : (const void*)epis_f[v].data();
+    }
+    rslfx::Depth1DComputer_pile<C> one(ctx, ptrs.data(), u8, V, S, U, 0, -1.0f, 2.0f, D);
+    one.run();
+    rslfx::MultiContext multi(std::vector<int>(2, 0));
+    multi.set_chunk_rows(3);
+    rslfx::Depth1DComputer_pile<C> two(multi, ptrs.data(), u8, V, S, U, 0, -1.0f, 2.0f, D);
+    two.run();
+    int bad = 0;   // one bit per plane / figure that differs
+    bad |= (one.m_edge_confidence_v_u != two.m_edge_confidence_v_u) << 0;
+    bad |= (one.m_edge_confidence_mask_v_u != two.m_edge_confidence_mask_v_u) << 1;
+    bad |= (one.m_disp_confidence_v_u != two.m_disp_confidence_v_u) << 2;
+    bad |= (one.m_best_depth_v_u != two.m_best_depth_v_u) << 3;
+    bad |= (one.m_rbar_v_u != two.m_rbar_v_u) << 4;
+    bad |= (one.m_depth_idx_v_u != two.m_depth_idx_v_u) << 5;
+    bad |= (one.m_score_v_u != two.m_score_v_u) << 6;
+    bad |= (one.stats.pixels_scanned != two.stats.pixels_scanned) << 7;
+    bad |= (one.epi_scale_factor() != two.epi_scale_factor()) << 8;
+    std::printf("multi C=%d %s: %d devices, %lld px scanned (single context %lld), scale %.9g (%.9g), %s 0x%x\n", C,
+                u8 ? "u8" : "f32", multi.device_count(), (long long)two.stats.pixels_scanned, (long long)one.stats.pixels_scanned,
+                two.epi_scale_factor(), one.epi_scale_factor(), bad ? "MISMATCH" : "planes identical", bad);
+    return bad ? 16 : 0;
+}
+
 int main(int argc, char** argv)
 {
     const std::string dir = argc > 1 ? argv[1] : ".";
@@ -115,6 +159,8 @@ int main(int argc, char** argv)
         rc |= run_case<3>(ctx, dir, "f32_3ch", false);
         rc |= run_case<3>(ctx, dir, "u8_3ch", true);
         rc |= run_sweeps(ctx, dir);
+        rc |= run_multi<1>(ctx, false);
+        rc |= run_multi<3>(ctx, true);
         // error convention: the C-ABI never throws; the C++ wrapper turns its status into rslfx::Error
         bool threw = false;
         try {

@@ -126,3 +126,15 @@ def test_product_does_not_import_the_oracle():
                     if re.search(r"^\s*(import|from)\s+oracle\b", txt, flags=re.M) or "rslf_oracle" in txt or "liboracle" in txt:
                         bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+def test_opencv_block_compiles():
+    """The cv::Mat constructors and getters of include/rslf_hip.hpp (north_star's literal 'cv::Mat in / cv::Mat out') are
+    compiled -- syntax and types only -- against a declaration-only mock of the few cv::Mat members they touch: this image
+    has no OpenCV, and without this the block had never met a compiler."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run(["g++", "-std=c++11", "-fsyntax-only", "-Wall", "-I", os.path.join(root, "include"),
+                        "-I", os.path.join(root, "tests", "cpp", "opencv_mock"), os.path.join(root, "tests", "cpp", "opencv_block.cpp")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr

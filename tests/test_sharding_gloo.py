@@ -105,3 +105,59 @@ def test_pack_unpack_roundtrip():
     out = sharding.unpack_planes(bufs, parts, max_rows, U, C)
     for k in full:
         assert torch.equal(out[k], full[k]), k
+
+
+def _scale_worker(rank, world, port, V, S, U, D, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import oracle
+        raw = _raw_field(V, S, U)
+        shard = sharding.make_shard(V, rank, world, 5)
+        mine = raw[shard.rows]
+        # the constructor's default scale (-1 = max over all EPIs): one MAX all-reduce makes it the same on every rank
+        scale = sharding.global_epi_scale(float(mine.max()), -1.0)
+        vol, used = oracle.normalize_f32(mine, scale)
+        r = oracle.depth1d_pile_run(vol, -1.0, 2.0, D)
+        planes = dict(edge_confidence=torch.from_numpy(r.edge_confidence), disp_confidence=torch.from_numpy(r.disp_confidence),
+                      depth=torch.from_numpy(r.depth), depth_raw=torch.from_numpy(r.depth_raw), score=torch.from_numpy(r.score),
+                      depth_idx=torch.from_numpy(r.depth_idx), rbar=torch.from_numpy(r.rbar), edge_mask=torch.from_numpy(r.edge_mask))
+        out = sharding.gather_planes(planes, shard, U, 1)
+        if rank == 0:
+            np.savez(out_path, scale=np.float32(scale), **{k: v.numpy() for k, v in out.items()})
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def _raw_field(V, S, U):
+    """Un-normalised float radiances whose maximum sits in the LAST block, so a block-local maximum differs."""
+    from remotesensingproject_amd.synth import make_lightfield
+    vol, _ = make_lightfield(U, V, S, 1, seed=5, dmin=-1.0, dmax=2.0, band=3)
+    raw = (vol * np.float32(180.0)).astype(np.float32)
+    raw[:V // 2] *= np.float32(0.35)     # darker first half: its own maximum would rescale it by almost 3
+    return raw
+
+
+def test_sharded_default_normalisation_uses_the_global_maximum(tmp_path, oracle_mod):
+    """with epi_scale_factor < 0 every rank must divide by the maximum over ALL EPIs (dc.hpp:442-474), not
+    by the maximum of its own block -- else thresholds act on differently scaled radiances and the stitched planes
+    show seams.  global_epi_scale() all-reduces the raw maxima; the stitched planes then equal the unsharded run."""
+    V, S, U, D, world = 12, 9, 48, 12, 2
+    out_path = str(tmp_path / "scaled.npz")
+    mp.spawn(_scale_worker, args=(world, _free_port(), V, S, U, D, out_path), nprocs=world, join=True)
+    got = np.load(out_path)
+    raw = _raw_field(V, S, U)
+    vol, used = oracle_mod.normalize_f32(raw, -1.0)
+    assert float(got["scale"]) == float(raw.max()) == used
+    ref = oracle_mod.depth1d_pile_run(vol, -1.0, 2.0, D)
+    for k in ("edge_confidence", "edge_mask", "disp_confidence", "depth", "rbar", "depth_idx", "score", "depth_raw"):
+        assert np.array_equal(got[k], getattr(ref, k)), k
+    # and the block-local maximum would indeed have given different planes (the test field is built for that)
+    half, _ = oracle_mod.normalize_f32(raw[:V // 2 + 2], -1.0)
+    assert not np.array_equal(oracle_mod.depth1d_pile_run(half, -1.0, 2.0, D).edge_confidence[:V // 2], ref.edge_confidence[:V // 2])
+    with pytest.raises(ValueError):
+        sharding.require_explicit_scale(-1.0, 2)
+    sharding.require_explicit_scale(-1.0, 1)
+    sharding.require_explicit_scale(255.0, 8)
