@@ -94,6 +94,17 @@ def end_to_end(rs, host: np.ndarray, cfg: dict, units: int, device: int) -> dict
             "input_gb": host.nbytes / 1e9}
 
 
+def pick_config(args, default_for_c3: str | None = None) -> tuple[dict, str]:
+    """--config, or --shape U,V,S,C,D,dmin,dmax for a synthetic field of another size (context lines)."""
+    from remotesensingproject_amd.synth import CONFIGS
+    if args.shape:
+        U, V, S, C_, D = [int(x) for x in args.shape.split(",")[:5]]
+        dmin, dmax = [float(x) for x in args.shape.split(",")[5:7]]
+        return dict(U=U, V=V, S=S, C=C_, D=D, dmin=dmin, dmax=dmax, seed=20260099), "shape " + args.shape
+    name = args.config if not (default_for_c3 and args.config == "c3" and not args.config_given) else default_for_c3
+    return dict(CONFIGS[name]), name
+
+
 def bench_sweep2d(args) -> None:
     """Depth2DComputer::run() (dc.hpp:748-805) on a synthetic field: a step = edge confidence of every view
     + one visit per view (scan on the running mask, median, propagation).  Units = pixels actually scanned,
@@ -103,7 +114,7 @@ def bench_sweep2d(args) -> None:
     from remotesensingproject_amd.synth import CONFIGS, make_lightfield
     if args.gpus != 1:
         raise SystemExit("the 2-D sweep bench is single-GPU")
-    cfg = dict(CONFIGS[args.config if args.config != "c3" else "c2"])
+    cfg, cfg_name = pick_config(args, "c2")
     if args.rows:
         cfg["V"] = args.rows
     U, V, S, C, D = cfg["U"], cfg["V"], cfg["S"], cfg["C"], cfg["D"]
@@ -127,7 +138,7 @@ def bench_sweep2d(args) -> None:
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "2-D sweep (Depth2DComputer::run) over %s: %dx%d px x %d views x %d ch, %d hypotheses; %d visits, "
                                "%d pixels scanned in total (%.2f views' worth)" % (
-                                   args.config if args.config != "c3" else "c2", U, V, S, C, D, S, units // D, units / D / (U * V)),
+                                   cfg_name, U, V, S, C, D, S, units // D, units / D / (U * V)),
                    "path": "sweep2d"},
     }), flush=True)
 
@@ -138,7 +149,7 @@ def bench_f2c(args) -> None:
     import torch
     from remotesensingproject_amd import depth as rs
     from remotesensingproject_amd.synth import CONFIGS, make_lightfield
-    cfg = dict(CONFIGS[args.config if args.config != "c3" else "c2"])
+    cfg, cfg_name = pick_config(args, "c2")
     if args.rows:
         cfg["V"] = args.rows
     U, V, S, C, D = cfg["U"], cfg["V"], cfg["S"], cfg["C"], cfg["D"]
@@ -167,7 +178,7 @@ def bench_f2c(args) -> None:
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "fine-to-coarse (FineToCoarse ctor + run + get_results, host upload included) over %s: %dx%d px x %d views "
-                               "x %d ch, %d hypotheses; pyramid %s" % (args.config if args.config != "c3" else "c2", U, V, S, C, D, dims),
+                               "x %d ch, %d hypotheses; pyramid %s" % (cfg_name, U, V, S, C, D, dims),
                    "path": "f2c", "pixels_scanned": units // D},
     }), flush=True)
 
@@ -194,7 +205,8 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", default="c3", help="synthetic config of BASELINE.md section 4 (c2, c3, c5)")
+    ap.add_argument("--config", default=None, help="synthetic config of BASELINE.md section 4 (c1, c2, c3, c5); default c3")
+    ap.add_argument("--shape", default="", help="U,V,S,C,D,dmin,dmax: a synthetic field of another size (sweep2d / f2c paths)")
     ap.add_argument("--rows", type=int, default=0, help="override the number of scanlines (developer runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the host-in / host-out figure (the `e2e` key)")
@@ -202,6 +214,8 @@ def main() -> None:
                     help="pile = Depth1DComputer_pile::run (the headline path); sweep2d = Depth2DComputer::run, the 'next' row "
                          "(all views, centre outwards, with propagation), 1 GPU only")
     args = ap.parse_args()
+    args.config_given = args.config is not None
+    args.config = args.config or "c3"
     if args.gpus > 1 and "RANK" not in os.environ:
         return launch_ranks(args.gpus)
     if args.path == "sweep2d":

@@ -157,15 +157,22 @@ __global__ __launch_bounds__(256) void k1_edge_confidence(VolView vol, int s, Ed
     if (u >= vol.U)
         return;
     const float* r0 = vol.row(v, s);
-    const int centre = (ec.filter_size - 1) / 2;
     const long long o = (long long)v * vol.U + u;
+    const float ce = edge_confidence_pixel<C>(vol, r0, u, ec, Ce[o]);
+    Ce[o] = ce;
+    mask[o] = (ce > ec.edge_thr) ? 255 : 0;
+}
 
+// One pixel's edge confidence, shadow cut applied (core.hpp:449-474); `ce` is what the caller's plane held.
+template <int C>
+__device__ __forceinline__ float edge_confidence_pixel(const VolView& vol, const float* __restrict__ r0, int u, const EdgeConsts& ec,
+                                                       float ce)
+{
+    const int centre = (ec.filter_size - 1) / 2;
     float e[C];
 #pragma unroll
     for (int c = 0; c < C; c++)
         e[c] = r0[u * C + c];
-
-    float ce = Ce[o];
     for (int j = 0; j < ec.filter_size; j++) {
         if (j == centre)
             continue;
@@ -186,8 +193,56 @@ __global__ __launch_bounds__(256) void k1_edge_confidence(VolView vol, int s, Ed
         if (n < ec.shadow_level)
             ce = 0.0f;
     }
-    Ce[o] = ce;
-    mask[o] = (ce > ec.edge_thr) ? 255 : 0;
+    return ce;
+}
+
+// K1 and the compaction of the scan mask in ONE launch (the pile step: Depth1DComputer_pile::run, dc.hpp:538-547, when
+// the edge mask is not opened and the caller passes no scan mask -- then the scan mask IS the edge mask, core.hpp:513).
+// One block per scanline: it computes the scanline's C_e and mask 256 pixels at a time and appends the confident u to
+// the scanline's list in the same sweep (the list the scan's tiles are cut from).
+template <int C>
+__global__ __launch_bounds__(256) void k1_edge_confidence_compact(VolView vol, int s, EdgeConsts ec, float* __restrict__ Ce,
+                                                                 uint8_t* __restrict__ mask, int* __restrict__ list,
+                                                                 int* __restrict__ count, unsigned long long* __restrict__ total)
+{
+    const int v = blockIdx.x;
+    const int U = vol.U;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const float* r0 = vol.row(v, s);
+    __shared__ int wave_tot[4];
+    __shared__ int base_s;
+    if (threadIdx.x == 0)
+        base_s = 0;
+    __syncthreads();
+    for (int u0 = 0; u0 < U; u0 += 256) {
+        const int u = u0 + threadIdx.x;
+        bool f = false;
+        if (u < U) {
+            const long long o = (long long)v * U + u;
+            const float ce = edge_confidence_pixel<C>(vol, r0, u, ec, Ce[o]);
+            Ce[o] = ce;
+            f = ce > ec.edge_thr;                 // core.hpp:476
+            mask[o] = f ? 255 : 0;
+        }
+        const unsigned long long b = __ballot(f);
+        const int rank = __popcll(b & ((1ull << lane) - 1ull));
+        if (lane == 0)
+            wave_tot[w] = __popcll(b);
+        __syncthreads();
+        int off = base_s;
+        for (int i = 0; i < w; i++)
+            off += wave_tot[i];
+        if (f)
+            list[(long long)v * U + off + rank] = u;
+        __syncthreads();
+        if (threadIdx.x == 0)
+            base_s += wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        count[v] = base_s;
+        atomicAdd(total, (unsigned long long)base_s);
+    }
 }
 
 // ---- optional morphological opening of the edge mask -----------------------

@@ -7,7 +7,7 @@
 //
 // Variants: k2_scan_reg (samples held in registers; scalar, or packed fp32 at one wave per SIMD),
 // k2_scan_stream (samples re-gathered every pass), k2_scan_generic (any input, nearest-neighbour modes),
-// k2_kernel_column (the optional K output), k2_scan_combine (merges hypothesis groups).
+// k2_kernel_column (the optional K output); hypothesis groups merge their records in the epilogue (combine_tile).
 //
 // Work mapping (every variant)
 //   workgroup = one tile: 64 consecutive entries of one scanline's confident-pixel list
@@ -63,6 +63,7 @@ struct ScanArgs {
     // them in hypothesis order.
     int groups;
     struct Partial* partial;   // [tile][group][64]
+    int* ticket;               // [tile], zero between launches: the group that draws the last ticket merges the tile
     int v0;                    // row tiles: first scanline of this launch (grouped dense launches go by row blocks)
     // Packed tiles (sparse launches): `list` is ONE list of pixel indices v*U + u over all scanlines,
     // *packed_n long, and a tile is 64 consecutive entries of it -- lanes of a wave then sit on different
@@ -193,8 +194,11 @@ __device__ __forceinline__ void write_pixel(const ScanArgs& a, long long o, floa
     }
 }
 
+template <int C>
+__device__ __forceinline__ void combine_tile(const ScanArgs& a, int tile, int v, int u);
+
 // Merge the waves' partial results in hypothesis order (first maximum wins, cv::minMaxLoc) and either
-// write the pixel (groups == 1) or leave this group's record for k2_scan_combine.
+// write the pixel (groups == 1) or leave this group's record -- the last group to finish merges the records.
 template <int C>
 __device__ __forceinline__ void scan_epilogue(const ScanArgs& a, int lb, int v, int u, bool active, const Best<C>& mine)
 {
@@ -246,17 +250,34 @@ __device__ __forceinline__ void scan_epilogue(const ScanArgs& a, int lb, int v, 
 #pragma unroll
         for (int c = 0; c < C; c++)
             pr.rbar[c] = best_rbar[c];
+        // The group that finishes LAST merges the tile's records (no combine launch).  Hand-off between workgroups
+        // that may sit on different XCDs (their L2s are not coherent): every lane's record is made visible at agent
+        // scope (release fence) before lane 0 draws the ticket; the group that draws the last one acquires at agent
+        // scope before it reads the other groups' records (MI355X_MICROARCH.md "Correctness boundaries").
+        __threadfence();
+        const int tile = lb / a.groups;
+        int drawn = 0;
+        if (lane == 0)
+            drawn = atomicAdd(&a.ticket[tile], 1);
+        drawn = __builtin_amdgcn_readfirstlane(drawn);
+        if (drawn != a.groups - 1)
+            return;
+        __threadfence();
+        if (active)
+            combine_tile<C>(a, tile, v, u);
+        if (lane == 0)
+            a.ticket[tile] = 0;   // clean for the next launch (kernel boundary orders it)
         return;
     }
     if (active)
         write_pixel<C>(a, (long long)v * a.vol.U + u, best, best_d, best_D, best_rbar, sum);
 }
 
-// groups > 1: one wave per tile merges the groups' records in hypothesis order and writes the pixels.
+// groups > 1: the wave that drew the tile's last ticket merges the groups' records in hypothesis order and writes the pixels.
 template <int C>
 __device__ __forceinline__ void combine_tile(const ScanArgs& a, int tile, int v, int u)
 {
-    const Partial* pr = a.partial + (long long)tile * a.groups * 64 + threadIdx.x;
+    const Partial* pr = a.partial + (long long)tile * a.groups * 64 + (threadIdx.x & 63);
     float best = pr[0].score, best_D = pr[0].D;
     int best_d = pr[0].d;
     float best_rbar[C];
@@ -277,32 +298,6 @@ __device__ __forceinline__ void combine_tile(const ScanArgs& a, int tile, int v,
         }
     }
     write_pixel<C>(a, (long long)v * a.vol.U + u, best, best_d, best_D, best_rbar, sum);
-}
-
-template <int C>
-__global__ __launch_bounds__(64) void k2_scan_combine(ScanArgs a)
-{
-    if (a.packed) {
-        const int n = *a.packed_n;
-        for (int tile = blockIdx.x; tile * 64 < n; tile += gridDim.x) {
-            const int e = tile * 64 + (int)threadIdx.x;
-            if (e < n) {
-                const unsigned o = (unsigned)a.list[e];
-                const int v = (int)(o / (unsigned)a.vol.U);
-                combine_tile<C>(a, tile, v, (int)(o - (unsigned)v * (unsigned)a.vol.U));
-            }
-        }
-        return;
-    }
-    const int tile = blockIdx.x;
-    const int vr = tile / a.tiles_per_row;
-    const int j = tile - vr * a.tiles_per_row;
-    const int v = vr + a.v0;
-    const int n = a.count[v];
-    const int e = j * a.tile_w + (int)threadIdx.x;
-    if ((int)threadIdx.x >= a.tile_w || e >= n)
-        return;
-    combine_tile<C>(a, tile, v, a.list[(long long)v * a.vol.U + e]);
 }
 
 // ---------------------------------------------------------------------------

@@ -17,23 +17,13 @@ namespace rslf {
 
 constexpr int kMedianMaxSize = 7;   // window side; 49 LDS slots per thread
 
+// The median of one mask pixel (v, u); `cand` is the block's [size*size][256] LDS array.
 template <int C>
-__global__ __launch_bounds__(256) void k3_selective_median(VolView vol, const float* __restrict__ src,
-                                                          float* __restrict__ dst, const uint8_t* __restrict__ mask,
-                                                          int s_hat, int size, float eps)
+__device__ __forceinline__ float selective_median_pixel(const VolView& vol, const float* __restrict__ src,
+                                                        const uint8_t* __restrict__ mask, int s_hat, int size, float eps, int v,
+                                                        int u, float (*cand)[256])
 {
-    extern __shared__ __attribute__((aligned(16))) float s_median_cand[];   // [size*size][256]
-    float (*cand)[256] = reinterpret_cast<float (*)[256]>(s_median_cand);
-    const int v = blockIdx.y;
-    const int u = blockIdx.x * blockDim.x + threadIdx.x;
-    if (u >= vol.U)
-        return;
     const int U = vol.U, V = vol.V;
-    const long long o = (long long)v * U + u;
-    if (!mask[o]) {
-        dst[o] = 0.0f;
-        return;
-    }
     const int w = (size - 1) / 2;
     const float* rc = vol.row(v, s_hat);
     float ec[C];
@@ -76,7 +66,22 @@ __global__ __launch_bounds__(256) void k3_selective_median(VolView vol, const fl
             break;
         }
     }
-    dst[o] = out;
+    return out;
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void k3_selective_median(VolView vol, const float* __restrict__ src,
+                                                          float* __restrict__ dst, const uint8_t* __restrict__ mask,
+                                                          int s_hat, int size, float eps)
+{
+    extern __shared__ __attribute__((aligned(16))) float s_median_cand[];   // [size*size][256]
+    float (*cand)[256] = reinterpret_cast<float (*)[256]>(s_median_cand);
+    const int v = blockIdx.y;
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= vol.U)
+        return;
+    const long long o = (long long)v * vol.U + u;
+    dst[o] = mask[o] ? selective_median_pixel<C>(vol, src, mask, s_hat, size, eps, v, u, cand) : 0.0f;
 }
 
 }  // namespace rslf

@@ -13,30 +13,20 @@
 // Both passes are HBM-bound streaming kernels (a few bytes per (s, v, u)).
 #pragma once
 
+#include "k3_median.hpp"
 #include "rslf_device.hpp"
 
 namespace rslf {
 
 constexpr int kNoWinner = 0x7F7F7F7F;   // what hipMemset(0x7F) leaves; >= any column index
 
+// One source pixel's claims (core.hpp:1105-1125): `cur` is its filtered disparity.
 template <int C>
-__global__ __launch_bounds__(256) void k4_propagate_claim(VolView vol, int s_hat, const float* __restrict__ filtered_vu,
-                                                         const uint8_t* __restrict__ edge_mask_vu,
-                                                         const float* __restrict__ rbar_vu,
-                                                         const uint8_t* __restrict__ mask_svu, int* __restrict__ winner_svu,
-                                                         float slope, float prop_eps, const float* __restrict__ gate_Cd_vu,
-                                                         float disp_thr)
+__device__ __forceinline__ void propagate_claim_pixel(const VolView& vol, int s_hat, int v, int u, float cur,
+                                                      const float* __restrict__ rbar_vu, const uint8_t* __restrict__ mask_svu,
+                                                      int* __restrict__ winner_svu, float slope, float prop_eps)
 {
-    const int v = blockIdx.y;
-    const int u = blockIdx.x * blockDim.x + threadIdx.x;
-    if (u >= vol.U)
-        return;
     const long long o = (long long)v * vol.U + u;
-    // what lets a pixel paint: the edge mask (default build, core.hpp:1102) or, with the reference's
-    // _USE_DISP_CONFIDENCE_SCORE switch, C_d > par_disp_score_threshold (core.hpp:1097-1098)
-    if (gate_Cd_vu ? !(gate_Cd_vu[o] > disp_thr) : !edge_mask_vu[o])
-        return;
-    const float cur = filtered_vu[o];
     float rb[C];
 #pragma unroll
     for (int c = 0; c < C; c++)
@@ -63,11 +53,61 @@ __global__ __launch_bounds__(256) void k4_propagate_claim(VolView vol, int s_hat
     }
 }
 
+template <int C>
+__global__ __launch_bounds__(256) void k4_propagate_claim(VolView vol, int s_hat, const float* __restrict__ filtered_vu,
+                                                         const uint8_t* __restrict__ edge_mask_vu,
+                                                         const float* __restrict__ rbar_vu,
+                                                         const uint8_t* __restrict__ mask_svu, int* __restrict__ winner_svu,
+                                                         float slope, float prop_eps, const float* __restrict__ gate_Cd_vu,
+                                                         float disp_thr)
+{
+    const int v = blockIdx.y;
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= vol.U)
+        return;
+    const long long o = (long long)v * vol.U + u;
+    // what lets a pixel paint: the edge mask (default build, core.hpp:1102) or, with the reference's
+    // _USE_DISP_CONFIDENCE_SCORE switch, C_d > par_disp_score_threshold (core.hpp:1097-1098)
+    if (gate_Cd_vu ? !(gate_Cd_vu[o] > disp_thr) : !edge_mask_vu[o])
+        return;
+    propagate_claim_pixel<C>(vol, s_hat, v, u, filtered_vu[o], rbar_vu, mask_svu, winner_svu, slope, prop_eps);
+}
+
+// K3 + claim in one launch (a sweep visit): a pixel's median needs its neighbours' RAW depths only (what the scan
+// left), and its claims need its own median only -- so the thread that filters a pixel also makes its claims.  The
+// filtered plane is still written: the apply pass reads the winners' values from it.
+template <int C>
+__global__ __launch_bounds__(256) void k34_median_claim(VolView vol, int s_hat, const float* __restrict__ raw_vu,
+                                                       float* __restrict__ filtered_vu, const uint8_t* __restrict__ edge_mask_vu,
+                                                       int size, float eps, const float* __restrict__ rbar_vu,
+                                                       const uint8_t* __restrict__ mask_svu, int* __restrict__ winner_svu,
+                                                       float slope, float prop_eps, const float* __restrict__ gate_Cd_vu,
+                                                       float disp_thr)
+{
+    extern __shared__ __attribute__((aligned(16))) float s_median_cand[];   // [size*size][256]
+    float (*cand)[256] = reinterpret_cast<float (*)[256]>(s_median_cand);
+    const int v = blockIdx.y;
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= vol.U)
+        return;
+    const long long o = (long long)v * vol.U + u;
+    // core.hpp:678-679, :881-892: the median over the edge mask, 0 elsewhere
+    const float cur = edge_mask_vu[o] ? selective_median_pixel<C>(vol, raw_vu, edge_mask_vu, s_hat, size, eps, v, u, cand) : 0.0f;
+    filtered_vu[o] = cur;
+    if (gate_Cd_vu ? !(gate_Cd_vu[o] > disp_thr) : !edge_mask_vu[o])   // core.hpp:1097-1103
+        return;
+    propagate_claim_pixel<C>(vol, s_hat, v, u, cur, rbar_vu, mask_svu, winner_svu, slope, prop_eps);
+}
+
+// `reset` (nullable): an int zeroed by the kernel for the next visit -- the packed list's length, which the next
+// visit's compaction expects at 0 (this is the last kernel of a visit and nothing after the scan reads it).
 __global__ __launch_bounds__(256) void k4_propagate_apply(int S, int V, int U, int s_hat, const float* __restrict__ filtered_vu,
                                                          const float* __restrict__ Cd_hat_vu, float* __restrict__ depth_svu,
                                                          float* __restrict__ Cd_svu, uint8_t* __restrict__ mask_svu,
-                                                         int* __restrict__ winner_svu)
+                                                         int* __restrict__ winner_svu, int* __restrict__ reset)
 {
+    if (reset && blockIdx.x == 0 && threadIdx.x == 0)
+        *reset = 0;
     const long long plane = (long long)V * U;
     const long long n = (long long)S * plane;
     for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {

@@ -84,6 +84,10 @@ struct rslf_ctx {
     bool stream_attr_set = false;
     Partial* scan_partial = nullptr;   // [tile][group][64] records of grouped scan launches
     size_t partial_rec_cap = 0;
+    int* scan_ticket = nullptr;        // [tile] of the same launches: which group merges the tile (zero between launches)
+    size_t ticket_cap = 0;
+    bool packed_n_clean = false;       // the packed list's length is already 0 (the sweep's apply pass resets it)
+    bool precompacted = false;         // the next scan's pixel lists and total are already in place (K1 + compaction in one launch)
     // 2-D sweep scratch
     int* winner = nullptr;        // [S][V][U]
     uint8_t* sweep_mask = nullptr;
@@ -142,6 +146,28 @@ static int ensure_plane_scratch(rslf_ctx* ctx, int V, int U)
         ctx->count_cap = 0;
         HIP_TRY(hipMalloc(&ctx->count, (size_t)V * sizeof(int)));
         ctx->count_cap = V;
+    }
+    return RSLF_OK;
+}
+
+// Records and tickets of grouped scan launches (k2_scan.hpp): grow-only, so a context allocates them once.
+static int ensure_group_scratch(rslf_ctx* ctx, size_t recs, int groups)
+{
+    if (recs > ctx->partial_rec_cap) {
+        HIP_TRY(hipFree(ctx->scan_partial));
+        ctx->scan_partial = nullptr;
+        ctx->partial_rec_cap = 0;
+        HIP_TRY(hipMalloc(&ctx->scan_partial, recs * sizeof(Partial)));
+        ctx->partial_rec_cap = recs;
+    }
+    const size_t tiles = recs / ((size_t)groups * 64);
+    if (tiles > ctx->ticket_cap) {
+        HIP_TRY(hipFree(ctx->scan_ticket));
+        ctx->scan_ticket = nullptr;
+        ctx->ticket_cap = 0;
+        HIP_TRY(hipMalloc(&ctx->scan_ticket, tiles * sizeof(int)));
+        HIP_TRY(hipMemsetAsync(ctx->scan_ticket, 0, tiles * sizeof(int), ctx->stream));   // the kernels leave it at zero
+        ctx->ticket_cap = tiles;
     }
     return RSLF_OK;
 }
@@ -286,6 +312,7 @@ extern "C" int rslf_ctx_destroy(rslf_ctx* ctx)
     (void)hipFree(ctx->minmax);
     (void)hipFree(ctx->staging);
     (void)hipFree(ctx->scan_partial);
+    (void)hipFree(ctx->scan_ticket);
     for (int i = 0; i < rslf_ctx::kHelperSlots; i++)
         (void)hipFree(ctx->helper[i]);
     (void)hipFree(ctx->winner);
@@ -880,7 +907,9 @@ extern "C" int rslf_depth_epi_scan(rslf_ctx* ctx, const rslf_volume* vol, const 
         HIP_TRY(hipMemsetAsync(d_idx_vu, 0xFF, n * sizeof(int32_t), st));   // -1
     if (d_score_vu)
         HIP_TRY(hipMemsetAsync(d_score_vu, 0, n * sizeof(float), st));
-    if (!ctx->keep_total)
+    const bool precompacted = ctx->precompacted;   // rslf_depth1d_pile_run: K1 already left the lists and the total
+    ctx->precompacted = false;
+    if (!ctx->keep_total && !precompacted)
         HIP_TRY(hipMemsetAsync(ctx->total, 0, sizeof(unsigned long long), st));
 
     // Which kernel?  Register variant: S within the compiled slot counts, and radiances in [0, 1e6] so that
@@ -915,12 +944,15 @@ extern "C" int rslf_depth_epi_scan(rslf_ctx* ctx, const rslf_volume* vol, const 
         packed = ctx->force_packed != 0;
     while (groups > 1 && dim_d < 2 * kScanWaves * groups)   // enough hypotheses to share out?
         groups /= 2;
-    if (n > (size_t)INT32_MAX)
-        packed = false;   // entry counts are ints
+    if (n > (size_t)INT32_MAX || precompacted)
+        packed = false;   // entry counts are ints; precompacted: the row lists are what K1 wrote
 
     int* packed_n = reinterpret_cast<int*>(ctx->total + 1);
-    if (packed) {
-        HIP_TRY(hipMemsetAsync(packed_n, 0, sizeof(int), st));
+    if (precompacted) {
+        packed = false;   // row lists are what K1 wrote
+    } else if (packed) {
+        if (!ctx->packed_n_clean)
+            HIP_TRY(hipMemsetAsync(packed_n, 0, sizeof(int), st));
         hipLaunchKernelGGL(k_compact_mask_packed, dim3(vol->V), dim3(256), 0, st, d_Ce_mask_vu, d_mask_vu, vol->U, ctx->list,
                            ctx->count, ctx->total, packed_n);
     } else {
@@ -961,6 +993,7 @@ extern "C" int rslf_depth_epi_scan(rslf_ctx* ctx, const rslf_volume* vol, const 
     a.stream_park = 0;
     a.stream_wave_floats = 0;
     a.partial = nullptr;
+    a.ticket = nullptr;
     a.v0 = 0;
 
     // Grouped launches leave one 32-byte record per (tile, group, lane) for k2_scan_combine.  The records are
@@ -980,14 +1013,11 @@ extern "C" int rslf_depth_epi_scan(rslf_ctx* ctx, const rslf_volume* vol, const 
     a.groups = groups;
     if (groups > 1) {
         const size_t recs = (packed ? (n + 63) / 64 : (size_t)rows_per_launch * a.tiles_per_row) * groups * 64;
-        if (recs > ctx->partial_rec_cap) {
-            HIP_TRY(hipFree(ctx->scan_partial));
-            ctx->scan_partial = nullptr;
-            ctx->partial_rec_cap = 0;
-            HIP_TRY(hipMalloc(&ctx->scan_partial, recs * sizeof(Partial)));
-            ctx->partial_rec_cap = recs;
-        }
+        rc = ensure_group_scratch(ctx, recs, groups);
+        if (rc)
+            return rc;
         a.partial = ctx->scan_partial;
+        a.ticket = ctx->scan_ticket;
     }
 
     size_t lds = 0;
@@ -1033,7 +1063,6 @@ extern "C" int rslf_depth_epi_scan(rslf_ctx* ctx, const rslf_volume* vol, const 
         a.per_xcd = (a.logical_blocks + 7) / 8;
         // packed: a fixed grid strides over the items (k2_scan.hpp); ~4 workgroups per CU cover any occupancy
         const dim3 grid(packed ? (unsigned)std::min<long long>(tiles * groups, 1024) : (unsigned)(a.per_xcd * 8));
-        const dim3 combine_grid(packed ? (unsigned)std::min<long long>(tiles, 1024) : (unsigned)tiles);
         if (spad) {
             rc = launch_scan_reg(spad, vol->C, a, grid, st);
             if (rc)
@@ -1048,14 +1077,7 @@ extern "C" int rslf_depth_epi_scan(rslf_ctx* ctx, const rslf_volume* vol, const 
         } else {
             hipLaunchKernelGGL(k2_scan_generic<3>, grid, dim3(64 * kScanWaves), 0, st, a);
         }
-        HIP_TRY(hipGetLastError());
-        if (groups > 1) {
-            if (vol->C == 1)
-                hipLaunchKernelGGL(k2_scan_combine<1>, combine_grid, dim3(64), 0, st, a);
-            else
-                hipLaunchKernelGGL(k2_scan_combine<3>, combine_grid, dim3(64), 0, st, a);
-            HIP_TRY(hipGetLastError());
-        }
+        HIP_TRY(hipGetLastError());   // grouped launches merge their records themselves (scan_epilogue): no combine launch
         if (packed)
             break;   // one launch covers the packed list
     }
@@ -1114,22 +1136,33 @@ extern "C" int rslf_depth_epi_pile(rslf_ctx* ctx, const rslf_volume* vol, const 
                                    uint8_t* d_mask_vu, int32_t* d_idx_vu, float* d_score_vu, float* d_depth_raw_vu,
                                    rslf_stats* stats)
 {
-    // core.hpp:799-854: the scan of every EPI ...
-    int rc = rslf_depth_epi_scan(ctx, vol, d_dmin_vu, d_dmax_vu, dmin, dmax, dim_d, s_hat, d_Ce_vu, d_Ce_mask_vu, d_Cd_vu,
-                                 d_depth_vu, d_rbar_vu, p, d_mask_vu, d_idx_vu, d_score_vu, nullptr);
+    if (!ctx || !vol || !d_depth_vu)
+        return fail(RSLF_ERR_INVALID_ARG, "NULL argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    int rc = ensure_plane_scratch(ctx, vol->V, vol->U);
     if (rc)
         return rc;
     const size_t n = (size_t)vol->V * vol->U;
     hipStream_t st = ctx->stream;
-    if (d_depth_raw_vu)
-        HIP_TRY(hipMemcpyAsync(d_depth_raw_vu, d_depth_vu, n * sizeof(float), hipMemcpyDeviceToDevice, st));
-
-    // ... then core.hpp:881-892: median over the EDGE mask, result replaces best_depth
-    rc = rslf_selective_median(ctx, vol, d_depth_vu, ctx->depth_tmp, s_hat, p->median_filter_size, d_Ce_mask_vu,
-                               p->median_filter_epsilon);
+    // core.hpp:799-854: the scan of every EPI writes the RAW disparities -- into the caller's raw plane if one is
+    // wanted (over the zeros best_depth starts from, dc.hpp:507), else into scratch, where no background is needed:
+    // the median reads the raw plane at mask pixels only, and every mask pixel has been written by the scan ...
+    // With a caller's scan mask, mask pixels that are NOT scanned now keep the disparity the plane came in with
+    // (a_best_depth_v_u is in/out, core.hpp:305), and the median reads them: the raw plane then starts as a copy.
+    float* raw = d_depth_raw_vu ? d_depth_raw_vu : ctx->depth_tmp;
+    if (d_mask_vu)
+        HIP_TRY(hipMemcpyAsync(raw, d_depth_vu, n * sizeof(float), hipMemcpyDeviceToDevice, st));
+    else if (d_depth_raw_vu)
+        HIP_TRY(hipMemsetAsync(d_depth_raw_vu, 0, n * sizeof(float), st));
+    rc = rslf_depth_epi_scan(ctx, vol, d_dmin_vu, d_dmax_vu, dmin, dmax, dim_d, s_hat, d_Ce_vu, d_Ce_mask_vu, d_Cd_vu, raw,
+                             d_rbar_vu, p, d_mask_vu, d_idx_vu, d_score_vu, nullptr);
     if (rc)
         return rc;
-    HIP_TRY(hipMemcpyAsync(d_depth_vu, ctx->depth_tmp, n * sizeof(float), hipMemcpyDeviceToDevice, st));
+    // ... then core.hpp:881-892: median over the EDGE mask, result replaces best_depth -- written straight into the
+    // caller's plane (every pixel: 0 where the mask is 0, core.hpp:678-679), so no plane is copied
+    rc = rslf_selective_median(ctx, vol, raw, d_depth_vu, s_hat, p->median_filter_size, d_Ce_mask_vu, p->median_filter_epsilon);
+    if (rc)
+        return rc;
 
     if (stats) {
         unsigned long long tot = 0;
@@ -1163,11 +1196,42 @@ extern "C" int rslf_depth1d_pile_run(rslf_ctx* ctx, const rslf_volume* vol, floa
     HIP_TRY(hipMemsetAsync(d_Cd_vu, 0, n * sizeof(float), st));
     HIP_TRY(hipMemsetAsync(d_depth_vu, 0, n * sizeof(float), st));
     HIP_TRY(hipMemsetAsync(d_rbar_vu, 0, n * vol->C * sizeof(float), st));
-    int rc = rslf_edge_confidence_pile(ctx, vol, s_hat, p, d_Ce_vu, d_Ce_mask_vu);   // dc.hpp:538
+    int rc = check_params(p);
     if (rc)
         return rc;
-    return rslf_depth_epi_pile(ctx, vol, nullptr, nullptr, dmin, dmax, dim_d, s_hat, d_Ce_vu, d_Ce_mask_vu, d_Cd_vu,   // dc.hpp:547
-                               d_depth_vu, d_rbar_vu, p, nullptr, d_idx_vu, d_score_vu, d_depth_raw_vu, stats);
+    // dc.hpp:538 + the findNonZero of dc.hpp:547's callee (core.hpp:513-516) in ONE launch when nothing sits between
+    // them: no opening of the mask (core.hpp:759-768) and row tiles.  A pile step is then three launches -- edge
+    // confidence + compaction, scan, selective median -- and no plane is copied.
+    const bool fuse = p->edge_confidence_opening_size <= 1 && ctx->force_packed != 1 && !ctx->scan_packed && vol->filled &&
+                      (size_t)vol->V * vol->U <= (size_t)INT32_MAX;
+    if (fuse) {
+        rc = ensure_plane_scratch(ctx, vol->V, vol->U);
+        if (rc)
+            return rc;
+        EdgeConsts ec;
+        ec.filter_size = p->edge_confidence_filter_size;
+        ec.cut_shadows = p->cut_shadows;
+        ec.shadow_level = p->shadow_level;
+        ec.edge_thr = p->edge_score_threshold;
+        if (!ctx->keep_total)
+            HIP_TRY(hipMemsetAsync(ctx->total, 0, sizeof(unsigned long long), st));
+        if (vol->C == 1)
+            hipLaunchKernelGGL(k1_edge_confidence_compact<1>, dim3(vol->V), dim3(256), 0, st, view_of(vol), s_hat, ec, d_Ce_vu,
+                               d_Ce_mask_vu, ctx->list, ctx->count, ctx->total);
+        else
+            hipLaunchKernelGGL(k1_edge_confidence_compact<3>, dim3(vol->V), dim3(256), 0, st, view_of(vol), s_hat, ec, d_Ce_vu,
+                               d_Ce_mask_vu, ctx->list, ctx->count, ctx->total);
+        HIP_TRY(hipGetLastError());
+        ctx->precompacted = true;
+    } else {
+        rc = rslf_edge_confidence_pile(ctx, vol, s_hat, p, d_Ce_vu, d_Ce_mask_vu);   // dc.hpp:538
+        if (rc)
+            return rc;
+    }
+    rc = rslf_depth_epi_pile(ctx, vol, nullptr, nullptr, dmin, dmax, dim_d, s_hat, d_Ce_vu, d_Ce_mask_vu, d_Cd_vu,   // dc.hpp:547
+                             d_depth_vu, d_rbar_vu, p, nullptr, d_idx_vu, d_score_vu, d_depth_raw_vu, stats);
+    ctx->precompacted = false;
+    return rc;
 }
 
 extern "C" int rslf_depth1d_run(rslf_ctx* ctx, const rslf_volume* vol, float dmin, float dmax, int dim_d, int s_hat,
@@ -1330,7 +1394,39 @@ extern "C" int rslf_depth_epi_2d(rslf_ctx* ctx, const rslf_volume* vol, const fl
 
     const dim3 grid_vu((U + 255) / 256, V);
     const unsigned apply_blocks = (unsigned)std::min<size_t>(((size_t)S * n + 255) / 256, 256 * 8 * 4);
-    ctx->keep_total = true;
+    if (p->median_filter_size < 1 || (p->median_filter_size & 1) == 0 || p->median_filter_size > kMedianMaxSize)
+        return fail(RSLF_ERR_UNSUPPORTED, "median size must be odd and <= %d", kMedianMaxSize);
+    const size_t median_lds = (size_t)p->median_filter_size * p->median_filter_size * 256 * sizeof(float);
+    int* packed_n = reinterpret_cast<int*>(ctx->total + 1);
+    {   // the sparse visits' records, sized before the first visit (no allocation in the middle of the sequence)
+        int g = 16;
+        while (g > 1 && dim_d < 2 * kScanWaves * g)
+            g /= 2;
+        while (g > 1 && ((n + 63) / 64) * g * 64 * sizeof(Partial) > kPartialBudget)
+            g /= 2;
+        if (g > 1 && n <= (size_t)INT32_MAX) {
+            rc = ensure_group_scratch(ctx, ((n + 63) / 64) * g * 64, g);
+            if (rc)
+                return rc;
+        }
+    }
+    // the launch shape of the visits (hypothesis groups, packed tiles, running total) is context state the scan reads:
+    // restored on EVERY exit, and after an error the winners are refilled on the next sweep (a claim pass whose apply
+    // never ran leaves them set)
+    struct SweepState {
+        rslf_ctx* c;
+        bool ok = false;
+        explicit SweepState(rslf_ctx* c_) : c(c_) { c->keep_total = true; }
+        ~SweepState()
+        {
+            c->keep_total = false;
+            c->scan_groups = 1;
+            c->scan_packed = false;
+            c->packed_n_clean = false;
+            if (!ok)
+                c->sweep_cap = 0;
+        }
+    } sweep_state(ctx);
     bool first_visit = true;
     for (int s_hat : order) {
         // After the centre view, propagation has explained most pixels: a visit scans a few per scanline.
@@ -1350,32 +1446,25 @@ extern "C" int rslf_depth_epi_2d(rslf_ctx* ctx, const rslf_volume* vol, const fl
                                  d_dmax_svu ? d_dmax_svu + (size_t)s_hat * n : nullptr, dmin, dmax, dim_d, s_hat,
                                  d_Ce_svu + (size_t)s_hat * n, cem, Cd, depth, rbar, p, mask_svu + (size_t)s_hat * n, nullptr,
                                  nullptr, nullptr);
-        if (!rc)
-            rc = rslf_selective_median(ctx, vol, depth, ctx->filtered, s_hat, p->median_filter_size, cem,
-                                       p->median_filter_epsilon);
-        if (rc) {
-            ctx->keep_total = false;
-            ctx->scan_groups = 1;
-            ctx->scan_packed = false;
+        if (rc)
             return rc;
-        }
-        // core.hpp:1088-1129
+        // core.hpp:881-892 (selective median over the edge mask) and :1088-1129 (propagation) -- the median and the
+        // claims of a pixel in one launch (k34_median_claim), then the apply pass; a visit is four launches:
+        // compaction, scan (its groups merge their records themselves), median + claims, apply
         if (C == 1)
-            hipLaunchKernelGGL(k4_propagate_claim<1>, grid_vu, dim3(256), 0, st, view_of(vol), s_hat, ctx->filtered, cem, rbar,
-                               mask_svu, ctx->winner, p->slope_factor, p->propagation_epsilon,
-                               p->use_disp_confidence_score ? Cd : nullptr, p->disp_score_threshold);
+            hipLaunchKernelGGL(k34_median_claim<1>, grid_vu, dim3(256), median_lds, st, view_of(vol), s_hat, depth, ctx->filtered, cem,
+                               p->median_filter_size, p->median_filter_epsilon, rbar, mask_svu, ctx->winner, p->slope_factor,
+                               p->propagation_epsilon, p->use_disp_confidence_score ? Cd : nullptr, p->disp_score_threshold);
         else
-            hipLaunchKernelGGL(k4_propagate_claim<3>, grid_vu, dim3(256), 0, st, view_of(vol), s_hat, ctx->filtered, cem, rbar,
-                               mask_svu, ctx->winner, p->slope_factor, p->propagation_epsilon,
-                               p->use_disp_confidence_score ? Cd : nullptr, p->disp_score_threshold);
+            hipLaunchKernelGGL(k34_median_claim<3>, grid_vu, dim3(256), median_lds, st, view_of(vol), s_hat, depth, ctx->filtered, cem,
+                               p->median_filter_size, p->median_filter_epsilon, rbar, mask_svu, ctx->winner, p->slope_factor,
+                               p->propagation_epsilon, p->use_disp_confidence_score ? Cd : nullptr, p->disp_score_threshold);
         HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(k4_propagate_apply, dim3(apply_blocks), dim3(256), 0, st, S, V, U, s_hat, ctx->filtered, Cd,
-                           d_depth_svu, d_Cd_svu, mask_svu, ctx->winner);
+                           d_depth_svu, d_Cd_svu, mask_svu, ctx->winner, packed_n);
         HIP_TRY(hipGetLastError());
+        ctx->packed_n_clean = true;   // the apply pass has queued the reset the next visit's compaction needs
     }
-    ctx->keep_total = false;
-    ctx->scan_groups = 1;
-    ctx->scan_packed = false;
     if (stats) {
         unsigned long long tot = 0;
         HIP_TRY(hipMemcpyAsync(&tot, ctx->total, sizeof(tot), hipMemcpyDeviceToHost, st));
@@ -1385,6 +1474,7 @@ extern "C" int rslf_depth_epi_2d(rslf_ctx* ctx, const rslf_volume* vol, const fl
         stats->scan_kernel = ctx->last_kernel;
         stats->s_pad = ctx->last_spad;
     }
+    sweep_state.ok = true;
     return RSLF_OK;
 }
 
