@@ -92,6 +92,7 @@ def lib():
                                       C.c_int, _f32p, _u8p]
         L.oracle_num_threads.restype = C.c_int
         L.oracle_set_num_threads.argtypes = [C.c_int]
+        L.oracle_set_assumptions.argtypes = [C.c_int]
         _lib = L
     return _lib
 
@@ -370,6 +371,14 @@ def usable_cpus() -> int:
         except (OSError, ValueError, IndexError):
             continue
     return max(1, n)
+
+
+ASSUME_RGB_SUM_IN_ORDER, ASSUME_MUL_SCALE_LAST, ASSUME_DIV0_IEEE, ASSUME_MAX_NAN_TAIL = 1, 2, 4, 8
+
+
+def set_assumptions(flags: int) -> None:
+    """What-if switches of tools/blast_radius.py (0 = the assumptions of record; tests never change it)."""
+    lib().oracle_set_assumptions(int(flags))
 
 
 def set_num_threads(n: int) -> None:

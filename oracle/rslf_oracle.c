@@ -57,6 +57,13 @@ static int nearest_index(float x, int U, int mode)
     return (r > -1 && r < U) ? r : -1;          /* interp.hpp:122 */
 }
 
+/* What-if switches for the OpenCV 3.x semantics the restatement assumes and cannot verify here:
+ * 0 = the assumptions of record.  tools/blast_radius.py counts what each alternative would change; the product and
+ * every parity test run with 0. */
+static int g_assume = 0;
+void oracle_set_assumptions(int flags) { g_assume = flags; }
+int oracle_assumptions(void) { return g_assume; }
+
 void oracle_set_num_threads(int n)
 {
 #ifdef _OPENMP
@@ -494,6 +501,120 @@ static void scan_pixel(const float* epi, int S, int U, int C, int u,
     }
 }
 
+/* cv::max(x, 0) on element `flat` of an array of n floats: the SIMD body sends NaN to 0; under
+ * ORACLE_ASSUME_MAX_NAN_TAIL the scalar tail (the last n % 8 elements, std::max) keeps it. */
+static inline float max0_at(float x, size_t flat, size_t n)
+{
+    if (x > 0.0f)
+        return x;
+    if ((g_assume & ORACLE_ASSUME_MAX_NAN_TAIL) && x != x && flat >= (n / 8) * 8)
+        return x;
+    return 0.0f;
+}
+
+/* scan_pixel under the what-if switches: the same passes over full S x D matrices, as the reference runs them
+ * (core.hpp:540-625), slow and plain.  Linear interpolation only. */
+static void scan_pixel_assume(const float* epi, int S, int U, int C, int u, float dmin, float dmax, int D, int s_hat,
+                              const oracle_params* p, scan_scratch* w, float inv_h2, float k1, int n_iter)
+{
+    const size_t SD = (size_t)S * D;
+    float* R = (float*)malloc(sizeof(float) * SD * C * 2 + sizeof(float) * SD);
+    float* R0 = R + SD * C;
+    float* K = R0 + SD * C;
+    const float range = dmax - dmin, denom = (float)(D - 1), uf = (float)u;
+    for (int d = 0; d < D; d++) {
+        const float num = (float)d * range;
+        const float quo = num / denom;
+        w->Dv[d] = dmin + quo;
+        w->card[d] = 0.0f;
+    }
+    for (int s = 0; s < S; s++) {
+        const float Ss = (float)(s_hat - s);
+        const float* erow = epi + (size_t)s * U * C;
+        for (int d = 0; d < D; d++) {
+            float xi = Ss * w->Dv[d];
+            xi = xi * p->slope_factor;
+            xi = xi + uf;
+            const int i0 = (int)floorf(xi), i1 = (int)ceilf(xi);
+            const float t = xi - (float)i0;
+            const int valid = !(i0 < 0 || i1 > U - 1);
+            for (int c = 0; c < C; c++) {
+                float r = NAN;
+                if (valid) {
+                    const float omt = 1.0f - t;
+                    const float a = omt * erow[(size_t)i0 * C + c];
+                    const float b = t * erow[(size_t)i1 * C + c];
+                    r = a + b;
+                }
+                R[c * SD + (size_t)s * D + d] = r;
+                /* core.hpp:580: cv::max(R, 0) on the S x D (x C interleaved) matrix */
+                R0[c * SD + (size_t)s * D + d] = max0_at(r, ((size_t)s * D + d) * C + c, SD * C);
+            }
+            if (valid)
+                w->card[d] = w->card[d] + 1.0f;
+        }
+    }
+    for (int c = 0; c < C; c++)
+        memcpy(w->rbar + (size_t)c * D, R + c * SD + (size_t)s_hat * D, sizeof(float) * D);
+    for (int it = 0; it < n_iter; it++) {
+        for (int c = 0; c < C; c++)
+            memset(w->A + (size_t)c * D, 0, sizeof(float) * D);
+        memset(w->B, 0, sizeof(float) * D);
+        for (int s = 0; s < S; s++) {
+            for (int d = 0; d < D; d++) {
+                float q[3] = {0.0f, 0.0f, 0.0f};
+                const float scale = (C == 1) ? k1 : inv_h2;
+                for (int c = 0; c < C; c++) {
+                    const float delta = R[c * SD + (size_t)s * D + d] - w->rbar[(size_t)c * D + d];
+                    if (g_assume & ORACLE_ASSUME_MUL_SCALE_LAST) {   /* scale * (a * b) */
+                        const float dd = delta * delta;
+                        q[c] = scale * dd;
+                    } else {                                         /* (scale * a) * b */
+                        const float t = scale * delta;
+                        q[c] = t * delta;
+                    }
+                }
+                float qs = q[0];
+                if (C == 3) {
+                    if (g_assume & ORACLE_ASSUME_RGB_SUM_IN_ORDER) {
+                        qs = q[0] + q[1];
+                        qs = qs + q[2];
+                    } else {
+                        qs = q[0] + q[2];
+                        qs = qs + q[1];
+                    }
+                }
+                const float o = 1.0f - qs;
+                const float k = max0_at(o, (size_t)s * D + d, SD);   /* kernels.cpp:25 / :53 on the S x D matrix */
+                K[(size_t)s * D + d] = k;
+                for (int c = 0; c < C; c++) {
+                    const float pr = R0[c * SD + (size_t)s * D + d] * k;
+                    w->A[(size_t)c * D + d] = w->A[(size_t)c * D + d] + pr;
+                }
+                w->B[d] = w->B[d] + k;
+            }
+        }
+        for (int c = 0; c < C; c++)
+            for (int d = 0; d < D; d++) {
+                float q;
+                if (g_assume & ORACLE_ASSUME_DIV0_IEEE)
+                    q = w->A[(size_t)c * D + d] / w->B[d];           /* OpenCV 4.x: IEEE inf / NaN */
+                else
+                    q = (w->B[d] != 0.0f) ? (w->A[(size_t)c * D + d] / w->B[d]) : 0.0f;
+                w->rbar[(size_t)c * D + d] = max0_at(q, (size_t)d * C + c, (size_t)D * C);   /* core.hpp:609 */
+            }
+    }
+    for (int d = 0; d < D; d++) {
+        float sc;
+        if (g_assume & ORACLE_ASSUME_DIV0_IEEE)
+            sc = w->B[d] / w->card[d];
+        else
+            sc = (w->card[d] != 0.0f) ? (w->B[d] / w->card[d]) : 0.0f;
+        w->score[d] = max0_at(sc, (size_t)d, (size_t)D);             /* core.hpp:622 */
+    }
+    free(R);
+}
+
 static int iter_count(float max_iter)
 {
     /* for (int i=0; i < par_mean_shift_max_iter; i++) with a float bound
@@ -544,7 +665,10 @@ static void depth_epi_impl(const float* epi, int S, int U, int C,
         if (!scan_mask[u])
             continue;
 
-        scan_pixel(epi, S, U, C, u, dmin_u[u], dmax_u[u], D, s_hat, p, w, inv_h2, k1, n_iter);
+        if (g_assume && p->interpolation == ORACLE_INTERP_LINEAR)
+            scan_pixel_assume(epi, S, U, C, u, dmin_u[u], dmax_u[u], D, s_hat, p, w, inv_h2, k1, n_iter);
+        else
+            scan_pixel(epi, S, U, C, u, dmin_u[u], dmax_u[u], D, s_hat, p, w, inv_h2, k1, n_iter);
 
         /* core.hpp:630-634: minMaxLoc, first maximum */
         int best = 0;

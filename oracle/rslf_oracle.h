@@ -199,6 +199,13 @@ void oracle_f2c_tighten_bounds(const float* depth_up_svu, const uint8_t* mask_up
 void oracle_f2c_fuse(const float* const* disp, const uint8_t* const* valid, const int* Vp, const int* Up, int P,
                      float* out_map, uint8_t* out_valid);
 
+/* What-if switches (tools/blast_radius.py): alternatives to the OpenCV 3.x readings of SURVEY.md App. B. */
+#define ORACLE_ASSUME_RGB_SUM_IN_ORDER 1   /* cv::reduce over 3 columns as (q0 + q1) + q2, not (q0 + q2) + q1 */
+#define ORACLE_ASSUME_MUL_SCALE_LAST   2   /* cv::multiply(a, b, scale) as scale * (a * b), not (scale * a) * b */
+#define ORACLE_ASSUME_DIV0_IEEE        4   /* cv::divide by 0 as IEEE inf / NaN (OpenCV 4.x), not 0 (3.x) */
+#define ORACLE_ASSUME_MAX_NAN_TAIL     8   /* cv::max(x, 0) keeps a NaN in the scalar tail (last n % 8 elements) */
+void oracle_set_assumptions(int flags);
+int oracle_assumptions(void);
 int oracle_num_threads(void);
 void oracle_set_num_threads(int n);
 

@@ -52,7 +52,7 @@ def main():
         with open(os.path.join(out, "%s_%s_kernel_stats.csv" % (rnd, tag)), "w", newline="") as f:
             csv.writer(f, quoting=csv.QUOTE_ALL).writerows(keep)
     summary = {}
-    for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2", "pmc_l2", "pmc_ta", "pmc_tcp"):
+    for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2", "pmc_l2", "pmc_ta", "pmc_td", "pmc_tcp"):
         for k, v in pmc_means(sub).items():
             summary.setdefault(k, {}).update(v)
     bench = {}
