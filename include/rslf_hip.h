@@ -141,7 +141,7 @@ int rslf_ctx_set_debug(rslf_ctx* ctx, const char* key, int value);
  * interleaved like the reference's Mat rows, so the two lerp taps of a sample, all
  * channels, are 2*C consecutive floats. */
 int rslf_volume_create(rslf_ctx* ctx, int V, int S, int U, int C, rslf_volume** out);
-int rslf_volume_destroy(rslf_volume* vol);
+int rslf_volume_destroy(rslf_volume* vol);   /* waits for the device; contexts and volumes may be destroyed in either order */
 int rslf_volume_describe(const rslf_volume* vol, rslf_volume_desc* out);
 
 /* Host EPIs as the reference holds them: h_epis[v] -> S rows of U*C values,
@@ -312,14 +312,19 @@ int rslf_depth2d_run(rslf_ctx* ctx, const rslf_volume* vol, float dmin, float dm
 /* rslf::FineToCoarse<T> (include/rslf_fine_to_coarse.hpp:26-81) is a host-side loop over pyramid
  * levels, each a Depth2DComputer (rslf_depth2d_run / rslf_depth_epi_2d above).  These are the pieces
  * between the levels; the loop itself lives in the host wrapper (depth.py: FineToCoarse).  Raw
- * (un-normalised) volumes here are dense float32 [V][S][U][C] on the device; the reference builds
- * uchar pyramids in uchar arithmetic, this ABI builds every pyramid in float. */
+ * (un-normalised) volumes here are dense float32 [V][S][U][C] on the device; uchar light fields keep uchar
+ * arithmetic through the pyramid (rslf_downsample_epis_u8), as the reference's CV_8U Mats do. */
 
 /* Level dimensions of cv::resize(0.5, 0.5): cvRound(V/2), cvRound(U/2) (ties to even). */
 int rslf_f2c_level_dims(int V, int U, int* V2, int* U2);
 /* rslf::downsample_EPIs -- src/rslf_fine_to_coarse_core.cpp:14-60: per view, cv::GaussianBlur(7x7,
  * sigma 0, BORDER_REFLECT) then cv::resize(0.5, 0.5, INTER_LINEAR).  d_out_vsuc is [V2][S][U2][C]. */
 int rslf_downsample_epis_f32(rslf_ctx* ctx, const float* d_in_vsuc, int V, int S, int U, int C, float* d_out_vsuc);
+/* The same for CV_8U light fields, in uchar arithmetic as the reference runs it (its Mats keep the input's type):
+ * d_in / d_out hold uchar levels 0..255 as float32.  GaussianBlur on 8U = exact integer convolution (the taps are
+ * exact in 8 fractional bits) rounded half up once -- the result of both 8U paths of OpenCV 3.4 (<= 3.4.0 8-bit
+ * fixed-point filter, >= 3.4.1 ufixedpoint16); resize = INTER_AREA's (sum + 2) >> 2. */
+int rslf_downsample_epis_u8(rslf_ctx* ctx, const float* d_in_vsuc, int V, int S, int U, int C, float* d_out_vsuc);
 /* max over a device buffer: the per-level epi_scale_factor of Depth2DComputer's constructor
  * (include/rslf_depth_computation.hpp:671-690).  Synchronises. */
 int rslf_device_max_f32(rslf_ctx* ctx, const float* d_values, size_t n, float* h_max);   /* returns the value: waits */

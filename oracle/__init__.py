@@ -87,6 +87,7 @@ def lib():
                                           _f32p, _f32p, C.POINTER(OracleParams), C.c_float, _u8p]
         L.oracle_f2c_out_dims.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.oracle_downsample_epis.argtypes = [_f32p, C.c_int, C.c_int, C.c_int, C.c_int, _f32p]
+        L.oracle_downsample_epis_u8.argtypes = [_f32p, C.c_int, C.c_int, C.c_int, C.c_int, _f32p]
         L.oracle_f2c_tighten_bounds.argtypes = [_f32p, _u8p, C.c_int, C.c_int, C.c_int, _f32p, _f32p, C.c_int, C.c_int]
         L.oracle_f2c_fuse.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_int),
                                       C.c_int, _f32p, _u8p]
@@ -276,6 +277,17 @@ def downsample_epis(raw_vsuc: np.ndarray) -> np.ndarray:
     return out
 
 
+def downsample_epis_u8(levels_vsuc: np.ndarray) -> np.ndarray:
+    """rslf::downsample_EPIs on CV_8U Mats: uchar levels (0..255) carried in float32, uchar arithmetic."""
+    a = np.ascontiguousarray(levels_vsuc, np.float32)
+    V, S, U, Cc = a.shape
+    v2, u2 = C.c_int(), C.c_int()
+    lib().oracle_f2c_out_dims(V, U, C.byref(v2), C.byref(u2))
+    out = np.zeros((v2.value, S, u2.value, Cc), np.float32)
+    lib().oracle_downsample_epis_u8(a.reshape(-1), V, S, U, Cc, out.reshape(-1))
+    return out
+
+
 def f2c_tighten_bounds(depth_up_svu, mask_up_svu, dmin_down_svu, dmax_down_svu):
     """rslf_fine_to_coarse.hpp:171-299; returns new (dmin, dmax) for the coarser level."""
     du = np.ascontiguousarray(depth_up_svu, np.float32); mu = np.ascontiguousarray(mask_up_svu, np.uint8)
@@ -299,7 +311,7 @@ def f2c_fuse(disp_pyr, valid_pyr):
 
 
 def fine_to_coarse_run(raw_vsuc, dmin, dmax, dim_d, params=None, max_pyr_depth=-1, accept_all_last_scale=True,
-                       min_spatial_dim=10, propagation_epsilon=0.1):
+                       min_spatial_dim=10, propagation_epsilon=0.1, is_u8=False):
     """rslf::FineToCoarse (rslf_fine_to_coarse.hpp:103-299 + get_results :302-324) on a RAW float32 volume
     [V,S,U,C]: every level normalises by its own max (epi_scale_factor = -1 in each Depth2DComputer), levels are
     built while min(V,U) > _MIN_SPATIAL_DIM, slope_factor = U_p / U_0.
@@ -318,9 +330,12 @@ def fine_to_coarse_run(raw_vsuc, dmin, dmax, dim_d, params=None, max_pyr_depth=-
         count += 1
         p = copy.copy(base) if not isinstance(base, OracleParams) else OracleParams.from_buffer_copy(base)
         p.slope_factor = np.float32((0.0 + U) / U0)                                # f2c.hpp:139
-        norm, _ = normalize_f32(cur, -1.0)                                         # Depth2DComputer ctor, dc.hpp:671-705
+        if is_u8:   # uchar EPIs: every level scales by 1/255 (dc.hpp:696-699) and the pyramid is built in uchar arithmetic
+            norm = normalize_u8(cur.astype(np.uint8))
+        else:
+            norm, _ = normalize_f32(cur, -1.0)                                     # Depth2DComputer ctor, dc.hpp:671-705
         vols.append(norm); pars.append(p)
-        cur = downsample_epis(cur)                                                 # f2c.hpp:145-147 (the RAW EPIs go down)
+        cur = downsample_epis_u8(cur) if is_u8 else downsample_epis(cur)           # f2c.hpp:145-147 (the RAW EPIs go down)
         V, U = cur.shape[0], cur.shape[2]
     S = raw.shape[1]
     thr = np.float32(base.edge_score_threshold)

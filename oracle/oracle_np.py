@@ -385,6 +385,36 @@ def downsample_epis(raw):
     return np.ascontiguousarray(np.stack(outs, axis=1))
 
 
+def downsample_epis_u8(levels):
+    """rslf::downsample_EPIs on CV_8U Mats, independently of the C restatement: uchar levels in, uchar levels out
+    (as float32).  GaussianBlur 7x7 (sigma 0) on 8U = the exact integer convolution with {8,28,56,72,56,28,8}/256 per
+    axis, BORDER_REFLECT, rounded half up once; resize x0.5 = INTER_AREA's 2x2 mean, (sum + 2) >> 2, and at an odd
+    border cvRound(sum / count)."""
+    V, S, U, C = levels.shape
+    k = np.array([8, 28, 56, 72, 56, 28, 8], np.int64)
+    V2, U2 = int(np.rint(V * 0.5)), int(np.rint(U * 0.5))
+    out = np.zeros((V2, S, U2, C), F)
+
+    def refl(i, n):
+        i = np.asarray(i)
+        i = np.where(i < 0, -i - 1, i)
+        return np.where(i >= n, 2 * n - 1 - i, i)
+
+    for s in range(S):
+        img = levels[:, s].astype(np.int64)                                     # [V, U, C]
+        rows = sum(k[j] * img[:, refl(np.arange(U) + j - 3, U)] for j in range(7))
+        full = sum(k[j] * rows[refl(np.arange(V) + j - 3, V)] for j in range(7))
+        blur = (full + 32768) >> 16
+        for y in range(V2):
+            for x in range(U2):
+                blk = blur[2 * y:2 * y + 2, 2 * x:2 * x + 2]                    # the pixels that exist
+                if blk.shape[0] == 2 and blk.shape[1] == 2:
+                    out[y, s, x] = (blk.sum(axis=(0, 1)) + 2) >> 2
+                elif blk.size:
+                    out[y, s, x] = np.rint(blk.sum(axis=(0, 1)).astype(F) / F(blk.shape[0] * blk.shape[1]))
+    return out
+
+
 def tighten_bounds(depth_up, mask_up, dmin_down, dmax_down):
     """rslf_fine_to_coarse.hpp:202-294."""
     S, Vu, Uu = depth_up.shape

@@ -1070,6 +1070,84 @@ void oracle_downsample_epis(const float* in, int V, int S, int U, int C, float* 
     }
 }
 
+/* downsample_EPIs on CV_8U Mats (fine_to_coarse_core.cpp:14-60; the reference blurs and resizes in the input's own
+ * type).  Values are uchar levels 0..255, carried here in float arrays.
+ *  - cv::GaussianBlur(7x7, sigma 0, BORDER_REFLECT) on 8U: the 7-tap kernel {1, 3.5, 7, 9, 7, 3.5, 1}/32 is exact in
+ *    8 fractional bits ({8, 28, 56, 72, 56, 28, 8}/256), so both 8U paths of OpenCV 3.4 -- the 8-bit fixed-point
+ *    separable filter up to 3.4.0 (row filter to int, column filter with FixedPtCastEx<int, uchar>(16)) and the
+ *    ufixedpoint16 path from 3.4.1 on -- form the exact double sum and round it once, half up:
+ *    (sum + 32768) >> 16.  The restatement therefore holds for every 3.4.x.
+ *  - cv::resize(0.5, 0.5, INTER_LINEAR) with an exact factor 2 runs INTER_AREA's fast path: (S00 + S01 + S10 + S11
+ *    + 2) >> 2; where the block sticks out of an odd-sized source, saturate_cast<uchar>((float)sum / count), i.e.
+ *    cvRound (ties to even). */
+static void gaussian7_reflect_u8(const float* src, int* dst, int* tmp, int R, int W, int C)
+{
+    static const int k[7] = {8, 28, 56, 72, 56, 28, 8};
+    for (int y = 0; y < R; y++)
+        for (int x = 0; x < W; x++)
+            for (int c = 0; c < C; c++) {
+                int s = 0;
+                for (int j = 0; j < 7; j++)
+                    s += k[j] * (int)src[((size_t)y * W + reflect_border(x + j - 3, W)) * C + c];
+                tmp[((size_t)y * W + x) * C + c] = s;
+            }
+    for (int y = 0; y < R; y++)
+        for (int x = 0; x < W; x++)
+            for (int c = 0; c < C; c++) {
+                int s = 0;
+                for (int j = 0; j < 7; j++)
+                    s += k[j] * tmp[((size_t)reflect_border(y + j - 3, R) * W + x) * C + c];
+                dst[((size_t)y * W + x) * C + c] = (s + 32768) >> 16;
+            }
+}
+
+static void halve_area_u8(const int* src, int R, int W, int C, float* dst, int R2, int W2)
+{
+    for (int y = 0; y < R2; y++)
+        for (int x = 0; x < W2; x++)
+            for (int c = 0; c < C; c++) {
+                const int y0 = 2 * y, x0 = 2 * x;
+                int out;
+                if (y0 + 1 < R && x0 + 1 < W) {
+                    out = (src[((size_t)y0 * W + x0) * C + c] + src[((size_t)y0 * W + x0 + 1) * C + c] +
+                           src[((size_t)(y0 + 1) * W + x0) * C + c] + src[((size_t)(y0 + 1) * W + x0 + 1) * C + c] + 2) >> 2;
+                } else {
+                    int sum = 0, cnt = 0;
+                    for (int sy = 0; sy < 2; sy++)
+                        for (int sx = 0; sx < 2; sx++)
+                            if (y0 + sy < R && x0 + sx < W) {
+                                sum += src[((size_t)(y0 + sy) * W + x0 + sx) * C + c];
+                                cnt++;
+                            }
+                    out = cnt ? (int)lrintf((float)sum / (float)cnt) : 0;
+                }
+                dst[((size_t)y * W2 + x) * C + c] = (float)out;
+            }
+}
+
+void oracle_downsample_epis_u8(const float* in, int V, int S, int U, int C, float* out)
+{
+    int V2, U2;
+    oracle_f2c_out_dims(V, U, &V2, &U2);
+#pragma omp parallel
+    {
+        float* img = (float*)malloc(sizeof(float) * (size_t)V * U * C);
+        int* tmp = (int*)malloc(sizeof(int) * (size_t)V * U * C);
+        int* blur = (int*)malloc(sizeof(int) * (size_t)V * U * C);
+        float* half = (float*)malloc(sizeof(float) * (size_t)V2 * U2 * C);
+#pragma omp for schedule(static)
+        for (int s = 0; s < S; s++) {
+            for (int v = 0; v < V; v++)
+                memcpy(img + (size_t)v * U * C, in + (((size_t)v * S + s) * U) * C, sizeof(float) * (size_t)U * C);
+            gaussian7_reflect_u8(img, blur, tmp, V, U, C);
+            halve_area_u8(blur, V, U, C, half, V2, U2);
+            for (int v = 0; v < V2; v++)
+                memcpy(out + (((size_t)v * S + s) * U2) * C, half + (size_t)v * U2 * C, sizeof(float) * (size_t)U2 * C);
+        }
+        free(img); free(tmp); free(blur); free(half);
+    }
+}
+
 void oracle_f2c_tighten_bounds(const float* depth_up, const uint8_t* mask_up, int S, int V_up, int U_up,
                                float* dmin_down, float* dmax_down, int V_down, int U_down)
 {

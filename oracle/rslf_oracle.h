@@ -186,6 +186,8 @@ void oracle_depth2d_run(const float* vol, int V, int S, int U, int C,
  * in [V][S][U][C] -> out [V2][S][U2][C]; V2 = cvRound(V/2), U2 = cvRound(U/2) (round half to even). */
 void oracle_f2c_out_dims(int V, int U, int* V2, int* U2);
 void oracle_downsample_epis(const float* in_vsuc, int V, int S, int U, int C, float* out_vsuc);
+/* the same on CV_8U Mats: uchar levels (0..255) in float arrays, uchar arithmetic (fine_to_coarse_core.cpp:22-41) */
+void oracle_downsample_epis_u8(const float* in, int V, int S, int U, int C, float* out);
 
 /* FineToCoarse::run(), the bound tightening between two levels (include/rslf_fine_to_coarse.hpp:171-299):
  * for every pixel of the coarser level, the nearest valid disparities left and right of column 2u on

@@ -27,7 +27,7 @@ SYMBOLS = [
     "rslf_depth1d_pile_run", "rslf_depth1d_pile_run_host", "rslf_last_scan_kernel_ms",
     "rslf_edge_confidence_2d", "rslf_depth_epi_2d", "rslf_depth2d_run",
     "rslf_depth_epi_scan", "rslf_depth1d_run",
-    "rslf_f2c_level_dims", "rslf_downsample_epis_f32", "rslf_device_max_f32", "rslf_f2c_tighten_bounds", "rslf_f2c_fuse",
+    "rslf_f2c_level_dims", "rslf_downsample_epis_f32", "rslf_downsample_epis_u8", "rslf_device_max_f32", "rslf_f2c_tighten_bounds", "rslf_f2c_fuse",
     "rslf_depth2d_run_host", "rslf_fine_to_coarse_run_host", "rslf_kernel_columns_pile", "rslf_volume_upload_images_xf_f32", "rslf_volume_upload_images_xf_u8",
 ]
 
@@ -153,6 +153,7 @@ def lib():
                                                ci, ci, vp, vp, C.POINTER(ci), C.POINTER(RslfStats)]
     L.rslf_f2c_level_dims.argtypes = [ci, ci, C.POINTER(ci), C.POINTER(ci)]
     L.rslf_downsample_epis_f32.argtypes = [vp, vp, ci, ci, ci, ci, vp]
+    L.rslf_downsample_epis_u8.argtypes = [vp, vp, ci, ci, ci, ci, vp]
     L.rslf_device_max_f32.argtypes = [vp, vp, C.c_size_t, C.POINTER(cf)]
     L.rslf_f2c_tighten_bounds.argtypes = [vp, vp, vp, ci, ci, ci, vp, vp, ci, ci]
     L.rslf_f2c_fuse.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(ci), C.POINTER(ci), ci, ci, vp, vp]

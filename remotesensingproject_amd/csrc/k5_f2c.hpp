@@ -93,6 +93,67 @@ __global__ __launch_bounds__(256) void k5_gauss_cols_halve(const float* __restri
     out[(((long long)y * S + s) * U2 + x) * C + c] = r;
 }
 
+// ---- the same on CV_8U Mats (uchar levels 0..255 carried in float arrays) -----------------------------------
+// The reference blurs and halves a uchar light field in uchar arithmetic (fine_to_coarse_core.cpp:22-41).
+// cv::GaussianBlur(7x7, sigma 0) on 8U: the taps are exact in 8 fractional bits ({8, 28, 56, 72, 56, 28, 8}/256), so
+// OpenCV 3.4's 8U paths -- the 8-bit fixed-point separable filter (<= 3.4.0) and ufixedpoint16 (>= 3.4.1) -- both form
+// the exact double sum and round once, half up: (sum + 32768) >> 16.  cv::resize(0.5, INTER_LINEAR) = INTER_AREA's fast
+// path, (S00 + S01 + S10 + S11 + 2) >> 2; at an odd border saturate_cast<uchar>((float)sum / count) = cvRound.
+__constant__ const int kGauss7u8[7] = {8, 28, 56, 72, 56, 28, 8};
+
+__global__ __launch_bounds__(256) void k5_gauss_rows_u8(const float* __restrict__ in, int* __restrict__ tmp, long long rows, int U, int C)
+{
+    const int xblocks = (U * C + (int)blockDim.x - 1) / (int)blockDim.x;
+    const long long row = blockIdx.x / xblocks;   // over V*S
+    const int xc = (int)(blockIdx.x % xblocks) * blockDim.x + threadIdx.x;
+    if (xc >= U * C || row >= rows)
+        return;
+    const int x = xc / C, c = xc - x * C;
+    const float* r = in + row * (long long)U * C;
+    int s = 0;
+#pragma unroll
+    for (int j = 0; j < 7; j++)
+        s += kGauss7u8[j] * (int)r[(long long)reflect_border(x + j - 3, U) * C + c];
+    tmp[row * (long long)U * C + xc] = s;   // 8 fractional bits, <= 255 * 256
+}
+
+__device__ __forceinline__ int gauss_col_u8(const int* __restrict__ tmp, int y, int s, int x, int c, int V, int S, int U, int C)
+{
+    const long long rs = (long long)S * U * C;
+    const long long o = ((long long)s * U + x) * C + c;
+    int acc = 0;
+#pragma unroll
+    for (int j = 0; j < 7; j++)
+        acc += kGauss7u8[j] * tmp[(long long)reflect_border(y + j - 3, V) * rs + o];
+    return (acc + 32768) >> 16;   // the blurred uchar level
+}
+
+__global__ __launch_bounds__(256) void k5_gauss_cols_halve_u8(const int* __restrict__ tmp, float* __restrict__ out, int V, int S, int U,
+                                                             int C, int V2, int U2)
+{
+    const int xc = blockIdx.x * blockDim.x + threadIdx.x;
+    const int s = blockIdx.y, y = blockIdx.z;
+    if (xc >= U2 * C)
+        return;
+    const int x = xc / C, c = xc - x * C;
+    const int y0 = 2 * y, x0 = 2 * x;
+    int r;
+    if (y0 + 1 < V && x0 + 1 < U) {
+        r = (gauss_col_u8(tmp, y0, s, x0, c, V, S, U, C) + gauss_col_u8(tmp, y0, s, x0 + 1, c, V, S, U, C) +
+             gauss_col_u8(tmp, y0 + 1, s, x0, c, V, S, U, C) + gauss_col_u8(tmp, y0 + 1, s, x0 + 1, c, V, S, U, C) + 2) >> 2;
+    } else {
+        int sum = 0, cnt = 0;
+        for (int sy = 0; sy < 2; sy++)
+            for (int sx = 0; sx < 2; sx++)
+                if (y0 + sy < V && x0 + sx < U) {
+                    sum += gauss_col_u8(tmp, y0 + sy, s, x0 + sx, c, V, S, U, C);
+                    cnt++;
+                }
+        r = cnt ? (int)rintf((float)sum / (float)cnt) : 0;   // cvRound: ties to even
+    }
+    out[(((long long)y * S + s) * U2 + x) * C + c] = (float)r;
+}
+
 // max over a dense float buffer (per-level epi_scale_factor, dc.hpp:671-690)
 __global__ __launch_bounds__(256) void k5_max_partial(const float* __restrict__ in, long long n, float* __restrict__ partial)
 {

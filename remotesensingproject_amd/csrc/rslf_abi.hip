@@ -103,6 +103,7 @@ struct rslf_ctx {
 
 struct rslf_volume {
     rslf_ctx* ctx = nullptr;
+    int device = 0;   // kept here too: a volume may be destroyed after its context
     int V = 0, S = 0, U = 0, C = 0, pitch = 0;
     float* base = nullptr;
     size_t bytes = 0;
@@ -386,6 +387,7 @@ extern "C" int rslf_volume_create(rslf_ctx* ctx, int V, int S, int U, int C, rsl
     if (!vol)
         return fail(RSLF_ERR_ALLOC, "out of host memory");
     vol->ctx = ctx;
+    vol->device = ctx->device;
     vol->V = V;
     vol->S = S;
     vol->U = U;
@@ -405,8 +407,9 @@ extern "C" int rslf_volume_destroy(rslf_volume* vol)
 {
     if (!vol)
         return RSLF_OK;
-    (void)hipSetDevice(vol->ctx->device);
-    (void)hipStreamSynchronize(vol->ctx->stream);
+    // hipFree waits for the device's outstanding work, so the slab outlives every launch that reads it; the
+    // context is not touched (it may already be gone -- contexts and volumes can be destroyed in either order)
+    (void)hipSetDevice(vol->device);
     (void)hipFree(vol->base);
     delete vol;
     return RSLF_OK;
@@ -1543,6 +1546,31 @@ extern "C" int rslf_downsample_epis_f32(rslf_ctx* ctx, const float* d_in_vsuc, i
     return RSLF_OK;   // enqueued on the context's stream like every device entry point
 }
 
+extern "C" int rslf_downsample_epis_u8(rslf_ctx* ctx, const float* d_in_vsuc, int V, int S, int U, int C, float* d_out_vsuc)
+{
+    if (!ctx || !d_in_vsuc || !d_out_vsuc || V < 1 || S < 1 || U < 1 || (C != 1 && C != 3))
+        return fail(RSLF_ERR_INVALID_ARG, "bad arguments");
+    HIP_TRY(hipSetDevice(ctx->device));
+    int V2, U2;
+    rslf_f2c_level_dims(V, U, &V2, &U2);
+    if (V2 < 1 || U2 < 1)
+        return fail(RSLF_ERR_INVALID_ARG, "level too small to halve");
+    void* tmp_p = nullptr;
+    int rc = helper_scratch(ctx, 0, (size_t)V * S * U * C * sizeof(int), &tmp_p);
+    if (rc)
+        return rc;
+    hipStream_t st = ctx->stream;
+    const long long row_blocks = (long long)V * S * ((U * C + 255) / 256);
+    if (row_blocks > (1ll << 31) - 1)
+        return fail(RSLF_ERR_UNSUPPORTED, "volume too large for one downsampling launch");
+    hipLaunchKernelGGL(k5_gauss_rows_u8, dim3((unsigned)row_blocks), dim3(256), 0, st, d_in_vsuc, (int*)tmp_p, (long long)V * S, U, C);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(k5_gauss_cols_halve_u8, dim3((U2 * C + 255) / 256, S, V2), dim3(256), 0, st, (const int*)tmp_p, d_out_vsuc,
+                       V, S, U, C, V2, U2);
+    HIP_TRY(hipGetLastError());
+    return RSLF_OK;
+}
+
 extern "C" int rslf_device_max_f32(rslf_ctx* ctx, const float* d_values, size_t n, float* h_max)
 {
     if (!ctx || !d_values || !h_max || n == 0)
@@ -1774,7 +1802,9 @@ extern "C" int rslf_fine_to_coarse_run_host(rslf_ctx* ctx, const void* const* h_
             break;
         DevBuf next;                                                       // f2c.hpp:145-147: the RAW EPIs go down
         HIP_TRY(next.alloc((size_t)v2 * S * u2 * C * sizeof(float)));
-        rc = rslf_downsample_epis_f32(ctx, cur_p, dim_v, S, dim_u, C, (float*)next.p);
+        // uchar EPIs go down in uchar arithmetic, as the reference's CV_8U Mats do (fine_to_coarse_core.cpp:22-41)
+        rc = is_u8 ? rslf_downsample_epis_u8(ctx, cur_p, dim_v, S, dim_u, C, (float*)next.p)
+                   : rslf_downsample_epis_f32(ctx, cur_p, dim_v, S, dim_u, C, (float*)next.p);
         if (rc)
             return rc;
         std::swap(cur.p, next.p);   // `next` now frees the previous level's raw copy

@@ -626,9 +626,10 @@ class Depth1DComputer:
 _MIN_SPATIAL_DIM = 10   # rslf_fine_to_coarse.hpp:8
 
 
-def downsample_EPIs(raw_vsuc: torch.Tensor, ctx: Context | None = None) -> torch.Tensor:
+def downsample_EPIs(raw_vsuc: torch.Tensor, ctx: Context | None = None, is_u8: bool = False) -> torch.Tensor:
     """rslf::downsample_EPIs (src/rslf_fine_to_coarse_core.cpp:14-60) on a dense RAW float32 CUDA volume
-    [V,S,U,C] -> [V2,S,U2,C]."""
+    [V,S,U,C] -> [V2,S,U2,C].  is_u8: the values are uchar levels (a CV_8U light field) and the blur and the halving
+    run in uchar arithmetic, as the reference's Mats of the input's own type do."""
     ctx = ctx or default_context(raw_vsuc.device)
     t = raw_vsuc.contiguous()
     V, S, U, C_ = t.shape
@@ -636,7 +637,10 @@ def downsample_EPIs(raw_vsuc: torch.Tensor, ctx: Context | None = None) -> torch
     check(_lib.lib().rslf_f2c_level_dims(V, U, C.byref(v2), C.byref(u2)), "rslf_f2c_level_dims")
     out = torch.empty((v2.value, S, u2.value, C_), dtype=torch.float32, device=t.device)
     ctx.use_current_stream()
-    check(_lib.lib().rslf_downsample_epis_f32(ctx._h, _ptr(t), V, S, U, C_, _ptr(out)), "rslf_downsample_epis_f32")
+    if is_u8:
+        check(_lib.lib().rslf_downsample_epis_u8(ctx._h, _ptr(t), V, S, U, C_, _ptr(out)), "rslf_downsample_epis_u8")
+    else:
+        check(_lib.lib().rslf_downsample_epis_f32(ctx._h, _ptr(t), V, S, U, C_, _ptr(out)), "rslf_downsample_epis_f32")
     return out
 
 
@@ -646,7 +650,7 @@ class FineToCoarse:
     tightened from the finer level, and a coarse-to-fine fusion of the disparity maps.
 
     `epis`: the reference's Vec<Mat> (list of V arrays [S,U] / [S,U,3]) or a dense array [V,S,U(,C)],
-    float32 or uint8.  Every pyramid is built in float (the reference blurs uchar input in uchar)."""
+    float32 or uint8.  A uint8 light field keeps uchar arithmetic through the pyramid, as the reference's CV_8U Mats do."""
 
     def __init__(self, epis, d_min: float, d_max: float, dim_d: int, epi_scale_factor: float = -1.0,
                  parameters: Depth1DParameters | None = None, max_pyr_depth: int = -1, accept_all_last_scale: bool = True,
@@ -685,7 +689,7 @@ class FineToCoarse:
             vol = Volume.from_dense(raw, scale, ctx)
             self.m_computers.append(Depth2DComputer(vol, d_min, d_max, dim_d, parameters=new_parameters))
             self.m_parameter_instances.append(new_parameters)
-            raw = downsample_EPIs(raw, ctx)                                                        # f2c.hpp:145-147
+            raw = downsample_EPIs(raw, ctx, self._is_u8)                                           # f2c.hpp:145-147
             dim_v, dim_u = raw.shape[0], raw.shape[2]
         if not self.m_computers:
             raise ValueError("light field smaller than _MIN_SPATIAL_DIM: no pyramid level")

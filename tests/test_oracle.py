@@ -329,3 +329,19 @@ def test_f2c_known_structure(oracle_mod):
     r = oracle_mod.fine_to_coarse_run((vol * 100).astype(np.float32), -1.0, 1.0, 5)
     assert r["dims"] == [(40, 48), (20, 24), (10, 12)] or r["dims"] == [(40, 48), (20, 24)]
     assert r["fused_map"].shape == (3, 40, 48)
+
+
+def test_downsample_u8_c_and_numpy_restatements_agree(oracle_mod):
+    """downsample_EPIs on CV_8U Mats (uchar arithmetic, fine_to_coarse_core.cpp:22-41): the C and the numpy restatement
+    are written independently and must agree bit for bit; results are uchar levels and stay close to the float pyramid."""
+    from oracle import oracle_np as onp
+    rng = np.random.default_rng(8)
+    for (V, S, U, C_) in [(12, 3, 15, 1), (11, 2, 14, 3), (7, 2, 7, 1), (16, 2, 16, 3), (13, 1, 22, 1)]:
+        lev = rng.integers(0, 256, size=(V, S, U, C_)).astype(np.float32)
+        c = oracle_mod.downsample_epis_u8(lev)
+        n = onp.downsample_epis_u8(lev)
+        assert np.array_equal(c, n), (V, S, U, C_)
+        assert np.array_equal(c, np.rint(c)) and c.min() >= 0 and c.max() <= 255
+        assert np.abs(c - oracle_mod.downsample_epis(lev)).max() < 1.0
+    flat = np.full((12, 2, 12, 1), 77.0, np.float32)       # a constant image stays constant: the taps sum to 256
+    assert np.all(oracle_mod.downsample_epis_u8(flat) == 77.0)
