@@ -954,8 +954,12 @@ __device__ __forceinline__ void scan_stream_rows(const ScanArgs& a, int v, int u
         // 63 consecutive pixels in lanes 0..62 (lane 63 is idle and shadows lane 62): lane 63 moves one pixel on --
         // still inside the row for every sample, wave_is_interior leaves two pixels of margin -- and the tail
         // shares taps between neighbours
+        // (every lane is compared, not just the ends: a short or gappy list can span 62 pixels too -- idle lanes shadow
+        // the last entry; found by the fuzz campaign, profiles/r02_fuzz_parity.txt)
         const int u0 = __builtin_amdgcn_readfirstlane(u), u62 = __builtin_amdgcn_readlane(u, 62);
-        if (a.tile_w == 63 && u62 - u0 == 62 && NRES + a.stream_park < a.vol.S) {
+        const int ln = threadIdx.x & 63;
+        const bool consecutive = __all(ln > 62 || u == u0 + ln);
+        if (a.tile_w == 63 && consecutive && NRES + a.stream_park < a.vol.S) {
             const int ud = ((threadIdx.x & 63) == 63) ? u62 + 1 : u;
             scan_stream_body<C, false, true, NRES, true>(a, v, ud, d0, d1, best, otab);
         } else {

@@ -588,3 +588,34 @@ def test_nan_radiances_take_the_generic_kernel(rs, oracle_mod):
         assert np.array_equal(got[k], getattr(ref, k)), k
     for k in ("score", "depth", "rbar", "edge_confidence"):
         assert np.array_equal(got[k], getattr(ref, k), equal_nan=True), k
+
+
+def test_stream_kernel_sparse_list_spanning_62_pixels(rs, oracle_mod, hooks):
+    """Regression (fuzz_parity seed 2001 case 2657): with a caller's scan mask a scanline's list can be short and still
+    span exactly 62 pixels from its first to its last entry -- idle lanes shadow the last entry -- which the streaming
+    kernel's 63-pixel tiles once took for 63 consecutive pixels and shared taps between unrelated lanes."""
+    import torch
+    hooks(force_scan="stream")
+    rng = np.random.default_rng(5)
+    V, S, U, D = 3, 31, 120, 24
+    vol = rng.uniform(0.05, 1.0, size=(V, S, U, 3)).astype(np.float32)
+    Ce, cm = oracle_mod.edge_confidence_pile(vol, S // 2)
+    mask = np.zeros((V, U), np.uint8)
+    mask[0, [30, 41, 55, 92]] = 255            # first and last entry 62 apart, interior tile
+    mask[1, 28:91] = 255                       # 63 consecutive pixels: the dense form proper
+    mask[2, [29, 30, 31, 60, 91]] = 255
+    assert cm[0, 30] and cm[0, 92] and cm[2, 29] and cm[2, 91]
+    dmin = np.full((V, U), -0.5, np.float32); dmax = np.full((V, U), 0.5, np.float32)
+    ref = oracle_mod.depth_epi_pile(vol, dmin, dmax, D, S // 2, Ce, cm, mask_vu=mask)
+    v = rs.Volume.from_dense(vol)
+    t = lambda a: torch.from_numpy(a.copy()).cuda()
+    tCe, tcm, tmask = t(Ce), t(cm), t(mask)
+    tCd = torch.zeros((V, U), device="cuda"); td = torch.zeros((V, U), device="cuda"); trb = torch.zeros((V, U, 3), device="cuda")
+    tidx = torch.empty((V, U), dtype=torch.int32, device="cuda"); tsc = torch.empty((V, U), device="cuda")
+    st = rs.compute_1D_depth_epi_pile(v, -0.5, 0.5, D, S // 2, tCe, tcm, tCd, td, trb, None, tmask, idx_v_u=tidx, score_v_u=tsc,
+                                      want_stats=True)
+    torch.cuda.synchronize()
+    assert st.scan_kernel == 2
+    assert np.array_equal(tidx.cpu().numpy(), ref.depth_idx)
+    assert np.array_equal(tsc.cpu().numpy(), ref.score)
+    assert np.array_equal(trb.cpu().numpy(), ref.rbar)

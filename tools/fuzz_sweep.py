@@ -99,10 +99,15 @@ def f2c_case(i, rng):
     D = int(rng.choice([5, 9, 16, 33, 40]))
     kind = str(rng.choice(["struct", "mixed", "jitter"]))
     vol = make_scene(rng, U, V, S, C_, kind)
-    raw = (vol * np.float32(rng.choice([1.0, 200.0])) + np.float32(rng.choice([0.0, 3.0]))).astype(np.float32)
-    ref = oracle.fine_to_coarse_run(raw, -1.0, 1.0, D)
+    is_u8 = bool(rng.uniform() < 0.35)   # a CV_8U light field: 1/255 per level, the pyramid in uchar arithmetic
+    if is_u8:
+        raw = np.round(vol * np.float32(255.0)).astype(np.uint8)
+        ref = oracle.fine_to_coarse_run(raw.astype(np.float32), -1.0, 1.0, D, is_u8=True)
+    else:
+        raw = (vol * np.float32(rng.choice([1.0, 200.0])) + np.float32(rng.choice([0.0, 3.0]))).astype(np.float32)
+        ref = oracle.fine_to_coarse_run(raw, -1.0, 1.0, D)
     f = rs.FineToCoarse(raw, -1.0, 1.0, D)
-    label = "f2c%d %s" % (i, (C_, S, U, V, D, kind))
+    label = "f2c%d %s" % (i, (C_, S, U, V, D, kind, "u8" if is_u8 else "f32"))
     assert [(c.m_epis.V, c.m_epis.U) for c in f.m_computers] == ref["dims"], label
     f.run()
     units = 0
@@ -120,7 +125,8 @@ def f2c_case(i, rng):
     nlev = C.c_int()
     p = rs.Depth1DParameters().to_c()
     ctx = f.m_computers[0].m_epis.ctx
-    _lib.check(_lib.lib().rslf_fine_to_coarse_run_host(ctx._h, ptrs, 0, V, S, U, C_, U * C_ * 4, -1.0, 1.0, D, -1.0, C.byref(p), -1, 1,
+    _lib.check(_lib.lib().rslf_fine_to_coarse_run_host(ctx._h, ptrs, 1 if is_u8 else 0, V, S, U, C_, U * C_ * (1 if is_u8 else 4), -1.0, 1.0,
+                                                       D, -1.0, C.byref(p), -1, 1,
                                                        hmap.ctypes.data_as(C.c_void_p), hval.ctypes.data_as(C.c_void_p), C.byref(nlev), None),
                "rslf_fine_to_coarse_run_host")
     assert nlev.value == len(ref["dims"]), (label, "native levels")
