@@ -95,6 +95,10 @@ def lib():
     global _LIB
     if _LIB is not None:
         return _LIB
+    # torch first: it brings its own copy of the HIP runtime (same soname as /opt/rocm's), and a process must not end up
+    # with the library bound to one copy and torch to the other -- whichever loads first serves both, and with ours
+    # first torch's streams and tensors and the library's context no longer see the same devices
+    import torch  # noqa: F401
     path = library_path()
     if not os.path.exists(path):
         try:
