@@ -275,6 +275,14 @@ int rslf_multi_depth1d_pile_f32(rslf_multi* m, const float* const* h_epis, size_
                                 float epi_scale_factor, float dmin, float dmax, int dim_d, int s_hat, const rslf_params* p,
                                 float* h_Ce_vu, uint8_t* h_Ce_mask_vu, float* h_Cd_vu, float* h_depth_vu, float* h_rbar_vu,
                                 int32_t* h_idx_vu, float* h_score_vu, float* h_depth_raw_vu, rslf_stats* stats, float* scale_used);
+/* Device-out form: the result planes live on device `out_device` (any device, one of the rslf_multi's or not); every
+ * worker copies its rows to their place there with hipMemcpyPeerAsync -- point-to-point over xGMI, no collective and no
+ * staging on the host.  Returns when the planes are complete. */
+int rslf_multi_depth1d_pile_f32_dev(rslf_multi* m, const float* const* h_epis, size_t row_stride_bytes, int V, int S, int U, int C,
+                                    float epi_scale_factor, float dmin, float dmax, int dim_d, int s_hat, const rslf_params* p,
+                                    int out_device, float* d_Ce_vu, uint8_t* d_Ce_mask_vu, float* d_Cd_vu, float* d_depth_vu,
+                                    float* d_rbar_vu, int32_t* d_idx_vu, float* d_score_vu, float* d_depth_raw_vu, rslf_stats* stats,
+                                    float* scale_used);
 int rslf_multi_depth1d_pile_u8(rslf_multi* m, const uint8_t* const* h_epis, size_t row_stride_bytes, int V, int S, int U, int C,
                                float dmin, float dmax, int dim_d, int s_hat, const rslf_params* p,
                                float* h_Ce_vu, uint8_t* h_Ce_mask_vu, float* h_Cd_vu, float* h_depth_vu, float* h_rbar_vu,

@@ -19,7 +19,7 @@ SYMBOLS = [
     "rslf_abi_version", "rslf_status_string", "rslf_last_error", "rslf_device_count", "rslf_default_params",
     "rslf_ctx_create", "rslf_ctx_destroy", "rslf_ctx_set_stream", "rslf_ctx_synchronize", "rslf_ctx_set_debug",
     "rslf_multi_create", "rslf_multi_destroy", "rslf_multi_device_count", "rslf_multi_set_chunk_rows",
-    "rslf_multi_depth1d_pile_f32", "rslf_multi_depth1d_pile_u8",
+    "rslf_multi_depth1d_pile_f32", "rslf_multi_depth1d_pile_u8", "rslf_multi_depth1d_pile_f32_dev",
     "rslf_volume_create", "rslf_volume_destroy", "rslf_volume_describe",
     "rslf_volume_upload_epis_f32", "rslf_volume_upload_epis_u8",
     "rslf_volume_upload_images_f32", "rslf_volume_upload_images_u8", "rslf_volume_pack_device_f32",
@@ -149,6 +149,8 @@ def lib():
     L.rslf_multi_set_chunk_rows.argtypes = [vp, ci]
     L.rslf_multi_depth1d_pile_f32.argtypes = [vp, C.POINTER(vp), C.c_size_t, ci, ci, ci, ci, cf, cf, cf, ci, ci, C.POINTER(RslfParams),
                                               vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(RslfStats), C.POINTER(cf)]
+    L.rslf_multi_depth1d_pile_f32_dev.argtypes = [vp, C.POINTER(vp), C.c_size_t, ci, ci, ci, ci, cf, cf, cf, ci, ci, C.POINTER(RslfParams), ci,
+                                                  vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(RslfStats), C.POINTER(cf)]
     L.rslf_multi_depth1d_pile_u8.argtypes = [vp, C.POINTER(vp), C.c_size_t, ci, ci, ci, ci, cf, cf, ci, ci, C.POINTER(RslfParams),
                                              vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(RslfStats)]
     L.rslf_kernel_columns_pile.argtypes = [vp, vp, vp, vp, cf, cf, ci, ci, C.POINTER(RslfParams), vp, vp]

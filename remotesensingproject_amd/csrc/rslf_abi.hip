@@ -2030,6 +2030,7 @@ struct MultiJob {
     float* h_score;
     float* h_raw;
     int halo;
+    int out_device;   // -1: the result planes are host memory; >= 0: they live on this device (peer copies)
 };
 
 struct Chunk {
@@ -2163,9 +2164,14 @@ int multi_worker(rslf_multi::Dev& d, const MultiJob& j, int r0, int r1, int chun
         const size_t off = (size_t)(c.a - c.lo) * j.U, cnt = (size_t)(c.b - c.a) * j.U, dst = (size_t)c.a * j.U;
         hipError_t e = hipStreamWaitEvent(d.s_down, d.done[k & 1], 0);
         auto pull = [&](void* h, const void* dv, size_t esz, size_t mult) {
-            if (e == hipSuccess && h)
+            if (e != hipSuccess || !h)
+                return;
+            if (j.out_device < 0)
                 e = hipMemcpyAsync((char*)h + dst * esz * mult, (const char*)dv + off * esz * mult, cnt * esz * mult, hipMemcpyDeviceToHost,
                                    d.s_down);
+            else   // device-out: each worker's rows go straight to their place in the planes on the output device (xGMI peer copy)
+                e = hipMemcpyPeerAsync((char*)h + dst * esz * mult, j.out_device, (const char*)dv + off * esz * mult, ctx->device,
+                                       cnt * esz * mult, d.s_down);
         };
         pull(j.h_Ce, q.Ce, 4, 1);
         pull(j.h_mask, q.mask, 1, 1);
@@ -2283,11 +2289,10 @@ int multi_run(rslf_multi* m, MultiJob j, rslf_stats* stats)
 
 }  // namespace
 
-extern "C" int rslf_multi_depth1d_pile_f32(rslf_multi* m, const float* const* h_epis, size_t row_stride_bytes, int V, int S, int U,
-                                           int C, float epi_scale_factor, float dmin, float dmax, int dim_d, int s_hat,
-                                           const rslf_params* p, float* h_Ce_vu, uint8_t* h_Ce_mask_vu, float* h_Cd_vu,
-                                           float* h_depth_vu, float* h_rbar_vu, int32_t* h_idx_vu, float* h_score_vu,
-                                           float* h_depth_raw_vu, rslf_stats* stats, float* scale_used)
+static int multi_pile_f32(rslf_multi* m, const float* const* h_epis, size_t row_stride_bytes, int V, int S, int U, int C,
+                          float epi_scale_factor, float dmin, float dmax, int dim_d, int s_hat, const rslf_params* p, int out_device,
+                          float* h_Ce_vu, uint8_t* h_Ce_mask_vu, float* h_Cd_vu, float* h_depth_vu, float* h_rbar_vu, int32_t* h_idx_vu,
+                          float* h_score_vu, float* h_depth_raw_vu, rslf_stats* stats, float* scale_used)
 {
     if (!m || !h_epis || V < 1)
         return fail(RSLF_ERR_INVALID_ARG, "NULL argument");
@@ -2302,8 +2307,30 @@ extern "C" int rslf_multi_depth1d_pile_f32(rslf_multi* m, const float* const* h_
     if (scale_used)
         *scale_used = epi_scale_factor;
     MultiJob j = {(const void* const*)h_epis, false, stride, V, S, U, C, epi_scale_factor, dmin, dmax, dim_d, s_hat, p,
-                  h_Ce_vu, h_Ce_mask_vu, h_Cd_vu, h_depth_vu, h_rbar_vu, h_idx_vu, h_score_vu, h_depth_raw_vu, 0};
+                  h_Ce_vu, h_Ce_mask_vu, h_Cd_vu, h_depth_vu, h_rbar_vu, h_idx_vu, h_score_vu, h_depth_raw_vu, 0, out_device};
     return multi_run(m, j, stats);
+}
+
+extern "C" int rslf_multi_depth1d_pile_f32(rslf_multi* m, const float* const* h_epis, size_t row_stride_bytes, int V, int S, int U,
+                                           int C, float epi_scale_factor, float dmin, float dmax, int dim_d, int s_hat,
+                                           const rslf_params* p, float* h_Ce_vu, uint8_t* h_Ce_mask_vu, float* h_Cd_vu,
+                                           float* h_depth_vu, float* h_rbar_vu, int32_t* h_idx_vu, float* h_score_vu,
+                                           float* h_depth_raw_vu, rslf_stats* stats, float* scale_used)
+{
+    return multi_pile_f32(m, h_epis, row_stride_bytes, V, S, U, C, epi_scale_factor, dmin, dmax, dim_d, s_hat, p, -1, h_Ce_vu,
+                          h_Ce_mask_vu, h_Cd_vu, h_depth_vu, h_rbar_vu, h_idx_vu, h_score_vu, h_depth_raw_vu, stats, scale_used);
+}
+
+extern "C" int rslf_multi_depth1d_pile_f32_dev(rslf_multi* m, const float* const* h_epis, size_t row_stride_bytes, int V, int S, int U,
+                                               int C, float epi_scale_factor, float dmin, float dmax, int dim_d, int s_hat,
+                                               const rslf_params* p, int out_device, float* d_Ce_vu, uint8_t* d_Ce_mask_vu,
+                                               float* d_Cd_vu, float* d_depth_vu, float* d_rbar_vu, int32_t* d_idx_vu,
+                                               float* d_score_vu, float* d_depth_raw_vu, rslf_stats* stats, float* scale_used)
+{
+    if (out_device < 0)
+        return fail(RSLF_ERR_INVALID_ARG, "out_device %d", out_device);
+    return multi_pile_f32(m, h_epis, row_stride_bytes, V, S, U, C, epi_scale_factor, dmin, dmax, dim_d, s_hat, p, out_device, d_Ce_vu,
+                          d_Ce_mask_vu, d_Cd_vu, d_depth_vu, d_rbar_vu, d_idx_vu, d_score_vu, d_depth_raw_vu, stats, scale_used);
 }
 
 extern "C" int rslf_multi_depth1d_pile_u8(rslf_multi* m, const uint8_t* const* h_epis, size_t row_stride_bytes, int V, int S, int U,
@@ -2312,6 +2339,6 @@ extern "C" int rslf_multi_depth1d_pile_u8(rslf_multi* m, const uint8_t* const* h
                                           float* h_score_vu, float* h_depth_raw_vu, rslf_stats* stats)
 {
     MultiJob j = {(const void* const*)h_epis, true, row_stride_bytes, V, S, U, C, 255.0f, dmin, dmax, dim_d, s_hat, p,
-                  h_Ce_vu, h_Ce_mask_vu, h_Cd_vu, h_depth_vu, h_rbar_vu, h_idx_vu, h_score_vu, h_depth_raw_vu, 0};
+                  h_Ce_vu, h_Ce_mask_vu, h_Cd_vu, h_depth_vu, h_rbar_vu, h_idx_vu, h_score_vu, h_depth_raw_vu, 0, -1};
     return multi_run(m, j, stats);
 }

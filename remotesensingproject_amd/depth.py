@@ -448,6 +448,30 @@ class MultiDevice:
         self.stats = st
         return out
 
+    def depth1d_pile_device_out(self, epis: Sequence[np.ndarray], dmin: float, dmax: float, dim_d: int, out_device: int = 0,
+                                s_hat: int = -1, epi_scale_factor: float = -1.0, parameters: Depth1DParameters | None = None) -> dict:
+        """The same with the result planes left on `out_device` as CUDA tensors (float32 EPIs): every worker copies its
+        rows there with a peer copy (rslf_multi_depth1d_pile_f32_dev)."""
+        keep = [np.ascontiguousarray(e, dtype=np.float32) for e in epis]
+        V = len(keep)
+        S, U = keep[0].shape[0], keep[0].shape[1]
+        C_ = 1 if keep[0].ndim == 2 else keep[0].shape[2]
+        ptrs = (C.c_void_p * V)(*[e.ctypes.data for e in keep])
+        dev = torch.device("cuda", out_device)
+        mk = lambda shape, dt: torch.empty(shape, dtype=dt, device=dev)
+        out = dict(edge_confidence=mk((V, U), torch.float32), edge_mask=mk((V, U), torch.uint8), disp_confidence=mk((V, U), torch.float32),
+                   depth=mk((V, U), torch.float32), rbar=mk((V, U, C_), torch.float32), depth_idx=mk((V, U), torch.int32),
+                   score=mk((V, U), torch.float32), depth_raw=mk((V, U), torch.float32))
+        torch.cuda.synchronize(dev)
+        hp = [_ptr(out[k]) for k in ("edge_confidence", "edge_mask", "disp_confidence", "depth", "rbar", "depth_idx", "score", "depth_raw")]
+        p = (parameters or Depth1DParameters()).to_c()
+        st, su = RslfStats(), C.c_float()
+        check(_lib.lib().rslf_multi_depth1d_pile_f32_dev(self._h, ptrs, 0, V, S, U, C_, float(epi_scale_factor), float(dmin), float(dmax),
+                                                         int(dim_d), int(s_hat), C.byref(p), int(out_device), *hp, C.byref(st), C.byref(su)),
+              "rslf_multi_depth1d_pile_f32_dev")
+        self.stats, self.scale_used = st, float(su.value)
+        return out
+
     def close(self) -> None:
         if getattr(self, "_h", None) and not sys.is_finalizing():
             _lib.lib().rslf_multi_destroy(self._h)

@@ -87,3 +87,20 @@ def test_multi_rejects_bad_arguments(rs):
     m = rs.MultiDevice()
     with pytest.raises(TypeError):
         m.depth1d_pile([np.zeros((3, 8), np.float64)], 0.0, 1.0, 4)
+
+
+def test_multi_device_out(rs):
+    """Device-out: the planes stay in HBM on the chosen device, each worker's rows arriving by peer copy."""
+    V, S, U, D = 27, 7, 90, 10
+    vol = _field(V, S, U, 1, 21)
+    epis = [vol[v, :, :, 0] for v in range(V)]
+    m = rs.MultiDevice([0, 0, 0])
+    m.set_chunk_rows(4)
+    got = m.depth1d_pile_device_out(epis, -1.0, 2.0, D, out_device=0, epi_scale_factor=1.0)
+    comp = rs.Depth1DComputer_pile(epis, -1.0, 2.0, D, epi_scale_factor=1.0)
+    comp.run()
+    ref = comp.results()
+    for k in PLANES:
+        assert got[k].is_cuda
+        assert np.array_equal(got[k].cpu().numpy(), ref[k]), k
+    assert m.stats.pixels_scanned == comp.stats.pixels_scanned
