@@ -1982,8 +1982,12 @@ extern "C" int rslf_multi_create(const int* devices, int n_devices, rslf_multi**
         int rc = rslf_ctx_create(n_devices > 0 ? devices[i] : 0, &d.ctx);   // a device may appear more than once
         hipError_t e = hipSuccess;
         if (rc == RSLF_OK) {
-            e = hipStreamCreateWithFlags(&d.s_up, hipStreamNonBlocking);
-            if (e == hipSuccess) e = hipStreamCreateWithFlags(&d.s_comp, hipStreamNonBlocking);
+            // the upload stream outranks the compute stream: its blit and pack kernels then take the slots the scan's
+            // workgroups free as they finish, instead of waiting behind the whole scan of the previous chunk
+            int prio_lo = 0, prio_hi = 0;
+            (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+            e = hipStreamCreateWithPriority(&d.s_up, hipStreamNonBlocking, prio_hi);
+            if (e == hipSuccess) e = hipStreamCreateWithPriority(&d.s_comp, hipStreamNonBlocking, prio_lo);
             if (e == hipSuccess) e = hipStreamCreateWithFlags(&d.s_down, hipStreamNonBlocking);
             for (int k = 0; k < 2 && e == hipSuccess; k++)
                 e = hipEventCreateWithFlags(&d.done[k], hipEventDisableTiming);
