@@ -310,6 +310,25 @@ int rslf_depth_epi_2d(rslf_ctx* ctx, const rslf_volume* vol, const float* d_dmin
                       float* d_Ce_svu, uint8_t* d_Ce_mask_svu, float* d_Cd_svu, float* d_depth_svu,
                       float* d_rbar_svu, const rslf_params* p, uint8_t* d_scan_mask_svu, rslf_stats* stats);
 
+/* The sweep one visit at a time -- for callers that shard the scanlines of a sweep over devices (DESIGN.md
+ * "Multi-GPU").  Scan and propagation are local to a scanline (core.hpp:1012-1028, :1088-1129) but the selective median
+ * of a visit reads +-(size-1)/2 scanlines of the visited view's raw disparities and edge mask (core.hpp:686), which a
+ * neighbouring device has just written: between rslf_sweep_visit_scan and rslf_sweep_visit_finish the caller brings
+ * those rows of d_depth_svu[s_hat] and d_Ce_mask_svu[s_hat] up to date (a 2-row exchange with each neighbour).
+ *   begin:  scanlines [v_lo, v_hi) of the volume are this device's own; the others are halo rows -- their running mask is
+ *           cleared, so nothing is ever scanned or painted on them here.  (0, V) = an unsharded sweep.
+ *   visits: in the reference's order, centre view outwards (core.hpp:981-990).
+ *   end:    restores the context (call it with ok = 0 after a failed step); stats count the own scanlines only.
+ * rslf_depth_epi_2d is exactly begin + (scan, finish) per view + end on (0, V). */
+int rslf_sweep_begin(rslf_ctx* ctx, const rslf_volume* vol, const uint8_t* d_Ce_mask_svu, uint8_t* d_scan_mask_svu, int dim_d,
+                     int v_lo, int v_hi);
+int rslf_sweep_visit_scan(rslf_ctx* ctx, const rslf_volume* vol, const float* d_dmin_svu, const float* d_dmax_svu, float dmin,
+                          float dmax, int dim_d, int s_hat, float* d_Ce_svu, uint8_t* d_Ce_mask_svu, float* d_Cd_svu,
+                          float* d_depth_svu, float* d_rbar_svu, const rslf_params* p);
+int rslf_sweep_visit_finish(rslf_ctx* ctx, const rslf_volume* vol, int s_hat, uint8_t* d_Ce_mask_svu, float* d_Cd_svu,
+                            float* d_depth_svu, float* d_rbar_svu, const rslf_params* p);
+int rslf_sweep_end(rslf_ctx* ctx, int ok, int dim_d, rslf_stats* stats);
+
 /* rslf::Depth2DComputer<T>::run() -- include/rslf_depth_computation.hpp:748-805 with the
  * constructor's output allocation (:718-750): zero-fills the outputs, then the two calls above. */
 int rslf_depth2d_run(rslf_ctx* ctx, const rslf_volume* vol, float dmin, float dmax, int dim_d, const rslf_params* p,

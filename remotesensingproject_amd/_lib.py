@@ -26,6 +26,7 @@ SYMBOLS = [
     "rslf_edge_confidence_pile", "rslf_depth_epi_pile", "rslf_selective_median",
     "rslf_depth1d_pile_run", "rslf_depth1d_pile_run_host", "rslf_last_scan_kernel_ms",
     "rslf_edge_confidence_2d", "rslf_depth_epi_2d", "rslf_depth2d_run",
+    "rslf_sweep_begin", "rslf_sweep_visit_scan", "rslf_sweep_visit_finish", "rslf_sweep_end",
     "rslf_depth_epi_scan", "rslf_depth1d_run",
     "rslf_f2c_level_dims", "rslf_downsample_epis_f32", "rslf_downsample_epis_u8", "rslf_device_max_f32", "rslf_f2c_tighten_bounds", "rslf_f2c_fuse",
     "rslf_depth2d_run_host", "rslf_fine_to_coarse_run_host", "rslf_kernel_columns_pile", "rslf_volume_upload_images_xf_f32", "rslf_volume_upload_images_xf_u8",
@@ -143,6 +144,10 @@ def lib():
                                         C.POINTER(RslfStats)]
     L.rslf_depth1d_pile_run_host.argtypes = L.rslf_depth1d_pile_run.argtypes
     L.rslf_last_scan_kernel_ms.argtypes = [vp, C.POINTER(cf)]
+    L.rslf_sweep_begin.argtypes = [vp, vp, vp, vp, ci, ci, ci]
+    L.rslf_sweep_visit_scan.argtypes = [vp, vp, vp, vp, cf, cf, ci, ci, vp, vp, vp, vp, vp, C.POINTER(RslfParams)]
+    L.rslf_sweep_visit_finish.argtypes = [vp, vp, ci, vp, vp, vp, vp, C.POINTER(RslfParams)]
+    L.rslf_sweep_end.argtypes = [vp, ci, ci, C.POINTER(RslfStats)]
     L.rslf_multi_create.argtypes = [C.POINTER(ci), ci, C.POINTER(vp)]
     L.rslf_multi_destroy.argtypes = [vp]
     L.rslf_multi_device_count.argtypes = [vp]

@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <string>
 #include <vector>
 
 #include "k1_edge.hpp"
@@ -88,6 +89,9 @@ struct rslf_ctx {
     size_t ticket_cap = 0;
     bool packed_n_clean = false;       // the packed list's length is already 0 (the sweep's apply pass resets it)
     bool precompacted = false;         // the next scan's pixel lists and total are already in place (K1 + compaction in one launch)
+    bool sweep_open = false;           // between rslf_sweep_begin and rslf_sweep_end
+    bool sweep_first = true;           // the next visit is the sweep's first (dense) one
+    uint8_t* sweep_mask_run = nullptr; // the running masks [S][V][U] of the open sweep
     // 2-D sweep scratch
     int* winner = nullptr;        // [S][V][U]
     uint8_t* sweep_mask = nullptr;
@@ -1362,45 +1366,45 @@ static int ensure_sweep_scratch(rslf_ctx* ctx, const rslf_volume* vol)
     return RSLF_OK;
 }
 
-extern "C" int rslf_depth_epi_2d(rslf_ctx* ctx, const rslf_volume* vol, const float* d_dmin_svu, const float* d_dmax_svu,
-                                 float dmin, float dmax, int dim_d, float* d_Ce_svu, uint8_t* d_Ce_mask_svu, float* d_Cd_svu,
-                                 float* d_depth_svu, float* d_rbar_svu, const rslf_params* p, uint8_t* d_scan_mask_svu,
-                                 rslf_stats* stats)
+// The sweep one visit at a time (rslf_sweep_*), and rslf_depth_epi_2d on top of it.  The launch shape of the visits
+// (hypothesis groups, packed tiles, running total) is context state the scan reads: rslf_sweep_end restores it, and after
+// an error the winners are refilled on the next sweep (a claim pass whose apply never ran leaves them set).
+static void sweep_close(rslf_ctx* ctx, bool ok)
 {
-    if (!ctx || !vol || !d_Ce_svu || !d_Ce_mask_svu || !d_Cd_svu || !d_depth_svu || !d_rbar_svu)
+    ctx->keep_total = false;
+    ctx->scan_groups = 1;
+    ctx->scan_packed = false;
+    ctx->packed_n_clean = false;
+    if (!ok)
+        ctx->sweep_cap = 0;
+    ctx->sweep_open = false;
+}
+
+extern "C" int rslf_sweep_begin(rslf_ctx* ctx, const rslf_volume* vol, const uint8_t* d_Ce_mask_svu, uint8_t* d_scan_mask_svu,
+                                int dim_d, int v_lo, int v_hi)
+{
+    if (!ctx || !vol || !d_Ce_mask_svu)
         return fail(RSLF_ERR_INVALID_ARG, "NULL argument");
-    int rc = check_params(p);
-    if (rc)
-        return rc;
-    if ((d_dmin_svu == nullptr) != (d_dmax_svu == nullptr))
-        return fail(RSLF_ERR_INVALID_ARG, "d_dmin_svu and d_dmax_svu must both be given or both be NULL");
+    if (v_lo < 0 || v_hi > vol->V || v_lo >= v_hi)
+        return fail(RSLF_ERR_INVALID_ARG, "active scanlines [%d, %d) outside the volume's %d", v_lo, v_hi, vol->V);
     HIP_TRY(hipSetDevice(ctx->device));
-    rc = ensure_sweep_scratch(ctx, vol);
+    if (ctx->sweep_open)
+        sweep_close(ctx, false);   // a sweep left open by a caller's error path
+    int rc = ensure_sweep_scratch(ctx, vol);
     if (rc)
         return rc;
-    const int S = vol->S, V = vol->V, U = vol->U, C = vol->C;
+    const int S = vol->S, V = vol->V, U = vol->U;
     const size_t n = (size_t)V * U;
     hipStream_t st = ctx->stream;
     uint8_t* mask_svu = d_scan_mask_svu ? d_scan_mask_svu : ctx->sweep_mask;
-    // core.hpp:958-965: running masks start as clones of the edge masks
+    // core.hpp:958-965: running masks start as clones of the edge masks ...
     HIP_TRY(hipMemcpyAsync(mask_svu, d_Ce_mask_svu, (size_t)S * n, hipMemcpyDeviceToDevice, st));
+    // ... except on halo scanlines (a sharded sweep): never scanned, never painted here -- their owner does both
+    if (v_lo > 0)
+        HIP_TRY(hipMemset2DAsync(mask_svu, n, 0, (size_t)v_lo * U, S, st));
+    if (v_hi < V)
+        HIP_TRY(hipMemset2DAsync(mask_svu + (size_t)v_hi * U, n, 0, (size_t)(V - v_hi) * U, S, st));
     HIP_TRY(hipMemsetAsync(ctx->total, 0, sizeof(unsigned long long), st));
-
-    std::vector<int> order;   // core.hpp:981-990
-    const int s_mid = (int)std::floor(S / 2.0);
-    order.push_back(s_mid);
-    for (int off = 1; off < S - s_mid; off++) {
-        order.push_back(s_mid + off);
-        if (s_mid - off > -1)
-            order.push_back(s_mid - off);
-    }
-
-    const dim3 grid_vu((U + 255) / 256, V);
-    const unsigned apply_blocks = (unsigned)std::min<size_t>(((size_t)S * n + 255) / 256, 256 * 8 * 4);
-    if (p->median_filter_size < 1 || (p->median_filter_size & 1) == 0 || p->median_filter_size > kMedianMaxSize)
-        return fail(RSLF_ERR_UNSUPPORTED, "median size must be odd and <= %d", kMedianMaxSize);
-    const size_t median_lds = (size_t)p->median_filter_size * p->median_filter_size * 256 * sizeof(float);
-    int* packed_n = reinterpret_cast<int*>(ctx->total + 1);
     {   // the sparse visits' records, sized before the first visit (no allocation in the middle of the sequence)
         int g = 16;
         while (g > 1 && dim_d < 2 * kScanWaves * g)
@@ -1413,72 +1417,138 @@ extern "C" int rslf_depth_epi_2d(rslf_ctx* ctx, const rslf_volume* vol, const fl
                 return rc;
         }
     }
-    // the launch shape of the visits (hypothesis groups, packed tiles, running total) is context state the scan reads:
-    // restored on EVERY exit, and after an error the winners are refilled on the next sweep (a claim pass whose apply
-    // never ran leaves them set)
-    struct SweepState {
-        rslf_ctx* c;
-        bool ok = false;
-        explicit SweepState(rslf_ctx* c_) : c(c_) { c->keep_total = true; }
-        ~SweepState()
-        {
-            c->keep_total = false;
-            c->scan_groups = 1;
-            c->scan_packed = false;
-            c->packed_n_clean = false;
-            if (!ok)
-                c->sweep_cap = 0;
-        }
-    } sweep_state(ctx);
-    bool first_visit = true;
-    for (int s_hat : order) {
-        // After the centre view, propagation has explained most pixels: a visit scans a few per scanline.
-        // Pack them into one list and share each tile's hypotheses out over up to 16 workgroups (k2_scan.hpp).
-        ctx->scan_groups = first_visit ? 1 : 16;
-        ctx->scan_packed = !first_visit;
-        first_visit = false;
-        float* depth = d_depth_svu + (size_t)s_hat * n;
-        float* Cd = d_Cd_svu + (size_t)s_hat * n;
-        float* rbar = d_rbar_svu + (size_t)s_hat * n * C;
-        uint8_t* cem = d_Ce_mask_svu + (size_t)s_hat * n;
-        // core.hpp:1012-1028: the pile call is the scan of every EPI followed by the selective median.  In the
-        // reference the stored plane keeps the RAW depths and only the local header is rebound to the median
-        // (core.hpp:892), which the propagation then paints from: so the scan writes `depth` and the median goes
-        // straight to ctx->filtered -- no plane copies.
-        rc = rslf_depth_epi_scan(ctx, vol, d_dmin_svu ? d_dmin_svu + (size_t)s_hat * n : nullptr,
-                                 d_dmax_svu ? d_dmax_svu + (size_t)s_hat * n : nullptr, dmin, dmax, dim_d, s_hat,
-                                 d_Ce_svu + (size_t)s_hat * n, cem, Cd, depth, rbar, p, mask_svu + (size_t)s_hat * n, nullptr,
-                                 nullptr, nullptr);
-        if (rc)
-            return rc;
-        // core.hpp:881-892 (selective median over the edge mask) and :1088-1129 (propagation) -- the median and the
-        // claims of a pixel in one launch (k34_median_claim), then the apply pass; a visit is four launches:
-        // compaction, scan (its groups merge their records themselves), median + claims, apply
-        if (C == 1)
-            hipLaunchKernelGGL(k34_median_claim<1>, grid_vu, dim3(256), median_lds, st, view_of(vol), s_hat, depth, ctx->filtered, cem,
-                               p->median_filter_size, p->median_filter_epsilon, rbar, mask_svu, ctx->winner, p->slope_factor,
-                               p->propagation_epsilon, p->use_disp_confidence_score ? Cd : nullptr, p->disp_score_threshold);
-        else
-            hipLaunchKernelGGL(k34_median_claim<3>, grid_vu, dim3(256), median_lds, st, view_of(vol), s_hat, depth, ctx->filtered, cem,
-                               p->median_filter_size, p->median_filter_epsilon, rbar, mask_svu, ctx->winner, p->slope_factor,
-                               p->propagation_epsilon, p->use_disp_confidence_score ? Cd : nullptr, p->disp_score_threshold);
-        HIP_TRY(hipGetLastError());
-        hipLaunchKernelGGL(k4_propagate_apply, dim3(apply_blocks), dim3(256), 0, st, S, V, U, s_hat, ctx->filtered, Cd,
-                           d_depth_svu, d_Cd_svu, mask_svu, ctx->winner, packed_n);
-        HIP_TRY(hipGetLastError());
-        ctx->packed_n_clean = true;   // the apply pass has queued the reset the next visit's compaction needs
-    }
-    if (stats) {
+    ctx->keep_total = true;
+    ctx->sweep_open = true;
+    ctx->sweep_first = true;
+    ctx->sweep_mask_run = mask_svu;
+    return RSLF_OK;
+}
+
+extern "C" int rslf_sweep_visit_scan(rslf_ctx* ctx, const rslf_volume* vol, const float* d_dmin_svu, const float* d_dmax_svu,
+                                     float dmin, float dmax, int dim_d, int s_hat, float* d_Ce_svu, uint8_t* d_Ce_mask_svu,
+                                     float* d_Cd_svu, float* d_depth_svu, float* d_rbar_svu, const rslf_params* p)
+{
+    if (!ctx || !vol || !d_Ce_svu || !d_Ce_mask_svu || !d_Cd_svu || !d_depth_svu || !d_rbar_svu)
+        return fail(RSLF_ERR_INVALID_ARG, "NULL argument");
+    if (!ctx->sweep_open)
+        return fail(RSLF_ERR_INVALID_ARG, "rslf_sweep_visit_scan without rslf_sweep_begin");
+    if ((d_dmin_svu == nullptr) != (d_dmax_svu == nullptr))
+        return fail(RSLF_ERR_INVALID_ARG, "d_dmin_svu and d_dmax_svu must both be given or both be NULL");
+    if (s_hat < 0 || s_hat >= vol->S)
+        return fail(RSLF_ERR_INVALID_ARG, "s_hat=%d outside [0,%d)", s_hat, vol->S);
+    const size_t n = (size_t)vol->V * vol->U;
+    // After the centre view, propagation has explained most pixels: a visit scans a few per scanline.
+    // Pack them into one list and share each tile's hypotheses out over up to 16 workgroups (k2_scan.hpp).
+    ctx->scan_groups = ctx->sweep_first ? 1 : 16;
+    ctx->scan_packed = !ctx->sweep_first;
+    // core.hpp:1012-1028: the pile call is the scan of every EPI followed by the selective median.  In the
+    // reference the stored plane keeps the RAW depths and only the local header is rebound to the median
+    // (core.hpp:892), which the propagation then paints from: so the scan writes the view's depth plane and the median
+    // goes to ctx->filtered (rslf_sweep_visit_finish) -- no plane copies.
+    return rslf_depth_epi_scan(ctx, vol, d_dmin_svu ? d_dmin_svu + (size_t)s_hat * n : nullptr,
+                               d_dmax_svu ? d_dmax_svu + (size_t)s_hat * n : nullptr, dmin, dmax, dim_d, s_hat,
+                               d_Ce_svu + (size_t)s_hat * n, d_Ce_mask_svu + (size_t)s_hat * n, d_Cd_svu + (size_t)s_hat * n,
+                               d_depth_svu + (size_t)s_hat * n, d_rbar_svu + (size_t)s_hat * n * vol->C, p,
+                               ctx->sweep_mask_run + (size_t)s_hat * n, nullptr, nullptr, nullptr);
+}
+
+extern "C" int rslf_sweep_visit_finish(rslf_ctx* ctx, const rslf_volume* vol, int s_hat, uint8_t* d_Ce_mask_svu, float* d_Cd_svu,
+                                       float* d_depth_svu, float* d_rbar_svu, const rslf_params* p)
+{
+    if (!ctx || !vol || !d_Ce_mask_svu || !d_Cd_svu || !d_depth_svu || !d_rbar_svu || !p)
+        return fail(RSLF_ERR_INVALID_ARG, "NULL argument");
+    if (!ctx->sweep_open)
+        return fail(RSLF_ERR_INVALID_ARG, "rslf_sweep_visit_finish without rslf_sweep_begin");
+    if (s_hat < 0 || s_hat >= vol->S)
+        return fail(RSLF_ERR_INVALID_ARG, "s_hat=%d outside [0,%d)", s_hat, vol->S);
+    if (p->median_filter_size < 1 || (p->median_filter_size & 1) == 0 || p->median_filter_size > kMedianMaxSize)
+        return fail(RSLF_ERR_UNSUPPORTED, "median size must be odd and <= %d", kMedianMaxSize);
+    HIP_TRY(hipSetDevice(ctx->device));
+    const int S = vol->S, V = vol->V, U = vol->U, C = vol->C;
+    const size_t n = (size_t)V * U;
+    hipStream_t st = ctx->stream;
+    uint8_t* mask_svu = ctx->sweep_mask_run;
+    const dim3 grid_vu((U + 255) / 256, V);
+    const unsigned apply_blocks = (unsigned)std::min<size_t>(((size_t)S * n + 255) / 256, 256 * 8 * 4);
+    const size_t median_lds = (size_t)p->median_filter_size * p->median_filter_size * 256 * sizeof(float);
+    int* packed_n = reinterpret_cast<int*>(ctx->total + 1);
+    float* depth = d_depth_svu + (size_t)s_hat * n;
+    float* Cd = d_Cd_svu + (size_t)s_hat * n;
+    float* rbar = d_rbar_svu + (size_t)s_hat * n * C;
+    uint8_t* cem = d_Ce_mask_svu + (size_t)s_hat * n;
+    // core.hpp:881-892 (selective median over the edge mask) and :1088-1129 (propagation) -- the median and the
+    // claims of a pixel in one launch (k34_median_claim), then the apply pass; a visit is four launches:
+    // compaction, scan (its groups merge their records themselves), median + claims, apply
+    if (C == 1)
+        hipLaunchKernelGGL(k34_median_claim<1>, grid_vu, dim3(256), median_lds, st, view_of(vol), s_hat, depth, ctx->filtered, cem,
+                           p->median_filter_size, p->median_filter_epsilon, rbar, mask_svu, ctx->winner, p->slope_factor,
+                           p->propagation_epsilon, p->use_disp_confidence_score ? Cd : nullptr, p->disp_score_threshold);
+    else
+        hipLaunchKernelGGL(k34_median_claim<3>, grid_vu, dim3(256), median_lds, st, view_of(vol), s_hat, depth, ctx->filtered, cem,
+                           p->median_filter_size, p->median_filter_epsilon, rbar, mask_svu, ctx->winner, p->slope_factor,
+                           p->propagation_epsilon, p->use_disp_confidence_score ? Cd : nullptr, p->disp_score_threshold);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(k4_propagate_apply, dim3(apply_blocks), dim3(256), 0, st, S, V, U, s_hat, ctx->filtered, Cd, d_depth_svu,
+                       d_Cd_svu, mask_svu, ctx->winner, packed_n);
+    HIP_TRY(hipGetLastError());
+    ctx->packed_n_clean = true;   // the apply pass has queued the reset the next visit's compaction needs
+    ctx->sweep_first = false;
+    return RSLF_OK;
+}
+
+extern "C" int rslf_sweep_end(rslf_ctx* ctx, int ok, int dim_d, rslf_stats* stats)
+{
+    if (!ctx)
+        return fail(RSLF_ERR_INVALID_ARG, "ctx is NULL");
+    const bool was_open = ctx->sweep_open;
+    sweep_close(ctx, ok != 0 && was_open);
+    if (ok && was_open && stats) {
         unsigned long long tot = 0;
-        HIP_TRY(hipMemcpyAsync(&tot, ctx->total, sizeof(tot), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(hipSetDevice(ctx->device));
+        HIP_TRY(hipMemcpyAsync(&tot, ctx->total, sizeof(tot), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
         stats->pixels_scanned = (int64_t)tot;
         stats->units = (int64_t)tot * dim_d;
         stats->scan_kernel = ctx->last_kernel;
         stats->s_pad = ctx->last_spad;
     }
-    sweep_state.ok = true;
     return RSLF_OK;
+}
+
+extern "C" int rslf_depth_epi_2d(rslf_ctx* ctx, const rslf_volume* vol, const float* d_dmin_svu, const float* d_dmax_svu,
+                                 float dmin, float dmax, int dim_d, float* d_Ce_svu, uint8_t* d_Ce_mask_svu, float* d_Cd_svu,
+                                 float* d_depth_svu, float* d_rbar_svu, const rslf_params* p, uint8_t* d_scan_mask_svu,
+                                 rslf_stats* stats)
+{
+    if (!ctx || !vol || !d_Ce_svu || !d_Ce_mask_svu || !d_Cd_svu || !d_depth_svu || !d_rbar_svu)
+        return fail(RSLF_ERR_INVALID_ARG, "NULL argument");
+    int rc = check_params(p);
+    if (rc)
+        return rc;
+    rc = rslf_sweep_begin(ctx, vol, d_Ce_mask_svu, d_scan_mask_svu, dim_d, 0, vol->V);
+    if (rc)
+        return rc;
+    const int S = vol->S;
+    std::vector<int> order;   // core.hpp:981-990
+    const int s_mid = (int)std::floor(S / 2.0);
+    order.push_back(s_mid);
+    for (int off = 1; off < S - s_mid; off++) {
+        order.push_back(s_mid + off);
+        if (s_mid - off > -1)
+            order.push_back(s_mid - off);
+    }
+    for (int s_hat : order) {
+        rc = rslf_sweep_visit_scan(ctx, vol, d_dmin_svu, d_dmax_svu, dmin, dmax, dim_d, s_hat, d_Ce_svu, d_Ce_mask_svu, d_Cd_svu,
+                                   d_depth_svu, d_rbar_svu, p);
+        if (!rc)
+            rc = rslf_sweep_visit_finish(ctx, vol, s_hat, d_Ce_mask_svu, d_Cd_svu, d_depth_svu, d_rbar_svu, p);
+        if (rc) {
+            const std::string msg = g_err;
+            (void)rslf_sweep_end(ctx, 0, dim_d, nullptr);
+            return fail(rc, "%s", msg.c_str());
+        }
+    }
+    return rslf_sweep_end(ctx, 1, dim_d, stats);
 }
 
 extern "C" int rslf_depth2d_run(rslf_ctx* ctx, const rslf_volume* vol, float dmin, float dmax, int dim_d, const rslf_params* p,

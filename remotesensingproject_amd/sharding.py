@@ -18,6 +18,8 @@ from __future__ import annotations
 from dataclasses import dataclass
 from typing import Callable, Dict, List, Optional, Tuple
 
+import ctypes as C
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -233,3 +235,181 @@ def run_sharded(local_compute: Callable[[Shard], Dict[str, torch.Tensor]], V: in
     shard = make_shard(V, rank, world, median_filter_size, opening_size)
     planes = local_compute(shard)
     return gather_planes(planes, shard, U, C, group)
+
+
+# ---- the 2-D sweep over scanline shards ---------------------------------------------------------------------------------
+#
+# Depth2DComputer::run (dc.hpp:748-805): the scan and the propagation of a visit are local to a scanline, the selective
+# median between them reads +-(size-1)/2 scanlines of the VISITED view's raw disparities and edge mask (core.hpp:686).
+# Recomputing a halo does not work here as it does for the pile path -- every visit would widen it by two rows -- so this
+# is the one place on the path with a real exchange step: after a visit's scan each rank sends its first and last
+# (size-1)/2 own rows of those two planes to its neighbours (two small point-to-point messages per neighbour and visit,
+# 2 x 1920 x 5 B each at c3), then runs the median, the claims and the apply pass on its own rows.
+
+def sweep_order(S: int) -> List[int]:
+    """core.hpp:981-990: centre view, then outwards, alternating."""
+    s_mid = int(np.floor(S / 2.0))
+    order = [s_mid]
+    for off in range(1, S - s_mid):
+        order.append(s_mid + off)
+        if s_mid - off > -1:
+            order.append(s_mid - off)
+    return order
+
+
+def exchange_halo_rows(rank: int, world: int, top, bottom, above, below, group=None) -> None:
+    """Neighbour exchange of one visit: `top` / `bottom` (tuples of tensors: this rank's first / last own rows) go to
+    ranks rank-1 / rank+1, whose bottom / top rows land in `above` / `below` (None where there is no neighbour).  One
+    batch of point-to-point operations -- on RCCL they are stream-ordered device-to-device transfers over xGMI; gloo
+    (CPU rehearsal, tests) goes through host copies."""
+    if world == 1 or not dist.is_initialized():
+        return
+    via_host = dist.get_backend(group) == "gloo"
+    ops, landing = [], []
+    for peer, send, recv in ((rank - 1, top, above), (rank + 1, bottom, below)):
+        if peer < 0 or peer >= world or recv is None:
+            continue
+        for t_send, t_recv in zip(send, recv):
+            src = t_send.contiguous().cpu() if via_host else t_send.contiguous()
+            dst = torch.empty_like(src)
+            ops.append(dist.P2POp(dist.isend, src, peer, group))
+            ops.append(dist.P2POp(dist.irecv, dst, peer, group))
+            landing.append((t_recv, dst))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    for t_recv, dst in landing:
+        t_recv.copy_(dst)
+
+
+class ShardedDepth2D:
+    """One rank's share of Depth2DComputer::run: `vol` holds scanlines [shard.lo, shard.hi) of the light field (the own
+    block plus halo_rows() either side, normalised with the GLOBAL scale -- global_epi_scale), planes are [S, rows, U].
+
+    run() drives the visits with a neighbour exchange over torch.distributed (RCCL: stream-ordered, no host
+    synchronisation); the steps are public so that a lock-step harness can drive several shards in one process
+    (tests/test_gpu_sweep2d.py)."""
+
+    def __init__(self, vol, shard: Shard, dmin: float, dmax: float, dim_d: int, parameters=None, group=None):
+        from . import depth as rs
+        self.rs, self.vol, self.shard, self.group = rs, vol, shard, group
+        self.p = parameters or rs.Depth1DParameters()
+        self.dmin, self.dmax, self.dim_d = float(dmin), float(dmax), int(dim_d)
+        self.h = (int(self.p.par_median_filter_size) - 1) // 2          # rows the median reads either side
+        self.own = shard.interior                                         # own rows in the local frame
+        if vol.V != shard.hi - shard.lo:
+            raise ValueError("the volume must hold rows [%d, %d) of the light field" % (shard.lo, shard.hi))
+        if (shard.v0 > 0 and shard.v0 - shard.lo < self.h) or (shard.v1 < shard.V and shard.hi - shard.v1 < self.h):
+            raise ValueError("the shard's halo is narrower than the median's reach")
+        if shard.v1 - shard.v0 < self.h:
+            raise ValueError("a block of %d scanlines cannot fill its neighbours' %d halo rows" % (shard.v1 - shard.v0, self.h))
+        dev = vol.ctx.device
+        S, V, U, C_ = vol.S, vol.V, vol.U, vol.C
+        self.Ce = torch.zeros((S, V, U), dtype=torch.float32, device=dev)
+        self.Cd = torch.zeros((S, V, U), dtype=torch.float32, device=dev)
+        self.depth = torch.zeros((S, V, U), dtype=torch.float32, device=dev)
+        self.rbar = torch.zeros((S, V, U, C_), dtype=torch.float32, device=dev)
+        self.scan_mask = torch.empty((S, V, U), dtype=torch.uint8, device=dev)
+        self.cem = None
+        self.stats = None
+
+    # -- steps -------------------------------------------------------------------------------------------------------------
+    def prepare(self) -> None:
+        rs, L = self.rs, self._L()
+        self.cem = rs.compute_2D_edge_confidence(self.vol, self.Ce, self.p)     # every local row: the masks are row-local
+        self.vol.ctx.use_current_stream()
+        self._check(L.rslf_sweep_begin(self.vol.ctx._h, self.vol._h, self._ptr(self.cem), self._ptr(self.scan_mask), self.dim_d,
+                                       self.own.start, self.own.stop), "rslf_sweep_begin")
+
+    def visit_scan(self, s_hat: int) -> None:
+        pc = self.p.to_c()
+        self.vol.ctx.use_current_stream()
+        self._check(self._L().rslf_sweep_visit_scan(self.vol.ctx._h, self.vol._h, None, None, self.dmin, self.dmax, self.dim_d, int(s_hat),
+                                                    self._ptr(self.Ce), self._ptr(self.cem), self._ptr(self.Cd), self._ptr(self.depth),
+                                                    self._ptr(self.rbar), C.byref(pc)), "rslf_sweep_visit_scan")
+
+    def boundary_rows(self, s_hat: int):
+        """(top, bottom): this rank's first / last h own rows of the visited view's raw depths and edge mask."""
+        a, b, h = self.own.start, self.own.stop, self.h
+        return ((self.depth[s_hat, a:a + h], self.cem[s_hat, a:a + h]), (self.depth[s_hat, b - h:b], self.cem[s_hat, b - h:b]))
+
+    def halo_slots(self, s_hat: int):
+        """(above, below): where the upper / lower neighbour's boundary rows belong (None at the field's edge)."""
+        a, b, h = self.own.start, self.own.stop, self.h
+        above = (self.depth[s_hat, a - h:a], self.cem[s_hat, a - h:a]) if self.shard.v0 > 0 else None
+        below = (self.depth[s_hat, b:b + h], self.cem[s_hat, b:b + h]) if self.shard.v1 < self.shard.V else None
+        return above, below
+
+    def visit_finish(self, s_hat: int) -> None:
+        pc = self.p.to_c()
+        self.vol.ctx.use_current_stream()
+        self._check(self._L().rslf_sweep_visit_finish(self.vol.ctx._h, self.vol._h, int(s_hat), self._ptr(self.cem), self._ptr(self.Cd),
+                                                      self._ptr(self.depth), self._ptr(self.rbar), C.byref(pc)), "rslf_sweep_visit_finish")
+
+    def finish(self, ok: bool = True) -> None:
+        from ._lib import RslfStats
+        st = RslfStats()
+        self._check(self._L().rslf_sweep_end(self.vol.ctx._h, 1 if ok else 0, self.dim_d, C.byref(st)), "rslf_sweep_end")
+        self.stats = st
+
+    # -- the distributed driver --------------------------------------------------------------------------------------------
+    def exchange(self, s_hat: int) -> None:
+        """Send the own boundary rows to the neighbours, receive theirs into the halo rows (two planes, 2 x h rows)."""
+        top, bottom = self.boundary_rows(s_hat)
+        above, below = self.halo_slots(s_hat)
+        exchange_halo_rows(self.shard.rank, self.shard.world, top, bottom, above, below, self.group)
+
+    def run(self) -> None:
+        self.prepare()
+        try:
+            for s_hat in sweep_order(self.vol.S):
+                self.visit_scan(s_hat)
+                self.exchange(s_hat)
+                self.visit_finish(s_hat)
+        except Exception:
+            self.finish(ok=False)
+            raise
+        self.finish()
+
+    def own_planes(self) -> Dict[str, torch.Tensor]:
+        o = self.own
+        return dict(edge_confidence=self.Ce[:, o], edge_mask=self.cem[:, o], disp_confidence=self.Cd[:, o], depth=self.depth[:, o],
+                    rbar=self.rbar[:, o], scan_mask=self.scan_mask[:, o])
+
+    # -- helpers -------------------------------------------------------------------------------------------------------------
+    @staticmethod
+    def _L():
+        from . import _lib
+        return _lib.lib()
+
+    @staticmethod
+    def _check(status, where):
+        from . import _lib
+        _lib.check(status, where)
+
+    @staticmethod
+    def _ptr(t):
+        return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def run_lockstep_sweep(shards: List["ShardedDepth2D"], exchange: bool = True) -> None:
+    """Several shards in ONE process, visit by visit, halo rows copied between them directly -- what the ranks do over
+    RCCL, without the transport (tests; a one-GPU box).  exchange=False leaves the halo rows stale: what the tests use to
+    show that the exchange is load-bearing."""
+    for sh in shards:
+        sh.prepare()
+    for s_hat in sweep_order(shards[0].vol.S):
+        for sh in shards:
+            sh.visit_scan(s_hat)
+        for i, sh in enumerate(shards if exchange else ()):
+            above, below = sh.halo_slots(s_hat)
+            if above is not None:
+                for dst, src in zip(above, shards[i - 1].boundary_rows(s_hat)[1]):
+                    dst.copy_(src)
+            if below is not None:
+                for dst, src in zip(below, shards[i + 1].boundary_rows(s_hat)[0]):
+                    dst.copy_(src)
+        for sh in shards:
+            sh.visit_finish(s_hat)
+    for sh in shards:
+        sh.finish()

@@ -161,3 +161,50 @@ def test_sharded_default_normalisation_uses_the_global_maximum(tmp_path, oracle_
         sharding.require_explicit_scale(-1.0, 2)
     sharding.require_explicit_scale(-1.0, 1)
     sharding.require_explicit_scale(255.0, 8)
+
+
+def _halo_worker(rank, world, port, h, U, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rows = 6
+        depth = torch.full((rows + 2 * h, U), float(rank), dtype=torch.float32)        # halo | own | halo, own rows tagged
+        mask = torch.full((rows + 2 * h, U), rank, dtype=torch.uint8)
+        depth[h:h + rows] += torch.arange(rows, dtype=torch.float32)[:, None] / 16.0
+        a, b = h, h + rows
+        top, bottom = (depth[a:a + h], mask[a:a + h]), (depth[b - h:b], mask[b - h:b])
+        above = (depth[a - h:a], mask[a - h:a]) if rank > 0 else None
+        below = (depth[b:b + h], mask[b:b + h]) if rank < world - 1 else None
+        sharding.exchange_halo_rows(rank, world, top, bottom, above, below)
+        np.savez(os.path.join(out_dir, "halo%d.npz" % rank), depth=depth.numpy(), mask=mask.numpy())
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_halo_row_exchange_between_neighbours(tmp_path, world):
+    """The per-visit exchange of the sharded 2-D sweep (ShardedDepth2D.exchange): every rank's halo rows end up holding
+    the neighbour's boundary rows, both planes, the field's outer halos untouched."""
+    h, U, rows = 2, 9, 6
+    mp.spawn(_halo_worker, args=(world, _free_port(), h, U, str(tmp_path)), nprocs=world, join=True)
+    got = [np.load(tmp_path / ("halo%d.npz" % r)) for r in range(world)]
+    for r in range(world):
+        d, m = got[r]["depth"], got[r]["mask"]
+        own = d[h:h + rows]
+        assert np.array_equal(own, r + np.arange(rows, dtype=np.float32)[:, None] / 16.0 + np.zeros((rows, U), np.float32))
+        if r > 0:
+            assert np.array_equal(d[:h], got[r - 1]["depth"][rows:rows + h]) and np.all(m[:h] == r - 1)
+        else:
+            assert np.all(d[:h] == 0.0) and np.all(m[:h] == 0)
+        if r < world - 1:
+            assert np.array_equal(d[h + rows:], got[r + 1]["depth"][h:2 * h]) and np.all(m[h + rows:] == r + 1)
+        else:
+            assert np.all(d[h + rows:] == r) and np.all(m[h + rows:] == r)
+
+
+def test_sweep_order_centre_outwards():
+    assert sharding.sweep_order(5) == [2, 3, 1, 4, 0]
+    assert sharding.sweep_order(1) == [0]
+    assert sharding.sweep_order(8) == [4, 5, 3, 6, 2, 7, 1]          # an even view count never visits view 0 (core.hpp:981-990)
