@@ -163,6 +163,22 @@ __global__ __launch_bounds__(256) void k1_edge_confidence(VolView vol, int s, Ed
     mask[o] = (ce > ec.edge_thr) ? 255 : 0;
 }
 
+// compute_2D_edge_confidence (core.hpp:918-934) in ONE launch: blockIdx.z is the view, planes are [S][V][U].
+template <int C>
+__global__ __launch_bounds__(256) void k1_edge_confidence_views(VolView vol, EdgeConsts ec, float* __restrict__ Ce_svu,
+                                                               uint8_t* __restrict__ mask_svu)
+{
+    const int s = blockIdx.z, v = blockIdx.y;
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= vol.U)
+        return;
+    const float* r0 = vol.row(v, s);
+    const long long o = ((long long)s * vol.V + v) * vol.U + u;
+    const float ce = edge_confidence_pixel<C>(vol, r0, u, ec, Ce_svu[o]);
+    Ce_svu[o] = ce;
+    mask_svu[o] = (ce > ec.edge_thr) ? 255 : 0;
+}
+
 // One pixel's edge confidence, shadow cut applied (core.hpp:449-474); `ce` is what the caller's plane held.
 template <int C>
 __device__ __forceinline__ float edge_confidence_pixel(const VolView& vol, const float* __restrict__ r0, int u, const EdgeConsts& ec,
@@ -332,11 +348,10 @@ __global__ __launch_bounds__(256) void k_compact_mask(const uint8_t* __restrict_
 // scan wavefront is full even when a scanline holds two or three pixels.  A block counts its row, claims
 // a range of the list with one atomic (rows land in arrival order; a pixel's result does not depend on
 // where in the list it sits), then writes the row's ascending u.  *packed_n must be 0 on entry.
-__global__ __launch_bounds__(256) void k_compact_mask_packed(const uint8_t* __restrict__ edge_mask, uint8_t* __restrict__ scan_mask,
-                                                            int U, int* __restrict__ list, int* __restrict__ count,
-                                                            unsigned long long* __restrict__ total, int* __restrict__ packed_n)
+__device__ __forceinline__ void compact_row_packed(int v, const uint8_t* __restrict__ edge_mask, uint8_t* scan_mask, int U,
+                                                   int* __restrict__ list, int* __restrict__ count,
+                                                   unsigned long long* __restrict__ total, int* __restrict__ packed_n)
 {
-    const int v = blockIdx.x;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     __shared__ int wave_tot[4];
     __shared__ int base_s;
@@ -386,6 +401,13 @@ __global__ __launch_bounds__(256) void k_compact_mask_packed(const uint8_t* __re
             base_s += wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
         __syncthreads();
     }
+}
+
+__global__ __launch_bounds__(256) void k_compact_mask_packed(const uint8_t* __restrict__ edge_mask, uint8_t* __restrict__ scan_mask,
+                                                            int U, int* __restrict__ list, int* __restrict__ count,
+                                                            unsigned long long* __restrict__ total, int* __restrict__ packed_n)
+{
+    compact_row_packed(blockIdx.x, edge_mask, scan_mask, U, list, count, total, packed_n);
 }
 
 }  // namespace rslf

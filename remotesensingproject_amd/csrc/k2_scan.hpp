@@ -947,28 +947,49 @@ __device__ __forceinline__ bool wave_is_interior(const ScanArgs& a, int u)
     return __all((uf - reach >= 0.0f) && (uf + reach <= (float)(a.vol.U - 1)));
 }
 
+// Whether a tile needs the validity test is decided per HYPOTHESIS, not once per tile: the reach of the sample lines is
+// max|s_hat - s| * |D[d]| * slope, and with 201 views and disparities up to 6 px/view (BASELINE.json configs[4]) the
+// all-hypotheses bound makes a third of a 4096-pixel row "border" where the per-hypothesis one leaves 15 %.  The border
+// form costs about twice the dense one in the re-gathered tail (two loads per sample instead of one shared tap).
+// Runs of hypotheses of the same kind go to one body call, in ascending order (first maximum wins, core.hpp:636-645).
 template <int C, int NRES>
 __device__ __forceinline__ void scan_stream_rows(const ScanArgs& a, int v, int u, int d0, int d1, Best<C>& best, float* otab)
 {
-    if (wave_is_interior(a, u)) {
-        // 63 consecutive pixels in lanes 0..62 (lane 63 is idle and shadows lane 62): lane 63 moves one pixel on --
-        // still inside the row for every sample, wave_is_interior leaves two pixels of margin -- and the tail
-        // shares taps between neighbours
-        // (every lane is compared, not just the ends: a short or gappy list can span 62 pixels too -- idle lanes shadow
-        // the last entry; found by the fuzz campaign, profiles/r02_fuzz_parity.txt)
-        const int u0 = __builtin_amdgcn_readfirstlane(u), u62 = __builtin_amdgcn_readlane(u, 62);
-        const int ln = threadIdx.x & 63;
-        const bool consecutive = __all(ln > 62 || u == u0 + ln);
-        if (a.tile_w == 63 && consecutive && NRES + a.stream_park < a.vol.S) {
-            const int ud = ((threadIdx.x & 63) == 63) ? u62 + 1 : u;
-            scan_stream_body<C, false, true, NRES, true>(a, v, ud, d0, d1, best, otab);
-        } else {
-            scan_stream_body<C, false, true, NRES>(a, v, u, d0, d1, best, otab);
-        }
-    } else if (!a.dmin_vu)
-        scan_stream_body<C, true, true, NRES>(a, v, u, d0, d1, best, otab);
-    else
+    if (a.dmin_vu) {
         scan_stream_body<C, true, false, NRES>(a, v, u, d0, d1, best, otab);
+        return;
+    }
+    // 63 consecutive pixels in lanes 0..62 (lane 63 is idle and shadows lane 62): lane 63 moves one pixel on -- still
+    // inside the row for every sample of an interior hypothesis, which leaves two pixels of margin -- and the tail
+    // shares taps between neighbours
+    // (every lane is compared, not just the ends: a short or gappy list can span 62 pixels too -- idle lanes shadow
+    // the last entry; found by the fuzz campaign, profiles/r02_fuzz_parity.txt)
+    const int u0 = __builtin_amdgcn_readfirstlane(u), u62 = __builtin_amdgcn_readlane(u, 62);
+    const int ln = threadIdx.x & 63;
+    const bool consecutive = __all(ln > 62 || u == u0 + ln);
+    const bool dense = a.tile_w == 63 && consecutive && NRES + a.stream_park < a.vol.S;
+    const int ud = (ln == 63) ? u62 + 1 : u;
+    const float max_ds = (float)max(a.s_hat, a.vol.S - 1 - a.s_hat);
+    const float range = a.dmax - a.dmin, denom = (float)(a.dim_d - 1);
+    const float uf = (float)u, Um1 = (float)(a.vol.U - 1);
+    auto interior = [&](int d) -> bool {   // |x - u| <= max|s_hat - s| * |D[d]| * slope for every sample of hypothesis d
+        const float reach = max_ds * fabsf(hypothesis(a.dmin, range, denom, d)) * fabsf(a.k.slope) + 2.0f;
+        return __all((uf - reach >= 0.0f) && (uf + reach <= Um1));
+    };
+    int d = d0;
+    while (d < d1) {
+        const bool in = interior(d);
+        int e = d + 1;
+        while (e < d1 && interior(e) == in)
+            e++;
+        if (!in)
+            scan_stream_body<C, true, true, NRES>(a, v, u, d, e, best, otab);
+        else if (dense)
+            scan_stream_body<C, false, true, NRES, true>(a, v, ud, d, e, best, otab);
+        else
+            scan_stream_body<C, false, true, NRES>(a, v, u, d, e, best, otab);
+        d = e;
+    }
 }
 
 template <int C>

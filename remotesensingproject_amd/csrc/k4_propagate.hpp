@@ -13,6 +13,7 @@
 // Both passes are HBM-bound streaming kernels (a few bytes per (s, v, u)).
 #pragma once
 
+#include "k1_edge.hpp"
 #include "k3_median.hpp"
 #include "rslf_device.hpp"
 
@@ -82,8 +83,12 @@ __global__ __launch_bounds__(256) void k34_median_claim(VolView vol, int s_hat, 
                                                        int size, float eps, const float* __restrict__ rbar_vu,
                                                        const uint8_t* __restrict__ mask_svu, int* __restrict__ winner_svu,
                                                        float slope, float prop_eps, const float* __restrict__ gate_Cd_vu,
-                                                       float disp_thr)
+                                                       float disp_thr, int* __restrict__ reset)
 {
+    // `reset`: the packed list's length, which the scan before this launch was the last to read and the apply pass after
+    // it counts up again from 0
+    if (reset && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
+        *reset = 0;
     extern __shared__ __attribute__((aligned(16))) float s_median_cand[];   // [size*size][256]
     float (*cand)[256] = reinterpret_cast<float (*)[256]>(s_median_cand);
     const int v = blockIdx.y;
@@ -99,29 +104,48 @@ __global__ __launch_bounds__(256) void k34_median_claim(VolView vol, int s_hat, 
     propagate_claim_pixel<C>(vol, s_hat, v, u, cur, rbar_vu, mask_svu, winner_svu, slope, prop_eps);
 }
 
-// `reset` (nullable): an int zeroed by the kernel for the next visit -- the packed list's length, which the next
-// visit's compaction expects at 0 (this is the last kernel of a visit and nothing after the scan reads it).
+// The apply pass of a visit (core.hpp:1119-1127) and, in the same launch, the pixel list of the NEXT visit's scan: one
+// workgroup per (view, scanline) row of the planes; the rows of view s_next come first and, once their claims are
+// applied (every write to a row's running mask comes from the row's own workgroup), compact that row of
+// edge_mask(s_next) & running mask(s_next) into the packed list exactly as k_compact_mask_packed would have -- one dense
+// pass and one launch fewer per visit.  *packed_n must be 0 on entry (k34_median_claim zeroes it: the scan before it
+// was its last reader).  s_next < 0: apply only.
 __global__ __launch_bounds__(256) void k4_propagate_apply(int S, int V, int U, int s_hat, const float* __restrict__ filtered_vu,
                                                          const float* __restrict__ Cd_hat_vu, float* __restrict__ depth_svu,
-                                                         float* __restrict__ Cd_svu, uint8_t* __restrict__ mask_svu,
-                                                         int* __restrict__ winner_svu, int* __restrict__ reset)
+                                                         float* __restrict__ Cd_svu, uint8_t* mask_svu, int* __restrict__ winner_svu,
+                                                         int s_next, const uint8_t* __restrict__ edge_mask_next_vu,
+                                                         int* __restrict__ list, int* __restrict__ count,
+                                                         unsigned long long* __restrict__ total, int* __restrict__ packed_n)
 {
-    if (reset && blockIdx.x == 0 && threadIdx.x == 0)
-        *reset = 0;
-    const long long plane = (long long)V * U;
-    const long long n = (long long)S * plane;
-    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
+    int b = blockIdx.x, s, v;
+    if (s_next >= 0 && b < V) {
+        s = s_next;
+        v = b;
+    } else {
+        if (s_next >= 0)
+            b -= V;
+        s = b / V;
+        v = b - s * V;
+        if (s_next >= 0 && s >= s_next)
+            s++;
+    }
+    const long long row = ((long long)s * V + v) * U;
+    const long long src_row = (long long)v * U;
+    for (int u = threadIdx.x; u < U; u += 256) {
+        const long long t = row + u;
         const int w = winner_svu[t];
         if (w >= U)
             continue;
-        const long long vu = t % plane;
-        const long long src = vu - (vu % U) + w;     // (v, w)
         // s == s_hat: w == u, both assignments are self-assignments (core.hpp:1119-1121)
-        depth_svu[t] = filtered_vu[src];
-        Cd_svu[t] = Cd_hat_vu[src];
+        depth_svu[t] = filtered_vu[src_row + w];
+        Cd_svu[t] = Cd_hat_vu[src_row + w];
         mask_svu[t] = 0;
         winner_svu[t] = kNoWinner;
     }
+    if (s != s_next)
+        return;
+    __syncthreads();   // this row's mask writes are the workgroup's own
+    compact_row_packed(v, edge_mask_next_vu, mask_svu + (long long)s_next * V * U, U, list, count, total, packed_n);
 }
 
 }  // namespace rslf

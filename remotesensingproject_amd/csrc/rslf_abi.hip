@@ -88,7 +88,9 @@ struct rslf_ctx {
     int* scan_ticket = nullptr;        // [tile] of the same launches: which group merges the tile (zero between launches)
     size_t ticket_cap = 0;
     bool packed_n_clean = false;       // the packed list's length is already 0 (the sweep's apply pass resets it)
-    bool precompacted = false;         // the next scan's pixel lists and total are already in place (K1 + compaction in one launch)
+    int precompacted = 0;              // the next scan's pixel lists and total are already in place: 1 = per-row lists (K1 +
+                                       // compaction in one launch), 2 = the packed list (a sweep's apply pass made it)
+    int sweep_expect = -1;             // the view the sweep visits next (core.hpp:981-990), -1 once all are done
     bool sweep_open = false;           // between rslf_sweep_begin and rslf_sweep_end
     bool sweep_first = true;           // the next visit is the sweep's first (dense) one
     uint8_t* sweep_mask_run = nullptr; // the running masks [S][V][U] of the open sweep
@@ -914,8 +916,8 @@ extern "C" int rslf_depth_epi_scan(rslf_ctx* ctx, const rslf_volume* vol, const 
         HIP_TRY(hipMemsetAsync(d_idx_vu, 0xFF, n * sizeof(int32_t), st));   // -1
     if (d_score_vu)
         HIP_TRY(hipMemsetAsync(d_score_vu, 0, n * sizeof(float), st));
-    const bool precompacted = ctx->precompacted;   // rslf_depth1d_pile_run: K1 already left the lists and the total
-    ctx->precompacted = false;
+    const int precompacted = ctx->precompacted;   // 1: rslf_depth1d_pile_run's K1 left row lists and total; 2: packed list (sweep)
+    ctx->precompacted = 0;
     if (!ctx->keep_total && !precompacted)
         HIP_TRY(hipMemsetAsync(ctx->total, 0, sizeof(unsigned long long), st));
 
@@ -951,12 +953,14 @@ extern "C" int rslf_depth_epi_scan(rslf_ctx* ctx, const rslf_volume* vol, const 
         packed = ctx->force_packed != 0;
     while (groups > 1 && dim_d < 2 * kScanWaves * groups)   // enough hypotheses to share out?
         groups /= 2;
-    if (n > (size_t)INT32_MAX || precompacted)
+    if (n > (size_t)INT32_MAX || precompacted == 1)
         packed = false;   // entry counts are ints; precompacted: the row lists are what K1 wrote
+    if (precompacted == 2)
+        packed = true;    // the previous visit's apply pass left the packed list and its length
 
     int* packed_n = reinterpret_cast<int*>(ctx->total + 1);
     if (precompacted) {
-        packed = false;   // row lists are what K1 wrote
+        // nothing to compact
     } else if (packed) {
         if (!ctx->packed_n_clean)
             HIP_TRY(hipMemsetAsync(packed_n, 0, sizeof(int), st));
@@ -1229,7 +1233,7 @@ extern "C" int rslf_depth1d_pile_run(rslf_ctx* ctx, const rslf_volume* vol, floa
             hipLaunchKernelGGL(k1_edge_confidence_compact<3>, dim3(vol->V), dim3(256), 0, st, view_of(vol), s_hat, ec, d_Ce_vu,
                                d_Ce_mask_vu, ctx->list, ctx->count, ctx->total);
         HIP_TRY(hipGetLastError());
-        ctx->precompacted = true;
+        ctx->precompacted = 1;
     } else {
         rc = rslf_edge_confidence_pile(ctx, vol, s_hat, p, d_Ce_vu, d_Ce_mask_vu);   // dc.hpp:538
         if (rc)
@@ -1237,7 +1241,7 @@ extern "C" int rslf_depth1d_pile_run(rslf_ctx* ctx, const rslf_volume* vol, floa
     }
     rc = rslf_depth_epi_pile(ctx, vol, nullptr, nullptr, dmin, dmax, dim_d, s_hat, d_Ce_vu, d_Ce_mask_vu, d_Cd_vu,   // dc.hpp:547
                              d_depth_vu, d_rbar_vu, p, nullptr, d_idx_vu, d_score_vu, d_depth_raw_vu, stats);
-    ctx->precompacted = false;
+    ctx->precompacted = 0;
     return rc;
 }
 
@@ -1329,6 +1333,26 @@ extern "C" int rslf_edge_confidence_2d(rslf_ctx* ctx, const rslf_volume* vol, co
     if (!ctx || !vol || !d_Ce_svu || !d_Ce_mask_svu)
         return fail(RSLF_ERR_INVALID_ARG, "NULL argument");
     const size_t n = (size_t)vol->V * vol->U;
+    if (p && p->edge_confidence_opening_size <= 1 && vol->S <= 65535 && vol->V <= 65535) {   // every view in one launch
+        int rc = check_params(p);
+        if (rc)
+            return rc;
+        if (!vol->filled)
+            return fail(RSLF_ERR_INVALID_ARG, "volume has not been filled");
+        HIP_TRY(hipSetDevice(ctx->device));
+        EdgeConsts ec;
+        ec.filter_size = p->edge_confidence_filter_size;
+        ec.cut_shadows = p->cut_shadows;
+        ec.shadow_level = p->shadow_level;
+        ec.edge_thr = p->edge_score_threshold;
+        const dim3 grid((vol->U + 255) / 256, vol->V, vol->S);
+        if (vol->C == 1)
+            hipLaunchKernelGGL(k1_edge_confidence_views<1>, grid, dim3(256), 0, ctx->stream, view_of(vol), ec, d_Ce_svu, d_Ce_mask_svu);
+        else
+            hipLaunchKernelGGL(k1_edge_confidence_views<3>, grid, dim3(256), 0, ctx->stream, view_of(vol), ec, d_Ce_svu, d_Ce_mask_svu);
+        HIP_TRY(hipGetLastError());
+        return RSLF_OK;
+    }
     for (int s = 0; s < vol->S; s++) {   // core.hpp:918-934
         int rc = rslf_edge_confidence_pile(ctx, vol, s, p, d_Ce_svu + (size_t)s * n, d_Ce_mask_svu + (size_t)s * n);
         if (rc)
@@ -1369,12 +1393,37 @@ static int ensure_sweep_scratch(rslf_ctx* ctx, const rslf_volume* vol)
 // The sweep one visit at a time (rslf_sweep_*), and rslf_depth_epi_2d on top of it.  The launch shape of the visits
 // (hypothesis groups, packed tiles, running total) is context state the scan reads: rslf_sweep_end restores it, and after
 // an error the winners are refilled on the next sweep (a claim pass whose apply never ran leaves them set).
+// core.hpp:981-990: the centre view, then outwards, alternating (an even view count never reaches view 0)
+static std::vector<int> sweep_order(int S)
+{
+    std::vector<int> order;
+    const int s_mid = (int)std::floor(S / 2.0);
+    order.push_back(s_mid);
+    for (int off = 1; off < S - s_mid; off++) {
+        order.push_back(s_mid + off);
+        if (s_mid - off > -1)
+            order.push_back(s_mid - off);
+    }
+    return order;
+}
+
+static int sweep_view_after(int S, int s_hat)
+{
+    const std::vector<int> order = sweep_order(S);
+    for (size_t i = 0; i + 1 < order.size(); i++)
+        if (order[i] == s_hat)
+            return order[i + 1];
+    return -1;
+}
+
 static void sweep_close(rslf_ctx* ctx, bool ok)
 {
     ctx->keep_total = false;
     ctx->scan_groups = 1;
     ctx->scan_packed = false;
     ctx->packed_n_clean = false;
+    ctx->precompacted = 0;
+    ctx->sweep_expect = -1;
     if (!ok)
         ctx->sweep_cap = 0;
     ctx->sweep_open = false;
@@ -1421,6 +1470,8 @@ extern "C" int rslf_sweep_begin(rslf_ctx* ctx, const rslf_volume* vol, const uin
     ctx->sweep_open = true;
     ctx->sweep_first = true;
     ctx->sweep_mask_run = mask_svu;
+    ctx->sweep_expect = sweep_order(S)[0];
+    ctx->precompacted = 0;
     return RSLF_OK;
 }
 
@@ -1436,6 +1487,8 @@ extern "C" int rslf_sweep_visit_scan(rslf_ctx* ctx, const rslf_volume* vol, cons
         return fail(RSLF_ERR_INVALID_ARG, "d_dmin_svu and d_dmax_svu must both be given or both be NULL");
     if (s_hat < 0 || s_hat >= vol->S)
         return fail(RSLF_ERR_INVALID_ARG, "s_hat=%d outside [0,%d)", s_hat, vol->S);
+    if (s_hat != ctx->sweep_expect)   // the previous visit has already listed this view's pixels (k4_propagate_apply)
+        return fail(RSLF_ERR_INVALID_ARG, "the sweep visits view %d next (core.hpp:981-990), not %d", ctx->sweep_expect, s_hat);
     const size_t n = (size_t)vol->V * vol->U;
     // After the centre view, propagation has explained most pixels: a visit scans a few per scanline.
     // Pack them into one list and share each tile's hypotheses out over up to 16 workgroups (k2_scan.hpp).
@@ -1459,8 +1512,8 @@ extern "C" int rslf_sweep_visit_finish(rslf_ctx* ctx, const rslf_volume* vol, in
         return fail(RSLF_ERR_INVALID_ARG, "NULL argument");
     if (!ctx->sweep_open)
         return fail(RSLF_ERR_INVALID_ARG, "rslf_sweep_visit_finish without rslf_sweep_begin");
-    if (s_hat < 0 || s_hat >= vol->S)
-        return fail(RSLF_ERR_INVALID_ARG, "s_hat=%d outside [0,%d)", s_hat, vol->S);
+    if (s_hat != ctx->sweep_expect)
+        return fail(RSLF_ERR_INVALID_ARG, "rslf_sweep_visit_finish(%d): the open visit is view %d", s_hat, ctx->sweep_expect);
     if (p->median_filter_size < 1 || (p->median_filter_size & 1) == 0 || p->median_filter_size > kMedianMaxSize)
         return fail(RSLF_ERR_UNSUPPORTED, "median size must be odd and <= %d", kMedianMaxSize);
     HIP_TRY(hipSetDevice(ctx->device));
@@ -1469,7 +1522,8 @@ extern "C" int rslf_sweep_visit_finish(rslf_ctx* ctx, const rslf_volume* vol, in
     hipStream_t st = ctx->stream;
     uint8_t* mask_svu = ctx->sweep_mask_run;
     const dim3 grid_vu((U + 255) / 256, V);
-    const unsigned apply_blocks = (unsigned)std::min<size_t>(((size_t)S * n + 255) / 256, 256 * 8 * 4);
+    if ((long long)S * V > (1ll << 31) - 1)
+        return fail(RSLF_ERR_UNSUPPORTED, "%d views x %d scanlines: too many rows for one apply launch", S, V);
     const size_t median_lds = (size_t)p->median_filter_size * p->median_filter_size * 256 * sizeof(float);
     int* packed_n = reinterpret_cast<int*>(ctx->total + 1);
     float* depth = d_depth_svu + (size_t)s_hat * n;
@@ -1477,21 +1531,29 @@ extern "C" int rslf_sweep_visit_finish(rslf_ctx* ctx, const rslf_volume* vol, in
     float* rbar = d_rbar_svu + (size_t)s_hat * n * C;
     uint8_t* cem = d_Ce_mask_svu + (size_t)s_hat * n;
     // core.hpp:881-892 (selective median over the edge mask) and :1088-1129 (propagation) -- the median and the
-    // claims of a pixel in one launch (k34_median_claim), then the apply pass; a visit is four launches:
-    // compaction, scan (its groups merge their records themselves), median + claims, apply
+    // claims of a pixel in one launch (k34_median_claim), then the apply pass, which also lists the pixels the NEXT
+    // visit scans; a visit is three launches: scan (its groups merge their records themselves), median + claims,
+    // apply + compaction
+    int s_next = sweep_view_after(S, s_hat);
+    const int s_after = s_next;
+    if (ctx->force_packed == 0 || n > (size_t)INT32_MAX)
+        s_next = -1;   // that scan will not take a packed list: it compacts for itself
     if (C == 1)
         hipLaunchKernelGGL(k34_median_claim<1>, grid_vu, dim3(256), median_lds, st, view_of(vol), s_hat, depth, ctx->filtered, cem,
                            p->median_filter_size, p->median_filter_epsilon, rbar, mask_svu, ctx->winner, p->slope_factor,
-                           p->propagation_epsilon, p->use_disp_confidence_score ? Cd : nullptr, p->disp_score_threshold);
+                           p->propagation_epsilon, p->use_disp_confidence_score ? Cd : nullptr, p->disp_score_threshold, packed_n);
     else
         hipLaunchKernelGGL(k34_median_claim<3>, grid_vu, dim3(256), median_lds, st, view_of(vol), s_hat, depth, ctx->filtered, cem,
                            p->median_filter_size, p->median_filter_epsilon, rbar, mask_svu, ctx->winner, p->slope_factor,
-                           p->propagation_epsilon, p->use_disp_confidence_score ? Cd : nullptr, p->disp_score_threshold);
+                           p->propagation_epsilon, p->use_disp_confidence_score ? Cd : nullptr, p->disp_score_threshold, packed_n);
     HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(k4_propagate_apply, dim3(apply_blocks), dim3(256), 0, st, S, V, U, s_hat, ctx->filtered, Cd, d_depth_svu,
-                       d_Cd_svu, mask_svu, ctx->winner, packed_n);
+    hipLaunchKernelGGL(k4_propagate_apply, dim3((unsigned)(S * V)), dim3(256), 0, st, S, V, U, s_hat, ctx->filtered, Cd, d_depth_svu,
+                       d_Cd_svu, mask_svu, ctx->winner, s_next, s_next >= 0 ? d_Ce_mask_svu + (size_t)s_next * n : nullptr, ctx->list,
+                       ctx->count, ctx->total, packed_n);
     HIP_TRY(hipGetLastError());
-    ctx->packed_n_clean = true;   // the apply pass has queued the reset the next visit's compaction needs
+    ctx->packed_n_clean = s_next < 0;       // k34_median_claim zeroed the packed list's length; a listing apply pass set it again
+    ctx->precompacted = s_next >= 0 ? 2 : 0;
+    ctx->sweep_expect = s_after;
     ctx->sweep_first = false;
     return RSLF_OK;
 }
@@ -1528,16 +1590,7 @@ extern "C" int rslf_depth_epi_2d(rslf_ctx* ctx, const rslf_volume* vol, const fl
     rc = rslf_sweep_begin(ctx, vol, d_Ce_mask_svu, d_scan_mask_svu, dim_d, 0, vol->V);
     if (rc)
         return rc;
-    const int S = vol->S;
-    std::vector<int> order;   // core.hpp:981-990
-    const int s_mid = (int)std::floor(S / 2.0);
-    order.push_back(s_mid);
-    for (int off = 1; off < S - s_mid; off++) {
-        order.push_back(s_mid + off);
-        if (s_mid - off > -1)
-            order.push_back(s_mid - off);
-    }
-    for (int s_hat : order) {
+    for (int s_hat : sweep_order(vol->S)) {   // core.hpp:981-990
         rc = rslf_sweep_visit_scan(ctx, vol, d_dmin_svu, d_dmax_svu, dmin, dmax, dim_d, s_hat, d_Ce_svu, d_Ce_mask_svu, d_Cd_svu,
                                    d_depth_svu, d_rbar_svu, p);
         if (!rc)
