@@ -385,7 +385,9 @@ int rslf_fine_to_coarse_run_host(rslf_ctx* ctx, const void* const* h_epis, int i
 /* ---- measurement ------------------------------------------------------ */
 /* Duration in milliseconds of the last scan-kernel launch (K2) of this
  * context, from HIP events recorded on the context's stream around that
- * launch.  Blocks until the launch has finished. */
+ * launch.  Blocks until the launch has finished.  Within a 2-D sweep only
+ * the first (dense, centre-view) visit is timed: an event is a packet of
+ * its own in the queue, and two per sparse visit cost a tenth of the visit. */
 int rslf_last_scan_kernel_ms(rslf_ctx* ctx, float* ms);
 
 #ifdef __cplusplus

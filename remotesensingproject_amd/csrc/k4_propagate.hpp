@@ -33,24 +33,46 @@ __device__ __forceinline__ void propagate_claim_pixel(const VolView& vol, int s_
     for (int c = 0; c < C; c++)
         rb[c] = rbar_vu[o * C + c];
     const long long plane = (long long)vol.V * vol.U;
-    for (int s = 0; s < vol.S; s++) {
-        // core.hpp:1109: u + (int)std::round(depth * (s_hat - s) * slope_factor)
-        float off = cur * (float)(s_hat - s);
-        off = off * slope;
-        const int ri = u + (int)roundf(off);
-        if (ri < 0 || ri >= vol.U)
-            continue;
-        const long long t = (long long)s * plane + (long long)v * vol.U + ri;
-        if (!mask_svu[t])
-            continue;
-        const float* e = vol.row(v, s);
-        float df[C];
+    const long long row = (long long)v * vol.U;
+    // eight views at a time: their running-mask bytes, then the radiances of those still unpainted, are loaded together
+    // before the first test -- the claims do not depend on one another (atomicMin), only the loads' latency did add up
+    constexpr int B = 8;
+    for (int s0 = 0; s0 < vol.S; s0 += B) {
+        int ri[B];
+        bool live[B];
 #pragma unroll
-        for (int c = 0; c < C; c++)
-            df[c] = e[ri * C + c] - rb[c];
-        const float nr = (C == 1) ? norm1(df[0]) : norm3(df[0], df[C > 1 ? 1 : 0], df[C > 2 ? 2 : 0]);
-        if (nr < prop_eps)   // core.hpp:1116
-            atomicMin(&winner_svu[t], u);
+        for (int j = 0; j < B; j++) {
+            const int s = s0 + j;
+            // core.hpp:1109: u + (int)std::round(depth * (s_hat - s) * slope_factor)
+            float off = cur * (float)(s_hat - s);
+            off = off * slope;
+            ri[j] = u + (int)roundf(off);
+            live[j] = s < vol.S && ri[j] >= 0 && ri[j] < vol.U;
+            if (live[j])
+                live[j] = mask_svu[(long long)s * plane + row + ri[j]] != 0;
+        }
+        float e[B][C];
+#pragma unroll
+        for (int j = 0; j < B; j++) {
+            if (live[j]) {
+                const float* er = vol.row(v, s0 + j);
+#pragma unroll
+                for (int c = 0; c < C; c++)
+                    e[j][c] = er[ri[j] * C + c];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < B; j++) {
+            if (!live[j])
+                continue;
+            float df[C];
+#pragma unroll
+            for (int c = 0; c < C; c++)
+                df[c] = e[j][c] - rb[c];
+            const float nr = (C == 1) ? norm1(df[0]) : norm3(df[0], df[C > 1 ? 1 : 0], df[C > 2 ? 2 : 0]);
+            if (nr < prop_eps)   // core.hpp:1116
+                atomicMin(&winner_svu[(long long)(s0 + j) * plane + row + ri[j]], u);
+        }
     }
 }
 
@@ -97,8 +119,15 @@ __global__ __launch_bounds__(256) void k34_median_claim(VolView vol, int s_hat, 
         return;
     const long long o = (long long)v * vol.U + u;
     // core.hpp:678-679, :881-892: the median over the edge mask, 0 elsewhere
-    const float cur = edge_mask_vu[o] ? selective_median_pixel<C>(vol, raw_vu, edge_mask_vu, s_hat, size, eps, v, u, cand) : 0.0f;
+#ifdef RSLF_PROBE_NO_MEDIAN
+    const float cur = raw_vu[o];
+#else
+    const float cur = edge_mask_vu[o] ? selective_median_any<C>(vol, raw_vu, edge_mask_vu, s_hat, size, eps, v, u, cand) : 0.0f;
+#endif
     filtered_vu[o] = cur;
+#ifdef RSLF_PROBE_NO_CLAIM
+    return;
+#endif
     if (gate_Cd_vu ? !(gate_Cd_vu[o] > disp_thr) : !edge_mask_vu[o])   // core.hpp:1097-1103
         return;
     propagate_claim_pixel<C>(vol, s_hat, v, u, cur, rbar_vu, mask_svu, winner_svu, slope, prop_eps);

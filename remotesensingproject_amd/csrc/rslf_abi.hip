@@ -47,10 +47,11 @@ static int fail(int code, const char* fmt, ...)
 // Streaming scan kernel: two workgroups per CU (two waves per SIMD) share the CU's 160 KiB of LDS; each has
 // 8 KiB of static LDS (the merge of the four waves' results), so 72 KiB of dynamic LDS per workgroup.
 static constexpr size_t kStreamLdsBytes = (size_t)72 << 10;
+constexpr int kSweepGroups = 16;    // workgroups sharing a packed tile's hypotheses on a sweep's sparse visits
 // Dense launches of the streaming kernel: this many workgroups share one tile's hypotheses.  The workgroups an
 // XCD runs together then sit on two or three tiles instead of a whole scanline, and what they gather from
 // stays inside the XCD's 4 MiB L2 (k2_scan.hpp)
-static constexpr int kStreamGroups = 16;
+constexpr int kStreamGroups = 16;
 static constexpr size_t kPartialBudget = (size_t)256 << 20;   // bytes of (tile, group, lane) records per grouped scan launch
 
 struct rslf_ctx {
@@ -951,12 +952,13 @@ extern "C" int rslf_depth_epi_scan(rslf_ctx* ctx, const rslf_volume* vol, const 
         groups = std::min(64, ctx->force_groups);
     if (ctx->force_packed >= 0)
         packed = ctx->force_packed != 0;
-    while (groups > 1 && dim_d < 2 * kScanWaves * groups)   // enough hypotheses to share out?
-        groups /= 2;
     if (n > (size_t)INT32_MAX || precompacted == 1)
         packed = false;   // entry counts are ints; precompacted: the row lists are what K1 wrote
     if (precompacted == 2)
         packed = true;    // the previous visit's apply pass left the packed list and its length
+    // enough hypotheses to share out?  (One per wave instead of two on the sweep's sparse launches measured slower.)
+    while (groups > 1 && dim_d < 2 * kScanWaves * groups)
+        groups /= 2;
 
     int* packed_n = reinterpret_cast<int*>(ctx->total + 1);
     if (precompacted) {
@@ -1062,7 +1064,12 @@ extern "C" int rslf_depth_epi_scan(rslf_ctx* ctx, const rslf_volume* vol, const 
     HIP_TRY(hipGetLastError());   // anything an earlier enqueue left behind is not this launch's fault
     ctx->last_spad = spad;
     ctx->last_kernel = spad ? RSLF_SCAN_REG : (stream_ok ? RSLF_SCAN_STREAM : RSLF_SCAN_GENERIC);
-    HIP_TRY(hipEventRecord(ctx->ev0, st));
+    // The events that time K2 are marker packets of their own: ~5.6 us each before the next kernel starts (measured,
+    // tools/probe_gaps.py) -- nothing beside a 66 ms scan, a tenth of a sweep's sparse visit.  A sweep times its first
+    // (dense) visit only.
+    const bool timed = !ctx->sweep_open || ctx->sweep_first;
+    if (timed)
+        HIP_TRY(hipEventRecord(ctx->ev0, st));
     for (int v0 = 0; v0 < vol->V; v0 += rows_per_launch) {
         const int rows = std::min(rows_per_launch, vol->V - v0);
         // row tiles: ceil(U/64) per scanline; packed tiles: at most ceil(V*U/64), the device knows how many
@@ -1092,8 +1099,10 @@ extern "C" int rslf_depth_epi_scan(rslf_ctx* ctx, const rslf_volume* vol, const 
         if (packed)
             break;   // one launch covers the packed list
     }
-    HIP_TRY(hipEventRecord(ctx->ev1, st));
-    ctx->ev_valid = true;
+    if (timed) {
+        HIP_TRY(hipEventRecord(ctx->ev1, st));
+        ctx->ev_valid = true;
+    }
 
     if (stats) {
         unsigned long long tot = 0;
@@ -1455,7 +1464,7 @@ extern "C" int rslf_sweep_begin(rslf_ctx* ctx, const rslf_volume* vol, const uin
         HIP_TRY(hipMemset2DAsync(mask_svu + (size_t)v_hi * U, n, 0, (size_t)(V - v_hi) * U, S, st));
     HIP_TRY(hipMemsetAsync(ctx->total, 0, sizeof(unsigned long long), st));
     {   // the sparse visits' records, sized before the first visit (no allocation in the middle of the sequence)
-        int g = 16;
+        int g = kSweepGroups;
         while (g > 1 && dim_d < 2 * kScanWaves * g)
             g /= 2;
         while (g > 1 && ((n + 63) / 64) * g * 64 * sizeof(Partial) > kPartialBudget)
@@ -1491,8 +1500,8 @@ extern "C" int rslf_sweep_visit_scan(rslf_ctx* ctx, const rslf_volume* vol, cons
         return fail(RSLF_ERR_INVALID_ARG, "the sweep visits view %d next (core.hpp:981-990), not %d", ctx->sweep_expect, s_hat);
     const size_t n = (size_t)vol->V * vol->U;
     // After the centre view, propagation has explained most pixels: a visit scans a few per scanline.
-    // Pack them into one list and share each tile's hypotheses out over up to 16 workgroups (k2_scan.hpp).
-    ctx->scan_groups = ctx->sweep_first ? 1 : 16;
+    // Pack them into one list and share each tile's hypotheses out over up to kSweepGroups workgroups (k2_scan.hpp).
+    ctx->scan_groups = ctx->sweep_first ? 1 : kSweepGroups;
     ctx->scan_packed = !ctx->sweep_first;
     // core.hpp:1012-1028: the pile call is the scan of every EPI followed by the selective median.  In the
     // reference the stored plane keeps the RAW depths and only the local header is rebound to the median
