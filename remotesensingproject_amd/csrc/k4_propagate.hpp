@@ -25,8 +25,10 @@ constexpr int kNoWinner = 0x7F7F7F7F;   // what hipMemset(0x7F) leaves; >= any c
 template <int C>
 __device__ __forceinline__ void propagate_claim_pixel(const VolView& vol, int s_hat, int v, int u, float cur,
                                                       const float* __restrict__ rbar_vu, const uint8_t* __restrict__ mask_svu,
-                                                      int* __restrict__ winner_svu, float slope, float prop_eps)
+                                                      int* __restrict__ winner_svu, uint8_t* __restrict__ dirty, float slope,
+                                                      float prop_eps)
 {
+    const int nseg = (vol.U + 255) >> 8;
     const long long o = (long long)v * vol.U + u;
     float rb[C];
 #pragma unroll
@@ -70,30 +72,12 @@ __device__ __forceinline__ void propagate_claim_pixel(const VolView& vol, int s_
             for (int c = 0; c < C; c++)
                 df[c] = e[j][c] - rb[c];
             const float nr = (C == 1) ? norm1(df[0]) : norm3(df[0], df[C > 1 ? 1 : 0], df[C > 2 ? 2 : 0]);
-            if (nr < prop_eps)   // core.hpp:1116
+            if (nr < prop_eps) {   // core.hpp:1116
                 atomicMin(&winner_svu[(long long)(s0 + j) * plane + row + ri[j]], u);
+                dirty[((long long)(s0 + j) * vol.V + v) * nseg + (ri[j] >> 8)] = 1;   // this 256-column segment holds a claim
+            }
         }
     }
-}
-
-template <int C>
-__global__ __launch_bounds__(256) void k4_propagate_claim(VolView vol, int s_hat, const float* __restrict__ filtered_vu,
-                                                         const uint8_t* __restrict__ edge_mask_vu,
-                                                         const float* __restrict__ rbar_vu,
-                                                         const uint8_t* __restrict__ mask_svu, int* __restrict__ winner_svu,
-                                                         float slope, float prop_eps, const float* __restrict__ gate_Cd_vu,
-                                                         float disp_thr)
-{
-    const int v = blockIdx.y;
-    const int u = blockIdx.x * blockDim.x + threadIdx.x;
-    if (u >= vol.U)
-        return;
-    const long long o = (long long)v * vol.U + u;
-    // what lets a pixel paint: the edge mask (default build, core.hpp:1102) or, with the reference's
-    // _USE_DISP_CONFIDENCE_SCORE switch, C_d > par_disp_score_threshold (core.hpp:1097-1098)
-    if (gate_Cd_vu ? !(gate_Cd_vu[o] > disp_thr) : !edge_mask_vu[o])
-        return;
-    propagate_claim_pixel<C>(vol, s_hat, v, u, filtered_vu[o], rbar_vu, mask_svu, winner_svu, slope, prop_eps);
 }
 
 // K3 + claim in one launch (a sweep visit): a pixel's median needs its neighbours' RAW depths only (what the scan
@@ -104,8 +88,8 @@ __global__ __launch_bounds__(256) void k34_median_claim(VolView vol, int s_hat, 
                                                        float* __restrict__ filtered_vu, const uint8_t* __restrict__ edge_mask_vu,
                                                        int size, float eps, const float* __restrict__ rbar_vu,
                                                        const uint8_t* __restrict__ mask_svu, int* __restrict__ winner_svu,
-                                                       float slope, float prop_eps, const float* __restrict__ gate_Cd_vu,
-                                                       float disp_thr, int* __restrict__ reset)
+                                                       uint8_t* __restrict__ dirty, float slope, float prop_eps,
+                                                       const float* __restrict__ gate_Cd_vu, float disp_thr, int* __restrict__ reset)
 {
     // `reset`: the packed list's length, which the scan before this launch was the last to read and the apply pass after
     // it counts up again from 0
@@ -130,7 +114,7 @@ __global__ __launch_bounds__(256) void k34_median_claim(VolView vol, int s_hat, 
 #endif
     if (gate_Cd_vu ? !(gate_Cd_vu[o] > disp_thr) : !edge_mask_vu[o])   // core.hpp:1097-1103
         return;
-    propagate_claim_pixel<C>(vol, s_hat, v, u, cur, rbar_vu, mask_svu, winner_svu, slope, prop_eps);
+    propagate_claim_pixel<C>(vol, s_hat, v, u, cur, rbar_vu, mask_svu, winner_svu, dirty, slope, prop_eps);
 }
 
 // The apply pass of a visit (core.hpp:1119-1127) and, in the same launch, the pixel list of the NEXT visit's scan: one
@@ -139,42 +123,74 @@ __global__ __launch_bounds__(256) void k34_median_claim(VolView vol, int s_hat, 
 // edge_mask(s_next) & running mask(s_next) into the packed list exactly as k_compact_mask_packed would have -- one dense
 // pass and one launch fewer per visit.  *packed_n must be 0 on entry (k34_median_claim zeroes it: the scan before it
 // was its last reader).  s_next < 0: apply only.
+// `dirty` has one byte per 256-column segment of every row, set by the claims: after the first visits most segments hold
+// no claim, and the pass reads the flags (S*V*ceil(U/256) bytes) instead of the winners (4 bytes per cell of the volume).
+// One 256-column segment of row r = s*V + v of the planes.
+__device__ __forceinline__ void apply_segment(long long r, int seg, int V, int U, const float* __restrict__ filtered_vu,
+                                              const float* __restrict__ Cd_hat_vu, float* __restrict__ depth_svu,
+                                              float* __restrict__ Cd_svu, uint8_t* mask_svu, int* __restrict__ winner_svu)
+{
+    const int u = (seg << 8) + threadIdx.x;
+    if (u >= U)
+        return;
+    const long long t = r * U + u;
+    const int w = winner_svu[t];
+    if (w >= U)
+        return;
+    const long long src = (r % V) * U + w;     // (v, w)
+    // s == s_hat: w == u, both assignments are self-assignments (core.hpp:1119-1121)
+    depth_svu[t] = filtered_vu[src];
+    Cd_svu[t] = Cd_hat_vu[src];
+    mask_svu[t] = 0;
+    winner_svu[t] = kNoWinner;
+}
+
+constexpr int kApplyRowsPerBlock = 4;     // rows a workgroup of the general part takes (their flags: one load)
+constexpr int kApplyFlagSlots = 1024;     // >= kApplyRowsPerBlock * ceil(U / 256) for U <= 65536
+
 __global__ __launch_bounds__(256) void k4_propagate_apply(int S, int V, int U, int s_hat, const float* __restrict__ filtered_vu,
                                                          const float* __restrict__ Cd_hat_vu, float* __restrict__ depth_svu,
                                                          float* __restrict__ Cd_svu, uint8_t* mask_svu, int* __restrict__ winner_svu,
-                                                         int s_next, const uint8_t* __restrict__ edge_mask_next_vu,
+                                                         uint8_t* __restrict__ dirty, int s_next, const uint8_t* __restrict__ edge_mask_next_vu,
                                                          int* __restrict__ list, int* __restrict__ count,
                                                          unsigned long long* __restrict__ total, int* __restrict__ packed_n)
 {
-    int b = blockIdx.x, s, v;
-    if (s_next >= 0 && b < V) {
-        s = s_next;
-        v = b;
-    } else {
-        if (s_next >= 0)
-            b -= V;
-        s = b / V;
-        v = b - s * V;
-        if (s_next >= 0 && s >= s_next)
-            s++;
-    }
-    const long long row = ((long long)s * V + v) * U;
-    const long long src_row = (long long)v * U;
-    for (int u = threadIdx.x; u < U; u += 256) {
-        const long long t = row + u;
-        const int w = winner_svu[t];
-        if (w >= U)
-            continue;
-        // s == s_hat: w == u, both assignments are self-assignments (core.hpp:1119-1121)
-        depth_svu[t] = filtered_vu[src_row + w];
-        Cd_svu[t] = Cd_hat_vu[src_row + w];
-        mask_svu[t] = 0;
-        winner_svu[t] = kNoWinner;
-    }
-    if (s != s_next)
+    __shared__ uint8_t s_flags[kApplyFlagSlots];
+    const int nseg = (U + 255) >> 8;
+    const int lead = s_next >= 0 ? V : 0;       // workgroups [0, lead): the rows of view s_next, one each
+    if ((int)blockIdx.x < lead) {
+        const int v = blockIdx.x;
+        const long long r = (long long)s_next * V + v;
+        uint8_t* flags = dirty + r * nseg;
+        for (int seg = 0; seg < nseg; seg++)
+            if (flags[seg])   // the same byte for the whole workgroup
+                apply_segment(r, seg, V, U, filtered_vu, Cd_hat_vu, depth_svu, Cd_svu, mask_svu, winner_svu);
+        __syncthreads();      // every thread has read the flags, and this row's mask writes are the workgroup's own
+        if ((int)threadIdx.x < nseg)
+            flags[threadIdx.x] = 0;
+        compact_row_packed(v, edge_mask_next_vu, mask_svu + (long long)s_next * V * U, U, list, count, total, packed_n);
         return;
-    __syncthreads();   // this row's mask writes are the workgroup's own
-    compact_row_packed(v, edge_mask_next_vu, mask_svu + (long long)s_next * V * U, U, list, count, total, packed_n);
+    }
+    // every other row, kApplyRowsPerBlock at a time: one coalesced load of their flags, then only the segments that hold
+    // a claim are touched
+    const long long nrows = (long long)S * V;
+    const long long r0 = (long long)(blockIdx.x - lead) * kApplyRowsPerBlock;
+    const long long r1 = r0 + kApplyRowsPerBlock < nrows ? r0 + kApplyRowsPerBlock : nrows;
+    const int nfl = (int)(r1 - r0) * nseg;
+    for (int i = threadIdx.x; i < nfl; i += 256) {
+        const long long r = r0 + i / nseg;
+        uint8_t f = 0;
+        if ((int)(r / V) != s_next) {           // the lead workgroups own those rows and their flags
+            f = dirty[r0 * nseg + i];
+            if (f)
+                dirty[r0 * nseg + i] = 0;
+        }
+        s_flags[i] = f;
+    }
+    __syncthreads();
+    for (int i = 0; i < nfl; i++)
+        if (s_flags[i])
+            apply_segment(r0 + i / nseg, i % nseg, V, U, filtered_vu, Cd_hat_vu, depth_svu, Cd_svu, mask_svu, winner_svu);
 }
 
 }  // namespace rslf

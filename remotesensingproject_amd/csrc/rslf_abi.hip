@@ -97,6 +97,8 @@ struct rslf_ctx {
     uint8_t* sweep_mask_run = nullptr; // the running masks [S][V][U] of the open sweep
     // 2-D sweep scratch
     int* winner = nullptr;        // [S][V][U]
+    uint8_t* dirty = nullptr;     // [S][V][ceil(U/256)]: segments of the winner rows that hold a claim (all 0 between visits)
+    size_t dirty_cap = 0;
     uint8_t* sweep_mask = nullptr;
     float* filtered = nullptr;    // [V][U] median of the visited view, the propagation's source
     size_t sweep_cap = 0;         // entries winner / sweep_mask can hold (S*V*U)
@@ -324,6 +326,7 @@ extern "C" int rslf_ctx_destroy(rslf_ctx* ctx)
     for (int i = 0; i < rslf_ctx::kHelperSlots; i++)
         (void)hipFree(ctx->helper[i]);
     (void)hipFree(ctx->winner);
+    (void)hipFree(ctx->dirty);
     (void)hipFree(ctx->sweep_mask);
     (void)hipFree(ctx->filtered);
     if (ctx->ev0)
@@ -1388,6 +1391,15 @@ static int ensure_sweep_scratch(rslf_ctx* ctx, const rslf_volume* vol)
         // every claim pass is undone by its apply pass, so one fill lasts
         HIP_TRY(hipMemsetAsync(ctx->winner, 0x7F, n * sizeof(int), ctx->stream));
     }
+    const size_t flags = (size_t)vol->S * vol->V * ((vol->U + 255) / 256);
+    if (flags > ctx->dirty_cap) {
+        (void)hipFree(ctx->dirty);
+        ctx->dirty = nullptr;
+        ctx->dirty_cap = 0;
+        HIP_TRY(hipMalloc(&ctx->dirty, flags));
+        ctx->dirty_cap = flags;
+        HIP_TRY(hipMemsetAsync(ctx->dirty, 0, flags, ctx->stream));   // every apply pass leaves them at 0 again
+    }
     const size_t plane = (size_t)vol->V * vol->U;
     if (plane > ctx->sweep_plane_cap) {
         (void)hipFree(ctx->filtered);
@@ -1433,8 +1445,10 @@ static void sweep_close(rslf_ctx* ctx, bool ok)
     ctx->packed_n_clean = false;
     ctx->precompacted = 0;
     ctx->sweep_expect = -1;
-    if (!ok)
-        ctx->sweep_cap = 0;
+    if (!ok) {
+        ctx->sweep_cap = 0;   // claims without their apply pass may be left behind: fresh winners and flags next time
+        ctx->dirty_cap = 0;
+    }
     ctx->sweep_open = false;
 }
 
@@ -1531,8 +1545,8 @@ extern "C" int rslf_sweep_visit_finish(rslf_ctx* ctx, const rslf_volume* vol, in
     hipStream_t st = ctx->stream;
     uint8_t* mask_svu = ctx->sweep_mask_run;
     const dim3 grid_vu((U + 255) / 256, V);
-    if ((long long)S * V > (1ll << 31) - 1)
-        return fail(RSLF_ERR_UNSUPPORTED, "%d views x %d scanlines: too many rows for one apply launch", S, V);
+    if ((long long)S * V > (1ll << 31) - 1 || U > 65536)
+        return fail(RSLF_ERR_UNSUPPORTED, "%d views x %d scanlines x %d columns: too large for one apply launch", S, V, U);
     const size_t median_lds = (size_t)p->median_filter_size * p->median_filter_size * 256 * sizeof(float);
     int* packed_n = reinterpret_cast<int*>(ctx->total + 1);
     float* depth = d_depth_svu + (size_t)s_hat * n;
@@ -1549,15 +1563,16 @@ extern "C" int rslf_sweep_visit_finish(rslf_ctx* ctx, const rslf_volume* vol, in
         s_next = -1;   // that scan will not take a packed list: it compacts for itself
     if (C == 1)
         hipLaunchKernelGGL(k34_median_claim<1>, grid_vu, dim3(256), median_lds, st, view_of(vol), s_hat, depth, ctx->filtered, cem,
-                           p->median_filter_size, p->median_filter_epsilon, rbar, mask_svu, ctx->winner, p->slope_factor,
+                           p->median_filter_size, p->median_filter_epsilon, rbar, mask_svu, ctx->winner, ctx->dirty, p->slope_factor,
                            p->propagation_epsilon, p->use_disp_confidence_score ? Cd : nullptr, p->disp_score_threshold, packed_n);
     else
         hipLaunchKernelGGL(k34_median_claim<3>, grid_vu, dim3(256), median_lds, st, view_of(vol), s_hat, depth, ctx->filtered, cem,
-                           p->median_filter_size, p->median_filter_epsilon, rbar, mask_svu, ctx->winner, p->slope_factor,
+                           p->median_filter_size, p->median_filter_epsilon, rbar, mask_svu, ctx->winner, ctx->dirty, p->slope_factor,
                            p->propagation_epsilon, p->use_disp_confidence_score ? Cd : nullptr, p->disp_score_threshold, packed_n);
     HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(k4_propagate_apply, dim3((unsigned)(S * V)), dim3(256), 0, st, S, V, U, s_hat, ctx->filtered, Cd, d_depth_svu,
-                       d_Cd_svu, mask_svu, ctx->winner, s_next, s_next >= 0 ? d_Ce_mask_svu + (size_t)s_next * n : nullptr, ctx->list,
+    const unsigned apply_blocks = (unsigned)((s_next >= 0 ? V : 0) + ((long long)S * V + kApplyRowsPerBlock - 1) / kApplyRowsPerBlock);
+    hipLaunchKernelGGL(k4_propagate_apply, dim3(apply_blocks), dim3(256), 0, st, S, V, U, s_hat, ctx->filtered, Cd, d_depth_svu,
+                       d_Cd_svu, mask_svu, ctx->winner, ctx->dirty, s_next, s_next >= 0 ? d_Ce_mask_svu + (size_t)s_next * n : nullptr, ctx->list,
                        ctx->count, ctx->total, packed_n);
     HIP_TRY(hipGetLastError());
     ctx->packed_n_clean = s_next < 0;       // k34_median_claim zeroed the packed list's length; a listing apply pass set it again
