@@ -290,11 +290,15 @@ class ShardedDepth2D:
     synchronisation); the steps are public so that a lock-step harness can drive several shards in one process
     (tests/test_gpu_sweep2d.py)."""
 
-    def __init__(self, vol, shard: Shard, dmin: float, dmax: float, dim_d: int, parameters=None, group=None):
+    def __init__(self, vol, shard: Shard, dmin, dmax, dim_d: int, parameters=None, group=None):
+        """dmin / dmax: floats, or [S, rows, U] f32 planes over the volume's rows (a fine-to-coarse level's tightened
+        per-pixel ranges, dc.hpp:201-203)."""
         from . import depth as rs
         self.rs, self.vol, self.shard, self.group = rs, vol, shard, group
+        self.bounds = (dmin, dmax) if isinstance(dmin, torch.Tensor) else None
         self.p = parameters or rs.Depth1DParameters()
-        self.dmin, self.dmax, self.dim_d = float(dmin), float(dmax), int(dim_d)
+        self.dmin, self.dmax = (0.0, 0.0) if self.bounds else (float(dmin), float(dmax))
+        self.dim_d = int(dim_d)
         self.h = (int(self.p.par_median_filter_size) - 1) // 2          # rows the median reads either side
         self.own = shard.interior                                         # own rows in the local frame
         if vol.V != shard.hi - shard.lo:
@@ -324,7 +328,8 @@ class ShardedDepth2D:
     def visit_scan(self, s_hat: int) -> None:
         pc = self.p.to_c()
         self.vol.ctx.use_current_stream()
-        self._check(self._L().rslf_sweep_visit_scan(self.vol.ctx._h, self.vol._h, None, None, self.dmin, self.dmax, self.dim_d, int(s_hat),
+        lo, hi = self.bounds if self.bounds else (None, None)
+        self._check(self._L().rslf_sweep_visit_scan(self.vol.ctx._h, self.vol._h, self._ptr(lo), self._ptr(hi), self.dmin, self.dmax, self.dim_d, int(s_hat),
                                                     self._ptr(self.Ce), self._ptr(self.cem), self._ptr(self.Cd), self._ptr(self.depth),
                                                     self._ptr(self.rbar), C.byref(pc)), "rslf_sweep_visit_scan")
 
@@ -413,3 +418,166 @@ def run_lockstep_sweep(shards: List["ShardedDepth2D"], exchange: bool = True) ->
             sh.visit_finish(s_hat)
     for sh in shards:
         sh.finish()
+
+
+# ---- fine-to-coarse over scanline shards -------------------------------------------------------------------------------------
+
+def _gather_rows(own: torch.Tensor, V: int, rank: int, world: int, group=None) -> torch.Tensor:
+    """All-gather of row blocks: `own` is this rank's [S, rows, U] block of a [S, V, U] plane cut by row_partition(V, world);
+    returns the whole plane on every rank.  Blocks differ by at most one row: every rank sends max_rows (zero padded)."""
+    parts = row_partition(V, world)
+    max_rows = max(b - a for a, b in parts)
+    S, rows, U = own.shape
+    via_host = dist.get_backend(group) == "gloo"
+    send = torch.zeros((S, max_rows, U), dtype=own.dtype, device="cpu" if via_host else own.device)
+    send[:, :rows] = own
+    recv = [torch.empty_like(send) for _ in range(world)]
+    dist.all_gather(recv, send, group=group)
+    full = torch.empty((S, V, U), dtype=own.dtype, device=own.device)
+    for (a, b), t in zip(parts, recv):
+        full[:, a:b] = t[:, :b - a].to(own.device)
+    return full
+
+
+class ShardedFineToCoarse:
+    """One rank's share of rslf::FineToCoarse (rslf_fine_to_coarse.hpp:103-324).
+
+    What is sharded is where the time goes: every level's 2-D sweep runs on this rank's block of scanlines
+    (ShardedDepth2D: one neighbour exchange of 2 boundary rows per visit).  The pyramid itself -- Gaussian blur and
+    halving, ~1 % of a run, and in need of the whole image's borders and odd-row rule -- is built on every rank from the
+    whole light field, so a level's normalisation is the whole level's maximum as in the unsharded run; each level is cut
+    by row_partition on its own.  After a level's sweep the ranks all-gather its disparity and validity planes (5 bytes
+    per pixel and view), and the bound tightening for the next level and the final coarse-to-fine fusion -- cheap
+    whole-image passes with non-local footprints (nearest valid column, bilinear upscaling, 3x3 median) -- run on the
+    gathered planes.  Results are those of FineToCoarse bit for bit (tests/test_gpu_f2c.py)."""
+
+    def __init__(self, epis, d_min: float, d_max: float, dim_d: int, rank: int, world: int, epi_scale_factor: float = -1.0,
+                 parameters=None, max_pyr_depth: int = -1, accept_all_last_scale: bool = True, ctx=None, group=None):
+        import copy
+        from . import depth as rs
+        from . import _lib
+        self.rs, self.rank, self.world, self.group = rs, int(rank), int(world), group
+        self.m_parameters = parameters or rs.Depth1DParameters.get_default()
+        self.ctx = ctx or rs.default_context()
+        dev = self.ctx.device
+        a = np.stack([np.asarray(e) for e in epis]) if isinstance(epis, (list, tuple)) else np.asarray(epis)
+        if a.ndim == 3:
+            a = a[..., None]
+        is_u8 = a.dtype == np.uint8
+        raw = torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dev)
+        start_dim_u = raw.shape[2]
+        if max_pyr_depth < 1:
+            max_pyr_depth = 1 << 30
+        self.levels: List[dict] = []
+        dim_v, dim_u, counter = raw.shape[0], raw.shape[2], 0
+        L = _lib.lib()
+        while dim_v > rs._MIN_SPATIAL_DIM and dim_u > rs._MIN_SPATIAL_DIM and counter < max_pyr_depth:   # f2c.hpp:130
+            counter += 1
+            par = copy.copy(self.m_parameters)
+            par.par_slope_factor = float(np.float32((0.0 + dim_u) / start_dim_u))                          # f2c.hpp:139
+            if is_u8:
+                scale = 255.0
+            elif epi_scale_factor < 0:      # the level's own maximum (dc.hpp:671-705) -- of the WHOLE level
+                mx = C.c_float()
+                self.ctx.use_current_stream()
+                _lib.check(L.rslf_device_max_f32(self.ctx._h, C.c_void_p(raw.data_ptr()), raw.numel(), C.byref(mx)), "rslf_device_max_f32")
+                scale = float(mx.value)
+            else:
+                scale = float(epi_scale_factor)
+            # a coarse level whose blocks would be thinner than the halo they must fill is small enough to run whole
+            # on every rank
+            replicated = self.world == 1 or dim_v // self.world < max(1, halo_rows(par.par_median_filter_size, par.par_edge_confidence_opening_size))
+            shard = make_shard(dim_v, 0, 1) if replicated else make_shard(dim_v, self.rank, self.world, par.par_median_filter_size,
+                                                                          par.par_edge_confidence_opening_size)
+            vol = rs.Volume.from_dense(raw[shard.rows].contiguous(), scale, self.ctx)
+            self.levels.append(dict(V=dim_v, U=dim_u, par=par, shard=shard, vol=vol, sweep=None, depth=None, valid=None, accept_all=False,
+                                    replicated=replicated))
+            raw = rs.downsample_EPIs(raw, self.ctx, is_u8)                                                 # f2c.hpp:145-147
+            dim_v, dim_u = raw.shape[0], raw.shape[2]
+        if not self.levels:
+            raise ValueError("light field smaller than _MIN_SPATIAL_DIM: no pyramid level")
+        if accept_all_last_scale:
+            self.levels[-1]["accept_all"] = True                                                           # f2c.hpp:157-158
+        self._dmin, self._dmax, self._dim_d = float(d_min), float(d_max), int(dim_d)
+        self.S = self.levels[0]["vol"].S
+
+    # -- steps (a lock-step harness drives them for several ranks in one process) ---------------------------------------
+    def begin_level(self, p: int) -> ShardedDepth2D:
+        """The sweep of level p over this rank's rows; levels below the finest take their per-pixel ranges from the
+        gathered planes of level p - 1 (f2c.hpp:202-294)."""
+        from . import _lib
+        lv = self.levels[p]
+        if p == 0:
+            lo, hi = self._dmin, self._dmax
+        else:
+            up = self.levels[p - 1]
+            if up["depth"] is None:
+                raise RuntimeError("level %d needs the gathered planes of level %d" % (p, p - 1))
+            dev = self.ctx.device
+            lo = torch.full((self.S, lv["V"], lv["U"]), self._dmin, dtype=torch.float32, device=dev)
+            hi = torch.full((self.S, lv["V"], lv["U"]), self._dmax, dtype=torch.float32, device=dev)
+            self.ctx.use_current_stream()
+            vp = C.c_void_p
+            _lib.check(_lib.lib().rslf_f2c_tighten_bounds(self.ctx._h, vp(up["depth"].data_ptr()), vp(up["valid"].data_ptr()), self.S, up["V"],
+                                                          up["U"], vp(lo.data_ptr()), vp(hi.data_ptr()), lv["V"], lv["U"]), "rslf_f2c_tighten_bounds")
+            rows = lv["shard"].rows
+            lo, hi = lo[:, rows].contiguous(), hi[:, rows].contiguous()
+        lv["sweep"] = ShardedDepth2D(lv["vol"], lv["shard"], lo, hi, self._dim_d, lv["par"], self.group)
+        return lv["sweep"]
+
+    def own_level_planes(self, p: int):
+        """(disparities, validity) of this rank's own rows of level p: [S, rows, U] f32 / u8 (dc.hpp:893-915)."""
+        lv = self.levels[p]
+        sw = lv["sweep"]
+        thr = -1.0 if lv["accept_all"] else float(np.float32(lv["par"].par_edge_score_threshold))
+        o = sw.own
+        return sw.depth[:, o].contiguous(), ((sw.Ce[:, o] > thr).to(torch.uint8) * 255).contiguous()
+
+    def set_level_planes(self, p: int, depth_full: torch.Tensor, valid_full: torch.Tensor) -> None:
+        self.levels[p]["depth"], self.levels[p]["valid"] = depth_full.contiguous(), valid_full.contiguous()
+
+    def run(self) -> None:
+        """f2c.hpp:171-299 over torch.distributed: per level one sharded sweep and one all-gather of two planes."""
+        for p, lv in enumerate(self.levels):
+            self.begin_level(p).run()
+            depth, valid = self.own_level_planes(p)
+            if not lv["replicated"]:
+                depth = _gather_rows(depth, lv["V"], self.rank, self.world, self.group)
+                valid = _gather_rows(valid, lv["V"], self.rank, self.world, self.group)
+            self.set_level_planes(p, depth, valid)
+
+    def get_results(self):
+        """f2c.hpp:302-324 on the gathered planes -> (out_map_s_v_u, out_validity_s_v_u) at the finest scale."""
+        from . import _lib
+        P = len(self.levels)
+        dp = (C.c_void_p * P)(*[lv["depth"].data_ptr() for lv in self.levels])
+        vp = (C.c_void_p * P)(*[lv["valid"].data_ptr() for lv in self.levels])
+        Vp = (C.c_int * P)(*[lv["V"] for lv in self.levels])
+        Up = (C.c_int * P)(*[lv["U"] for lv in self.levels])
+        dev = self.ctx.device
+        out_map = torch.empty((self.S, self.levels[0]["V"], self.levels[0]["U"]), dtype=torch.float32, device=dev)
+        out_valid = torch.empty((self.S, self.levels[0]["V"], self.levels[0]["U"]), dtype=torch.uint8, device=dev)
+        self.ctx.use_current_stream()
+        _lib.check(_lib.lib().rslf_f2c_fuse(self.ctx._h, dp, vp, Vp, Up, P, self.S, C.c_void_p(out_map.data_ptr()),
+                                            C.c_void_p(out_valid.data_ptr())), "rslf_f2c_fuse")
+        return out_map, out_valid
+
+    @property
+    def pixels_scanned(self) -> int:
+        """Pixels this rank scanned over all levels (a replicated level counts on every rank)."""
+        return sum(int(lv["sweep"].stats.pixels_scanned) for lv in self.levels if lv["sweep"] is not None and lv["sweep"].stats)
+
+
+def run_lockstep_f2c(ranks: List["ShardedFineToCoarse"]) -> None:
+    """Several ranks of a sharded fine-to-coarse run in ONE process: level by level, the sweeps in lock step and the
+    all-gather as a concatenation (tests; a one-GPU box)."""
+    for p in range(len(ranks[0].levels)):
+        run_lockstep_sweep([r.begin_level(p) for r in ranks])
+        planes = [r.own_level_planes(p) for r in ranks]
+        if ranks[0].levels[p]["replicated"]:
+            for r, (d, m) in zip(ranks, planes):
+                r.set_level_planes(p, d, m)
+            continue
+        for r in ranks:
+            dev = r.ctx.device
+            r.set_level_planes(p, torch.cat([d.to(dev) for d, _ in planes], dim=1), torch.cat([m.to(dev) for _, m in planes], dim=1))

@@ -101,3 +101,82 @@ def test_fine_to_coarse_end_to_end(oracle_mod, C_, dtype):
     out_map, out_valid = f2c.get_results()
     assert np.array_equal(out_map.cpu().numpy(), ref["fused_map"])
     assert np.array_equal(out_valid.cpu().numpy(), ref["fused_valid"])
+
+
+def _f2c_inputs(dtype, C_, V=44, U=64, S=5):
+    from remotesensingproject_amd.synth import make_lightfield
+    vol, _ = make_lightfield(U, V, S, C_, seed=2, dmin=-1, dmax=1, band=8)
+    if dtype == np.uint8:
+        return np.round(vol * 255.0).astype(np.uint8)
+    raw = (vol * 200 + 3).astype(np.float32)
+    raw[V // 2:] *= 0.5            # the halves differ in brightness: a rank's own maximum would be the wrong scale
+    return raw
+
+
+@pytest.mark.parametrize("world,C_,dtype,V", [(2, 1, np.float32, 44), (3, 3, np.uint8, 44), (4, 1, np.uint8, 90), (3, 1, np.float32, 61)])
+def test_fine_to_coarse_sharded_by_scanline(world, C_, dtype, V):
+    """FineToCoarse with every level's sweep cut into scanline blocks (ShardedFineToCoarse; the ranks' steps in one process,
+    one context each): every level's gathered planes and the fused map equal the unsharded run bit for bit -- float input
+    with the per-level default normalisation, uchar input, ragged blocks, a coarsest level too small to cut."""
+    import torch
+    from remotesensingproject_amd import depth as rs
+    from remotesensingproject_amd import sharding
+    raw = _f2c_inputs(dtype, C_, V=V)
+    full = rs.FineToCoarse(raw, -1.0, 1.0, 9)
+    full.run()
+    want_map, want_valid = full.get_results()
+    ranks = [sharding.ShardedFineToCoarse(raw, -1.0, 1.0, 9, r, world, ctx=rs.Context(0)) for r in range(world)]
+    assert len(ranks[0].levels) == len(full.m_computers)
+    assert any(not lv["replicated"] for lv in ranks[0].levels)
+    sharding.run_lockstep_f2c(ranks)
+    torch.cuda.synchronize()
+    for p, comp in enumerate(full.m_computers):
+        for r in ranks:
+            assert torch.equal(r.levels[p]["depth"], comp.m_best_depth_s_v_u), (p, r.rank)
+            assert torch.equal(r.levels[p]["valid"], comp.get_valid_depths_mask_s_v_u()), (p, r.rank)
+    for r in ranks:
+        got_map, got_valid = r.get_results()
+        assert torch.equal(got_map, want_map) and torch.equal(got_valid, want_valid)
+    scanned = sum(int(c.stats.pixels_scanned) for c in full.m_computers)
+    sharded = sum(int(r.levels[p]["sweep"].stats.pixels_scanned) for p in range(len(ranks[0].levels))
+                  for r in (ranks if not ranks[0].levels[p]["replicated"] else ranks[:1]))
+    assert sharded == scanned
+
+
+def _f2c_rank(rank, world, port, out_dir):
+    import os
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from remotesensingproject_amd import sharding
+        torch.cuda.set_device(0)
+        raw = _f2c_inputs(np.float32, 1)
+        f = sharding.ShardedFineToCoarse(raw, -1.0, 1.0, 9, rank, world)
+        f.run()                                   # sweeps with neighbour exchanges, one all-gather per level
+        out_map, out_valid = f.get_results()
+        torch.cuda.synchronize()
+        np.savez(os.path.join(out_dir, "f2c%d.npz" % rank), out_map=out_map.cpu().numpy(), out_valid=out_valid.cpu().numpy())
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_fine_to_coarse_sharded_over_torch_distributed(tmp_path):
+    """ShardedFineToCoarse.run() in two rank processes on the one GPU (gloo transport: a rehearsal of the exchange and the
+    gathers; RCCL on a multi-GPU node): every rank ends with the unsharded fused map."""
+    import socket
+    import torch
+    import torch.multiprocessing as mp
+    from remotesensingproject_amd import depth as rs
+    world = 2
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_f2c_rank, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    full = rs.FineToCoarse(_f2c_inputs(np.float32, 1), -1.0, 1.0, 9)
+    full.run()
+    want_map, want_valid = full.get_results()
+    for r in range(world):
+        q = np.load(tmp_path / ("f2c%d.npz" % r))
+        assert np.array_equal(q["out_map"], want_map.cpu().numpy()) and np.array_equal(q["out_valid"], want_valid.cpu().numpy())

@@ -208,3 +208,30 @@ def test_sweep_order_centre_outwards():
     assert sharding.sweep_order(5) == [2, 3, 1, 4, 0]
     assert sharding.sweep_order(1) == [0]
     assert sharding.sweep_order(8) == [4, 5, 3, 6, 2, 7, 1]          # an even view count never visits view 0 (core.hpp:981-990)
+
+
+def _gather_worker(rank, world, port, V, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        S, U = 3, 7
+        full = torch.arange(S * V * U, dtype=torch.float32).reshape(S, V, U)
+        a, b = sharding.row_partition(V, world)[rank]
+        got = sharding._gather_rows(full[:, a:b].contiguous(), V, rank, world)
+        gotb = sharding._gather_rows((full[:, a:b] % 251).to(torch.uint8).contiguous(), V, rank, world)
+        np.savez(os.path.join(out_dir, "g%d.npz" % rank), f=got.numpy(), b=gotb.numpy())
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,V", [(2, 10), (3, 11)])
+def test_all_gather_of_ragged_row_blocks(tmp_path, world, V):
+    """The per-level all-gather of the sharded fine-to-coarse run: every rank ends with the whole plane, blocks of
+    unequal height included (f32 disparities and u8 validity)."""
+    mp.spawn(_gather_worker, args=(world, _free_port(), V, str(tmp_path)), nprocs=world, join=True)
+    want = np.arange(3 * V * 7, dtype=np.float32).reshape(3, V, 7)
+    for r in range(world):
+        q = np.load(tmp_path / ("g%d.npz" % r))
+        assert np.array_equal(q["f"], want) and np.array_equal(q["b"], (want % 251).astype(np.uint8))
