@@ -194,6 +194,17 @@ __device__ __forceinline__ void write_pixel(const ScanArgs& a, long long o, floa
     }
 }
 
+// Word accesses that are coherent at agent scope by themselves (sc1: to / from the memory side), for data handed from one
+// workgroup to another that may run on a different XCD -- no cache-wide write-back or invalidate.
+__device__ __forceinline__ void store_coherent(unsigned* p, unsigned v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned load_coherent(const unsigned* p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 template <int C>
 __device__ __forceinline__ void combine_tile(const ScanArgs& a, int tile, int v, int u);
 
@@ -242,19 +253,26 @@ __device__ __forceinline__ void scan_epilogue(const ScanArgs& a, int lb, int v, 
         }
     }
     if (a.groups > 1) {
-        Partial& pr = a.partial[(long long)lb * 64 + lane];
-        pr.score = best;
-        pr.D = best_D;
-        pr.d = best_d;
-        pr.sum = sum;
+        // The group that finishes LAST merges the tile's records (no combine launch).  The groups of a tile may sit on
+        // different XCDs, whose L2s are not coherent.  A release / acquire fence pair at agent scope would be the textbook
+        // hand-off, but on gfx950 it is `buffer_wbl2 sc1` + `buffer_inv sc1` -- a write-back and an invalidate of the
+        // XCD's whole L2, i.e. of the EPI lines every other workgroup there is gathering from (measured: +12 % on the
+        // packed scans of a 100-view fine-to-coarse run).  So the records alone are made coherent, access by access:
+        // written with agent-scope atomic stores (sc1: through to the memory side), the wave waits for them to complete
+        // (s_waitcnt vmcnt(0)) before lane 0 draws the ticket, and the group that draws the last one reads the records
+        // with agent-scope atomic loads (sc1: past the caches), which its branch on the ticket orders after the draw.
+        unsigned* w = reinterpret_cast<unsigned*>(a.partial + ((long long)lb * 64 + lane));
+        static_assert(sizeof(Partial) == 32, "eight words per record");
+        const unsigned long long sb = (unsigned long long)__double_as_longlong(sum);
+        store_coherent(w + 0, __float_as_uint(best));
+        store_coherent(w + 1, __float_as_uint(best_D));
+        store_coherent(w + 2, (unsigned)best_d);
 #pragma unroll
-        for (int c = 0; c < C; c++)
-            pr.rbar[c] = best_rbar[c];
-        // The group that finishes LAST merges the tile's records (no combine launch).  Hand-off between workgroups
-        // that may sit on different XCDs (their L2s are not coherent): every lane's record is made visible at agent
-        // scope (release fence) before lane 0 draws the ticket; the group that draws the last one acquires at agent
-        // scope before it reads the other groups' records (MI355X_MICROARCH.md "Correctness boundaries").
-        __threadfence();
+        for (int c = 0; c < 3; c++)
+            store_coherent(w + 3 + c, c < C ? __float_as_uint(best_rbar[c < C ? c : 0]) : 0u);
+        store_coherent(w + 6, (unsigned)sb);
+        store_coherent(w + 7, (unsigned)(sb >> 32));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (a workgroup-scope release fence emits nothing here)
         const int tile = lb / a.groups;
         int drawn = 0;
         if (lane == 0)
@@ -262,7 +280,7 @@ __device__ __forceinline__ void scan_epilogue(const ScanArgs& a, int lb, int v, 
         drawn = __builtin_amdgcn_readfirstlane(drawn);
         if (drawn != a.groups - 1)
             return;
-        __threadfence();
+        asm volatile("" ::: "memory");
         if (active)
             combine_tile<C>(a, tile, v, u);
         if (lane == 0)
@@ -277,24 +295,43 @@ __device__ __forceinline__ void scan_epilogue(const ScanArgs& a, int lb, int v, 
 template <int C>
 __device__ __forceinline__ void combine_tile(const ScanArgs& a, int tile, int v, int u)
 {
-    const Partial* pr = a.partial + (long long)tile * a.groups * 64 + (threadIdx.x & 63);
-    float best = pr[0].score, best_D = pr[0].D;
-    int best_d = pr[0].d;
+    const unsigned* pr = reinterpret_cast<const unsigned*>(a.partial + (long long)tile * a.groups * 64 + (threadIdx.x & 63));
+    float best = -1.0f, best_D = 0.0f;
+    int best_d = -1;
     float best_rbar[C];
 #pragma unroll
     for (int c = 0; c < C; c++)
-        best_rbar[c] = pr[0].rbar[c];
-    double sum = pr[0].sum;
-    for (int g = 1; g < a.groups; g++) {
-        const Partial& q = pr[(long long)g * 64];
-        sum += q.sum;
-        if (q.score > best) {
-            best = q.score;
-            best_d = q.d;
-            best_D = q.D;
+        best_rbar[c] = 0.0f;
+    double sum = 0.0;
+    // eight groups' records at a time, every word's load issued before the first is used: the loads go past the caches
+    // (a round trip to memory each), and this wave is the last thing its tile waits for
+    constexpr int GB = 8, W = sizeof(Partial) / sizeof(unsigned);
+    for (int g0 = 0; g0 < a.groups; g0 += GB) {
+        unsigned w[GB][W];
 #pragma unroll
-            for (int c = 0; c < C; c++)
-                best_rbar[c] = q.rbar[c];
+        for (int j = 0; j < GB; j++) {
+            const unsigned* q = pr + (long long)min(g0 + j, a.groups - 1) * 64 * W;
+#pragma unroll
+            for (int k = 0; k < W; k++)
+                if (k < 3 + C || k >= 6)
+                    w[j][k] = load_coherent(q + k);
+        }
+#pragma unroll
+        for (int j = 0; j < GB; j++) {
+            const int g = g0 + j;
+            if (g >= a.groups)
+                break;
+            const float q_score = __uint_as_float(w[j][0]);
+            const double q_sum = __longlong_as_double((long long)((unsigned long long)w[j][6] | ((unsigned long long)w[j][7] << 32)));
+            sum = g == 0 ? q_sum : sum + q_sum;
+            if (g == 0 || q_score > best) {   // first maximum in hypothesis order: the lower group holds the lower hypotheses
+                best = q_score;
+                best_D = __uint_as_float(w[j][1]);
+                best_d = (int)w[j][2];
+#pragma unroll
+                for (int c = 0; c < C; c++)
+                    best_rbar[c] = __uint_as_float(w[j][3 + c]);
+            }
         }
     }
     write_pixel<C>(a, (long long)v * a.vol.U + u, best, best_d, best_D, best_rbar, sum);
