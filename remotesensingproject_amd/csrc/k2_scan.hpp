@@ -227,8 +227,10 @@ __device__ __forceinline__ void scan_epilogue(const ScanArgs& a, int lb, int v, 
     for (int c = 0; c < C; c++)
         s_rbar[wave][c][lane] = mine.rbar[c];
     __syncthreads();
-    if (wave != 0)
-        return;
+    if (wave != 0) {
+        __syncthreads();   // wave 0 has read the arrays: the next item's epilogue may overwrite them
+        return;            // ... and these waves go on to it while wave 0 hands over this item's record
+    }
 
     float best = mine.score, best_D = mine.D;
     int best_d = mine.d;
@@ -252,6 +254,7 @@ __device__ __forceinline__ void scan_epilogue(const ScanArgs& a, int lb, int v, 
                 best_rbar[c] = s_rbar[w][c][lane];
         }
     }
+    __syncthreads();       // (pairs with the other waves' second barrier)
     if (a.groups > 1) {
         // The group that finishes LAST merges the tile's records (no combine launch).  The groups of a tile may sit on
         // different XCDs, whose L2s are not coherent.  A release / acquire fence pair at agent scope would be the textbook
@@ -452,8 +455,8 @@ __device__ __forceinline__ void scan_generic_body(const ScanArgs& a, int v, int 
 
 // The launch shapes every variant shares.  Row tiles: one (tile, group) item per workgroup, dealt to XCDs
 // in scanline order.  Packed tiles: a fixed grid strides over the items the device-side count yields;
-// every wave of a workgroup makes the same trips, and the barrier separates one item's merge in LDS
-// from the next item's.
+// every wave of a workgroup makes the same trips, and the epilogue's second barrier separates one item's
+// merge in LDS from the next item's.
 #define RSLF_SCAN_PACKED_LOOP(PACKED_CALL) RSLF_SCAN_PACKED_LOOP_(scan_chunk, PACKED_CALL)
 #define RSLF_SCAN_ROW_TILE(ROWS_CALL) RSLF_SCAN_ROW_TILE_(scan_chunk, ROWS_CALL)
 #define RSLF_SCAN_PACKED_LOOP_(CHUNK, PACKED_CALL)                                      \
@@ -469,7 +472,6 @@ __device__ __forceinline__ void scan_generic_body(const ScanArgs& a, int v, int 
             best.init();                                                                \
             PACKED_CALL;                                                                \
             scan_epilogue<C>(a, item, v, u, active, best);                              \
-            __syncthreads();                                                            \
         }                                                                               \
     }
 #define RSLF_SCAN_ROW_TILE_(CHUNK, ROWS_CALL)                                           \
