@@ -453,6 +453,18 @@ __device__ __forceinline__ void scan_generic_body(const ScanArgs& a, int v, int 
     }
 }
 
+// Packed launches: only the device knows how many pixels the list holds.  Few tiles: every hypothesis group the host
+// allowed (the launch lasts as long as one wave's walk over its hypotheses).  Many tiles: the groups only multiply the
+// records to merge -- 64 000 pixels of the c2 shape take 530 us with one group and 920 us with sixteen
+// (tools/probe_sparse.py) -- so the groups are halved until the items are about two per workgroup of the fixed grid.
+constexpr int kPackedItemTarget = 2048;
+__device__ __forceinline__ int packed_groups(int groups, int tiles)
+{
+    while (groups > 1 && tiles * groups > kPackedItemTarget)
+        groups >>= 1;
+    return groups;
+}
+
 // The launch shapes every variant shares.  Row tiles: one (tile, group) item per workgroup, dealt to XCDs
 // in scanline order.  Packed tiles: a fixed grid strides over the items the device-side count yields;
 // every wave of a workgroup makes the same trips, and the epilogue's second barrier separates one item's
@@ -461,17 +473,22 @@ __device__ __forceinline__ void scan_generic_body(const ScanArgs& a, int v, int 
 #define RSLF_SCAN_ROW_TILE(ROWS_CALL) RSLF_SCAN_ROW_TILE_(scan_chunk, ROWS_CALL)
 #define RSLF_SCAN_PACKED_LOOP_(CHUNK, PACKED_CALL)                                      \
     {                                                                                   \
-        Best<C> best;                                                                   \
-        int v, u, d0, d1;                                                               \
-        bool active;                                                                    \
         const int n = *a.packed_n;                                                      \
-        const int items = ((n + 63) >> 6) * a.groups;                                   \
-        for (int item = blockIdx.x; item < items; item += gridDim.x) {                  \
-            scan_tile_packed(a, item, n, v, u, active);                                 \
-            CHUNK(a, item % a.groups, d0, d1);                                          \
-            best.init();                                                                \
-            PACKED_CALL;                                                                \
-            scan_epilogue<C>(a, item, v, u, active, best);                              \
+        ScanArgs a_items = a;                                                           \
+        a_items.groups = packed_groups(a.groups, (n + 63) >> 6);                        \
+        {                                                                               \
+            const ScanArgs& a = a_items;   /* shadows the kernel argument */            \
+            Best<C> best;                                                               \
+            int v, u, d0, d1;                                                           \
+            bool active;                                                                \
+            const int items = ((n + 63) >> 6) * a.groups;                               \
+            for (int item = blockIdx.x; item < items; item += gridDim.x) {              \
+                scan_tile_packed(a, item, n, v, u, active);                             \
+                CHUNK(a, item % a.groups, d0, d1);                                      \
+                best.init();                                                            \
+                PACKED_CALL;                                                            \
+                scan_epilogue<C>(a, item, v, u, active, best);                          \
+            }                                                                           \
         }                                                                               \
     }
 #define RSLF_SCAN_ROW_TILE_(CHUNK, ROWS_CALL)                                           \
