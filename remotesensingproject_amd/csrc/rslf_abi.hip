@@ -161,7 +161,7 @@ static int ensure_plane_scratch(rslf_ctx* ctx, int V, int U)
 }
 
 // Records and tickets of grouped scan launches (k2_scan.hpp): grow-only, so a context allocates them once.
-static int ensure_group_scratch(rslf_ctx* ctx, size_t recs, int groups)
+static int ensure_group_scratch(rslf_ctx* ctx, size_t recs, size_t tiles)
 {
     if (recs > ctx->partial_rec_cap) {
         HIP_TRY(hipFree(ctx->scan_partial));
@@ -170,7 +170,6 @@ static int ensure_group_scratch(rslf_ctx* ctx, size_t recs, int groups)
         HIP_TRY(hipMalloc(&ctx->scan_partial, recs * sizeof(Partial)));
         ctx->partial_rec_cap = recs;
     }
-    const size_t tiles = recs / ((size_t)groups * 64);
     if (tiles > ctx->ticket_cap) {
         HIP_TRY(hipFree(ctx->scan_ticket));
         ctx->scan_ticket = nullptr;
@@ -1012,24 +1011,20 @@ extern "C" int rslf_depth_epi_scan(rslf_ctx* ctx, const rslf_volume* vol, const 
     a.ticket = nullptr;
     a.v0 = 0;
 
-    // Grouped launches leave one 32-byte record per (tile, group, lane) for k2_scan_combine.  The records are
-    // bounded by kPartialBudget: packed launches (at most ceil(V*U/64) tiles, the device knows how many) halve
-    // their groups until they fit; row-tile launches go by blocks of scanlines.
+    // Grouped launches leave one 32-byte record per (tile, group, lane) for the tile's last group to merge.  Row-tile
+    // launches bound them by kPartialBudget and go by blocks of scanlines.  Packed launches settle their group count on
+    // the device (packed_groups, k2_scan.hpp): more than one group only while tiles x groups <= kPackedItemTarget, so
+    // that many records (4 MiB) serve any list length.
     int rows_per_launch = vol->V;
-    if (groups > 1) {
-        const size_t rec = 64 * sizeof(Partial);
-        if (packed) {
-            while (groups > 1 && ((n + 63) / 64) * groups * rec > kPartialBudget)
-                groups /= 2;
-        } else {
-            const size_t per_row = (size_t)a.tiles_per_row * groups * rec;
-            rows_per_launch = (int)std::min<size_t>((size_t)vol->V, std::max<size_t>(1, kPartialBudget / per_row));
-        }
+    if (groups > 1 && !packed) {
+        const size_t per_row = (size_t)a.tiles_per_row * groups * 64 * sizeof(Partial);
+        rows_per_launch = (int)std::min<size_t>((size_t)vol->V, std::max<size_t>(1, kPartialBudget / per_row));
     }
     a.groups = groups;
     if (groups > 1) {
-        const size_t recs = (packed ? (n + 63) / 64 : (size_t)rows_per_launch * a.tiles_per_row) * groups * 64;
-        rc = ensure_group_scratch(ctx, recs, groups);
+        const size_t tiles_max = packed ? std::min<size_t>((n + 63) / 64, kPackedItemTarget / 2) : (size_t)rows_per_launch * a.tiles_per_row;
+        const size_t recs = packed ? std::min<size_t>(((n + 63) / 64) * groups, kPackedItemTarget) * 64 : tiles_max * groups * 64;
+        rc = ensure_group_scratch(ctx, recs, tiles_max);
         if (rc)
             return rc;
         a.partial = ctx->scan_partial;
@@ -1481,10 +1476,9 @@ extern "C" int rslf_sweep_begin(rslf_ctx* ctx, const rslf_volume* vol, const uin
         int g = kSweepGroups;
         while (g > 1 && dim_d < 2 * kScanWaves * g)
             g /= 2;
-        while (g > 1 && ((n + 63) / 64) * g * 64 * sizeof(Partial) > kPartialBudget)
-            g /= 2;
         if (g > 1 && n <= (size_t)INT32_MAX) {
-            rc = ensure_group_scratch(ctx, ((n + 63) / 64) * g * 64, g);
+            rc = ensure_group_scratch(ctx, std::min<size_t>(((n + 63) / 64) * g, kPackedItemTarget) * 64,
+                                      std::min<size_t>((n + 63) / 64, kPackedItemTarget / 2));
             if (rc)
                 return rc;
         }
