@@ -1095,13 +1095,17 @@ constexpr int kPadSlack = 16;     // compiled slot counts step by at most this: 
 // PK:        the samples live in register PAIRS (s, s+1) and the mean-shift pass uses packed fp32
 //            instructions on them; the sums still take one sample at a time, in ascending s.  For the
 //            variants that run at one wave per SIMD (rslf_device.hpp, f2).
-template <int SPAD, int C, bool BORDER, bool UNIFORM_D, bool PK>
+// GB:        samples whose loads are in flight together, 0 = the default (gather_batch).  The packed kernel of long
+//            one-channel units asks for a quarter of the unit at once: on a sparse launch a wave has its SIMD nearly to
+//            itself, and a hypothesis costs it one memory round trip per batch.
+template <int SPAD, int C, bool BORDER, bool UNIFORM_D, bool PK, int GB = 0>
 __device__ __forceinline__ void scan_reg_body(const ScanArgs& a, int v, int u, int d0, int d1, Best<C>& best,
                                               float* __restrict__ otab)
 {
     // 104 slots (the c3 shape) have 15 registers to spare at three waves per SIMD: 13 loads in flight instead of 8
     // (8 batches instead of 13 per hypothesis) measured 0.5 % faster
-    constexpr int kGatherBatch = (C == 1 && !PK && SPAD == 104) ? 13 : gather_batch(C);
+    constexpr int kGatherBatch = GB > 0 ? GB : (C == 1 && !PK && SPAD == 104) ? 13 : gather_batch(C);
+    static_assert(SPAD % kGatherBatch == 0 && (!PK || kGatherBatch % 2 == 0), "whole batches, whole pairs");
     static_assert(SPAD % 8 == 0, "slot counts are multiples of 8");
     const VolView& vol = a.vol;
     const float* epi = vol.row(v, 0);
@@ -1236,7 +1240,8 @@ __device__ __forceinline__ void scan_reg_body(const ScanArgs& a, int v, int u, i
                         asm volatile("" : "+v"(R2[c][b / 2]), "+v"(R2[c][b / 2 + 1]));
                         if (kGatherBatch == 8)
                             asm volatile("" : "+v"(R2[c][b / 2 + 2]), "+v"(R2[c][b / 2 + 3]));
-                    } else if (kGatherBatch == 13) {
+                        static_assert(!PK || kGatherBatch == 4 || kGatherBatch == 8, "pair pinning is written for 4 and 8");
+                    } else if (kGatherBatch != 4 && kGatherBatch != 8) {
 #pragma unroll
                         for (int j = 0; j < kGatherBatch; j++)
                             asm volatile("" : "+v"(R[c][b + j]));
@@ -1416,11 +1421,20 @@ void k2_scan_reg(ScanArgs a)
 
 // Packed tiles: its own kernel, because per-lane EPI bases cost address registers the row kernel's
 // budget does not have (and must not pay for).
+#ifndef RSLF_PACKED_LONG_GB
+#define RSLF_PACKED_LONG_GB 4   // divisor: a quarter of the unit per gather batch
+#endif
+constexpr bool packed_long_unit(int spad, int c) { return c == 1 && spad >= 80 && spad <= 128 && spad % RSLF_PACKED_LONG_GB == 0; }
+constexpr int packed_waves(int spad, int c) { return packed_long_unit(spad, c) ? 2 : scan_reg_waves(spad + 24, c); }
+constexpr int packed_gather_batch(int spad, int c) { return packed_long_unit(spad, c) ? spad / RSLF_PACKED_LONG_GB : 0; }
+
 template <int SPAD, int C>
-__global__ __launch_bounds__(64 * kScanWaves) __attribute__((amdgpu_waves_per_eu(scan_reg_waves(SPAD + 24, C), scan_reg_waves(SPAD + 24, C))))
+__global__ __launch_bounds__(64 * kScanWaves) __attribute__((amdgpu_waves_per_eu(packed_waves(SPAD, C), packed_waves(SPAD, C))))
 void k2_scan_reg_packed(ScanArgs a)
 {
-    RSLF_SCAN_PACKED_LOOP((scan_reg_body<SPAD, C, true, false, scan_reg_packed_math(SPAD + 24, C)>(a, v, u, d0, d1, best, nullptr)))
+    // (Tiles whose 64 entries sit on one scanline -- most of them on a visit that scans many pixels -- were also given
+    // the row kernel's forms, scalar EPI base and shared offset table: no gain, not kept.)
+    RSLF_SCAN_PACKED_LOOP((scan_reg_body<SPAD, C, true, false, packed_waves(SPAD, C) == 1, packed_gather_batch(SPAD, C)>(a, v, u, d0, d1, best, nullptr)))
 }
 
 }  // namespace rslf

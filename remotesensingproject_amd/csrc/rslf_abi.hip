@@ -47,7 +47,7 @@ static int fail(int code, const char* fmt, ...)
 // Streaming scan kernel: two workgroups per CU (two waves per SIMD) share the CU's 160 KiB of LDS; each has
 // 8 KiB of static LDS (the merge of the four waves' results), so 72 KiB of dynamic LDS per workgroup.
 static constexpr size_t kStreamLdsBytes = (size_t)72 << 10;
-constexpr int kSweepGroups = 16;    // workgroups sharing a packed tile's hypotheses on a sweep's sparse visits
+constexpr int kSweepGroups = 32;    // workgroups sharing a packed tile's hypotheses on a sweep's sparse visits
 // Dense launches of the streaming kernel: this many workgroups share one tile's hypotheses.  The workgroups an
 // XCD runs together then sit on two or three tiles instead of a whole scanline, and what they gather from
 // stays inside the XCD's 4 MiB L2 (k2_scan.hpp)
