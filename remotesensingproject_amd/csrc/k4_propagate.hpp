@@ -17,6 +17,10 @@
 #include "k3_median.hpp"
 #include "rslf_device.hpp"
 
+#ifndef RSLF_CLAIM_BATCH
+#define RSLF_CLAIM_BATCH 8   // views whose running-mask bytes a source pixel has in flight together
+#endif
+
 namespace rslf {
 
 constexpr int kNoWinner = 0x7F7F7F7F;   // what hipMemset(0x7F) leaves; >= any column index
@@ -38,7 +42,7 @@ __device__ __forceinline__ void propagate_claim_pixel(const VolView& vol, int s_
     const long long row = (long long)v * vol.U;
     // eight views at a time: their running-mask bytes, then the radiances of those still unpainted, are loaded together
     // before the first test -- the claims do not depend on one another (atomicMin), only the loads' latency did add up
-    constexpr int B = 8;
+    constexpr int B = RSLF_CLAIM_BATCH;
     for (int s0 = 0; s0 < vol.S; s0 += B) {
         int ri[B];
         bool live[B];

@@ -814,7 +814,7 @@ extern "C" int rslf_selective_median(rslf_ctx* ctx, const rslf_volume* vol, cons
         return fail(RSLF_ERR_INVALID_ARG, "s_hat=%d outside [0,%d)", s_hat, vol->S);
     HIP_TRY(hipSetDevice(ctx->device));
     const dim3 grid((vol->U + 255) / 256, vol->V);
-    const size_t lds = (size_t)size * size * 256 * sizeof(float);   // one candidate slot per window pixel and thread
+    const size_t lds = size == 5 ? 0 : (size_t)size * size * 256 * sizeof(float);   // one candidate slot per window pixel and thread (5 x 5 sorts in registers)
     if (vol->C == 1)
         hipLaunchKernelGGL(k3_selective_median<1>, grid, dim3(256), lds, ctx->stream, view_of(vol), d_src_vu, d_dst_vu, d_mask_vu,
                            s_hat, size, epsilon);
@@ -1541,7 +1541,8 @@ extern "C" int rslf_sweep_visit_finish(rslf_ctx* ctx, const rslf_volume* vol, in
     const dim3 grid_vu((U + 255) / 256, V);
     if ((long long)S * V > (1ll << 31) - 1 || U > 65536)
         return fail(RSLF_ERR_UNSUPPORTED, "%d views x %d scanlines x %d columns: too large for one apply launch", S, V, U);
-    const size_t median_lds = (size_t)p->median_filter_size * p->median_filter_size * 256 * sizeof(float);
+    // the 5 x 5 window sorts in registers (selective_median_pixel_5x5); other sizes keep their candidates in LDS
+    const size_t median_lds = p->median_filter_size == 5 ? 0 : (size_t)p->median_filter_size * p->median_filter_size * 256 * sizeof(float);
     int* packed_n = reinterpret_cast<int*>(ctx->total + 1);
     float* depth = d_depth_svu + (size_t)s_hat * n;
     float* Cd = d_Cd_svu + (size_t)s_hat * n;
