@@ -71,6 +71,7 @@ struct ScanArgs {
     // the device knows how many there are.
     int packed;
     const int* packed_n;
+    int packed_adapt;          // 1: the kernel settles the group count from the list length (packed_groups)
     // streaming kernel: samples per lane parked in LDS behind the register-resident prefix (a multiple of the
     // gather batch; 0 = none), sized by the host to what the dynamic-LDS limit leaves after the offset table
     int stream_park;
@@ -458,9 +459,11 @@ __device__ __forceinline__ void scan_generic_body(const ScanArgs& a, int v, int 
 // records to merge -- 64 000 pixels of the c2 shape take 530 us with one group and 920 us with sixteen
 // (tools/probe_sparse.py) -- so the groups are halved until the items are about two per workgroup of the fixed grid.
 constexpr int kPackedItemTarget = 2048;
-__device__ __forceinline__ int packed_groups(int groups, int tiles)
+// Not for the streaming kernel: its groups are also what keeps the tiles an XCD works on at any one time few enough for
+// their EPI lines to stay in its L2 (a 100-view RGB fine-to-coarse run: +9 % with the groups cut) -- `adapt` is 0 there.
+__device__ __forceinline__ int packed_groups(int groups, int tiles, int adapt)
 {
-    while (groups > 1 && tiles * groups > kPackedItemTarget)
+    while (adapt && groups > 1 && tiles * groups > kPackedItemTarget)
         groups >>= 1;
     return groups;
 }
@@ -475,7 +478,7 @@ __device__ __forceinline__ int packed_groups(int groups, int tiles)
     {                                                                                   \
         const int n = *a.packed_n;                                                      \
         ScanArgs a_items = a;                                                           \
-        a_items.groups = packed_groups(a.groups, (n + 63) >> 6);                        \
+        a_items.groups = packed_groups(a.groups, (n + 63) >> 6, a.packed_adapt);        \
         {                                                                               \
             const ScanArgs& a = a_items;   /* shadows the kernel argument */            \
             Best<C> best;                                                               \

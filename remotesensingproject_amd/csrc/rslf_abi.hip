@@ -1005,6 +1005,7 @@ extern "C" int rslf_depth_epi_scan(rslf_ctx* ctx, const rslf_volume* vol, const 
     }
     a.packed = packed ? 1 : 0;
     a.packed_n = packed_n;
+    a.packed_adapt = 0;
     a.stream_park = 0;
     a.stream_wave_floats = 0;
     a.partial = nullptr;
@@ -1012,18 +1013,25 @@ extern "C" int rslf_depth_epi_scan(rslf_ctx* ctx, const rslf_volume* vol, const 
     a.v0 = 0;
 
     // Grouped launches leave one 32-byte record per (tile, group, lane) for the tile's last group to merge.  Row-tile
-    // launches bound them by kPartialBudget and go by blocks of scanlines.  Packed launches settle their group count on
-    // the device (packed_groups, k2_scan.hpp): more than one group only while tiles x groups <= kPackedItemTarget, so
-    // that many records (4 MiB) serve any list length.
+    // launches bound them by kPartialBudget and go by blocks of scanlines.  Packed launches of the register / generic
+    // kernels settle their group count on the device (packed_groups, k2_scan.hpp): more than one group only while
+    // tiles x groups <= kPackedItemTarget, so that many records (4 MiB) serve any list length.  The streaming kernel keeps
+    // its groups whatever the length (they are its L2 locality) and halves them here until the worst case fits the budget.
     int rows_per_launch = vol->V;
+    a.packed_adapt = (packed && !use_stream) ? 1 : 0;
     if (groups > 1 && !packed) {
         const size_t per_row = (size_t)a.tiles_per_row * groups * 64 * sizeof(Partial);
         rows_per_launch = (int)std::min<size_t>((size_t)vol->V, std::max<size_t>(1, kPartialBudget / per_row));
     }
+    if (packed && use_stream)
+        while (groups > 1 && ((n + 63) / 64) * groups * 64 * sizeof(Partial) > kPartialBudget)
+            groups /= 2;
     a.groups = groups;
     if (groups > 1) {
-        const size_t tiles_max = packed ? std::min<size_t>((n + 63) / 64, kPackedItemTarget / 2) : (size_t)rows_per_launch * a.tiles_per_row;
-        const size_t recs = packed ? std::min<size_t>(((n + 63) / 64) * groups, kPackedItemTarget) * 64 : tiles_max * groups * 64;
+        const size_t tiles_all = (n + 63) / 64;
+        const size_t tiles_max = !packed ? (size_t)rows_per_launch * a.tiles_per_row
+                                         : a.packed_adapt ? std::min<size_t>(tiles_all, kPackedItemTarget / 2) : tiles_all;
+        const size_t recs = (packed && a.packed_adapt) ? std::min<size_t>(tiles_all * groups, kPackedItemTarget) * 64 : tiles_max * groups * 64;
         rc = ensure_group_scratch(ctx, recs, tiles_max);
         if (rc)
             return rc;
@@ -1476,9 +1484,18 @@ extern "C" int rslf_sweep_begin(rslf_ctx* ctx, const rslf_volume* vol, const uin
         int g = kSweepGroups;
         while (g > 1 && dim_d < 2 * kScanWaves * g)
             g /= 2;
+        // (the same choice of kernel as rslf_depth_epi_scan makes for linear interpolation without debug hooks; should it
+        // differ, that call sizes the records itself)
+        const bool in_range = vol->min_value >= 0.0f && vol->max_value <= 1.0e6f;
+        const bool stream = in_range && pick_spad(S, vol->C) == 0 && (size_t)kScanWaves * S * sizeof(float) <= (size_t)48 << 10;
+        const size_t tiles_all = (n + 63) / 64;
+        if (stream)
+            while (g > 1 && tiles_all * g * 64 * sizeof(Partial) > kPartialBudget)
+                g /= 2;
         if (g > 1 && n <= (size_t)INT32_MAX) {
-            rc = ensure_group_scratch(ctx, std::min<size_t>(((n + 63) / 64) * g, kPackedItemTarget) * 64,
-                                      std::min<size_t>((n + 63) / 64, kPackedItemTarget / 2));
+            rc = stream ? ensure_group_scratch(ctx, tiles_all * g * 64, tiles_all)
+                        : ensure_group_scratch(ctx, std::min<size_t>(tiles_all * g, kPackedItemTarget) * 64,
+                                               std::min<size_t>(tiles_all, kPackedItemTarget / 2));
             if (rc)
                 return rc;
         }
