@@ -5,8 +5,9 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/context
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-run() {  # tag, args...
+run() {  # tag, args...   (ONLY=tag runs just that one)
   tag=$1; shift
+  if [ -n "$ONLY" ] && [ "$ONLY" != "$tag" ]; then return 0; fi
   echo "== $tag" >> $OUT/progress.txt
   timeout -k 10 400 python3 $R/bench.py "$@" --steps 2 --warmup 1 > $OUT/$tag.json 2> $OUT/$tag.err || { echo "$tag failed"; tail -3 $OUT/$tag.err; return 1; }
   timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$tag -- python3 $R/bench.py "$@" --steps 2 --warmup 1 > /dev/null 2> $OUT/prof_$tag.err || { echo "$tag profile failed"; return 1; }
