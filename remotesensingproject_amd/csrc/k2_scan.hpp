@@ -136,10 +136,20 @@ __device__ __forceinline__ bool scan_tile(const ScanArgs& a, int lb, int& v, int
     const int n = a.count[v];
     if (j * a.tile_w >= n)
         return false;
+    // 63-entry tiles (streaming kernel, lane 63 left to the shared taps): the row's LAST tile takes up to 64 entries, so
+    // that a row of 63 k + 1 pixels (4096 = 65 * 63 + 1) does not end in a tile of one
+    int width = a.tile_w;
+    if (a.tile_w == 63) {
+        const int T = max(1, (n + 61) / 63);      // tiles of this row: 63 entries each, the last one 1..64
+        if (j >= T)
+            return false;
+        if (j == T - 1)
+            width = n - 63 * j;
+    }
     const int e = j * a.tile_w + lane;
-    active = lane < a.tile_w && e < n;
+    active = lane < width && e < n;
     // idle lanes shadow the tile's last pixel so their addresses stay valid
-    u = a.list[(long long)v * a.vol.U + (active ? e : min(j * a.tile_w + a.tile_w, n) - 1)];
+    u = a.list[(long long)v * a.vol.U + (active ? e : min(j * a.tile_w + width, n) - 1)];
     return true;
 }
 
@@ -1012,7 +1022,8 @@ __device__ __forceinline__ bool wave_is_interior(const ScanArgs& a, int u)
 // form costs about twice the dense one in the re-gathered tail (two loads per sample instead of one shared tap).
 // Runs of hypotheses of the same kind go to one body call, in ascending order (first maximum wins, core.hpp:636-645).
 template <int C, int NRES>
-__device__ __forceinline__ void scan_stream_rows(const ScanArgs& a, int v, int u, int d0, int d1, Best<C>& best, float* otab)
+__device__ __forceinline__ void scan_stream_rows(const ScanArgs& a, int v, int u, bool active, int d0, int d1, Best<C>& best,
+                                                 float* otab)
 {
     if (a.dmin_vu) {
         scan_stream_body<C, true, false, NRES>(a, v, u, d0, d1, best, otab);
@@ -1026,7 +1037,9 @@ __device__ __forceinline__ void scan_stream_rows(const ScanArgs& a, int v, int u
     const int u0 = __builtin_amdgcn_readfirstlane(u), u62 = __builtin_amdgcn_readlane(u, 62);
     const int ln = threadIdx.x & 63;
     const bool consecutive = __all(ln > 62 || u == u0 + ln);
-    const bool dense = a.tile_w == 63 && consecutive && NRES + a.stream_park < a.vol.S;
+    // (a row's last tile may hold a 64th entry, scan_tile: lane 63 is then a pixel of its own and cannot lend itself out)
+    const bool lane63_free = !__any(ln == 63 && active);
+    const bool dense = a.tile_w == 63 && consecutive && lane63_free && NRES + a.stream_park < a.vol.S;
     const int ud = (ln == 63) ? u62 + 1 : u;
     const float max_ds = (float)max(a.s_hat, a.vol.S - 1 - a.s_hat);
     const float range = a.dmax - a.dmin, denom = (float)(a.dim_d - 1);
@@ -1058,13 +1071,13 @@ __global__ __launch_bounds__(64 * kScanWaves) __attribute__((amdgpu_waves_per_eu
     float* otab = s_stream_otab + (size_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * a.stream_wave_floats;
     // packed tiles: lanes sit on different scanlines, offsets are per lane (the <true, false> body)
     if (a.vol.S >= stream_resident_hi(C)) {
-        RSLF_SCAN_KERNEL_BODY((scan_stream_rows<C, stream_resident_hi(C)>(a, v, u, d0, d1, best, otab)),
+        RSLF_SCAN_KERNEL_BODY((scan_stream_rows<C, stream_resident_hi(C)>(a, v, u, active, d0, d1, best, otab)),
                               (scan_stream_body<C, true, false, stream_resident_hi(C)>(a, v, u, d0, d1, best, otab)))
     } else if (stream_resident_lo(C) > 0 && a.vol.S >= stream_resident_lo(C)) {
-        RSLF_SCAN_KERNEL_BODY((scan_stream_rows<C, stream_resident_lo(C)>(a, v, u, d0, d1, best, otab)),
+        RSLF_SCAN_KERNEL_BODY((scan_stream_rows<C, stream_resident_lo(C)>(a, v, u, active, d0, d1, best, otab)),
                               (scan_stream_body<C, true, false, stream_resident_lo(C)>(a, v, u, d0, d1, best, otab)))
     } else {
-        RSLF_SCAN_KERNEL_BODY((scan_stream_rows<C, 0>(a, v, u, d0, d1, best, otab)),
+        RSLF_SCAN_KERNEL_BODY((scan_stream_rows<C, 0>(a, v, u, active, d0, d1, best, otab)),
                               (scan_stream_body<C, true, false, 0>(a, v, u, d0, d1, best, otab)))
     }
 }

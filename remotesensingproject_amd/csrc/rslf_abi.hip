@@ -996,7 +996,8 @@ extern "C" int rslf_depth_epi_scan(rslf_ctx* ctx, const rslf_volume* vol, const 
     a.score = d_score_vu;
     // the streaming kernel's row tiles leave lane 63 to its neighbour's right tap (k2_scan.hpp, DENSE)
     a.tile_w = (use_stream && !packed && ctx->stream_share) ? 63 : 64;
-    a.tiles_per_row = (vol->U + a.tile_w - 1) / a.tile_w;
+    // 63-entry tiles: a row's last tile takes up to 64 entries (scan_tile)
+    a.tiles_per_row = a.tile_w == 63 ? std::max(1, (vol->U + 61) / 63) : (vol->U + a.tile_w - 1) / a.tile_w;
     {
         // largest position the scan can form, and one ulp of it below 1
         int e = 0;

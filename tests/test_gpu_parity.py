@@ -619,3 +619,35 @@ def test_stream_kernel_sparse_list_spanning_62_pixels(rs, oracle_mod, hooks):
     assert np.array_equal(tidx.cpu().numpy(), ref.depth_idx)
     assert np.array_equal(tsc.cpu().numpy(), ref.score)
     assert np.array_equal(trb.cpu().numpy(), ref.rbar)
+
+
+def test_stream_kernel_last_tile_of_a_row_takes_64_entries(rs, oracle_mod, hooks):
+    """63-entry tiles leave lane 63 to its neighbour's right tap; a row's LAST tile takes up to 64 entries instead of
+    ending in a tile of one (4096 = 65 * 63 + 1).  Lists of 64, 65, 127 and 128 consecutive interior pixels: the tile that
+    holds a 64th entry must not share taps (its lane 63 is a pixel of its own), the others do."""
+    import torch
+    hooks(force_scan="stream")
+    rng = np.random.default_rng(11)
+    V, S, U, D = 4, 31, 200, 20
+    vol = rng.uniform(0.05, 1.0, size=(V, S, U, 3)).astype(np.float32)
+    Ce, cm = oracle_mod.edge_confidence_pile(vol, S // 2)
+    mask = np.zeros((V, U), np.uint8)
+    mask[0, 20:84] = 255        # 64: one tile, lane 63 in use
+    mask[1, 20:85] = 255        # 65: 63 + 2
+    mask[2, 20:147] = 255       # 127: 63 + 64
+    mask[3, 20:148] = 255       # 128: 63 + 63 + 2
+    assert cm[:, 20:148].all()
+    ref = oracle_mod.depth_epi_pile(vol, np.full((V, U), -0.5, np.float32), np.full((V, U), 0.5, np.float32), D, S // 2, Ce, cm, mask_vu=mask)
+    v = rs.Volume.from_dense(vol)
+    t = lambda a: torch.from_numpy(a.copy()).cuda()
+    tCe, tcm, tmask = t(Ce), t(cm), t(mask)
+    tCd = torch.zeros((V, U), device="cuda"); td = torch.zeros((V, U), device="cuda"); trb = torch.zeros((V, U, 3), device="cuda")
+    tidx = torch.empty((V, U), dtype=torch.int32, device="cuda"); tsc = torch.empty((V, U), device="cuda")
+    st = rs.compute_1D_depth_epi_pile(v, -0.5, 0.5, D, S // 2, tCe, tcm, tCd, td, trb, None, tmask, idx_v_u=tidx, score_v_u=tsc,
+                                      want_stats=True)
+    torch.cuda.synchronize()
+    assert st.scan_kernel == 2 and st.pixels_scanned == 64 + 65 + 127 + 128
+    assert np.array_equal(tidx.cpu().numpy(), ref.depth_idx)
+    assert np.array_equal(tsc.cpu().numpy(), ref.score)
+    assert np.array_equal(trb.cpu().numpy(), ref.rbar)
+    assert np.array_equal(td.cpu().numpy(), ref.depth)
