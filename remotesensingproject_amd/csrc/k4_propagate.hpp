@@ -107,15 +107,8 @@ __global__ __launch_bounds__(256) void k34_median_claim(VolView vol, int s_hat, 
         return;
     const long long o = (long long)v * vol.U + u;
     // core.hpp:678-679, :881-892: the median over the edge mask, 0 elsewhere
-#ifdef RSLF_PROBE_NO_MEDIAN
-    const float cur = raw_vu[o];
-#else
     const float cur = edge_mask_vu[o] ? selective_median_any<C>(vol, raw_vu, edge_mask_vu, s_hat, size, eps, v, u, cand) : 0.0f;
-#endif
     filtered_vu[o] = cur;
-#ifdef RSLF_PROBE_NO_CLAIM
-    return;
-#endif
     if (gate_Cd_vu ? !(gate_Cd_vu[o] > disp_thr) : !edge_mask_vu[o])   // core.hpp:1097-1103
         return;
     propagate_claim_pixel<C>(vol, s_hat, v, u, cur, rbar_vu, mask_svu, winner_svu, dirty, slope, prop_eps);
