@@ -553,20 +553,38 @@ static int upload_host(rslf_volume* vol, const SrcT* const* h_ptrs, size_t row_s
         const int vn = std::min(chunk, vol->V - v0);
         if (!image_major) {
             // h_ptrs[v] -> S rows; staging [vn][S][U*C]
-            for (int i = 0; i < vn; i++) {
+            for (int i = 0; i < vn; i++)
                 if (!h_ptrs[v0 + i])
                     return fail(RSLF_ERR_INVALID_ARG, "h_epis[%d] is NULL", v0 + i);
-                HIP_TRY(hipMemcpy2DAsync((char*)ctx->staging + (size_t)i * epi_bytes, row_bytes, h_ptrs[v0 + i], row_stride_bytes,
-                                         row_bytes, vol->S, hipMemcpyHostToDevice, ctx->stream));
+            // Dense rows (the usual cv::Mat): an EPI is one run of bytes, and EPIs that follow one another in host memory
+            // (a stacked array) are one run together -- plain 1-D copies, which move pageable memory at the link's rate
+            // (57 GB/s measured, tools/probe_h2d.py) where the 2-D form with its 8 KB rows reached about 10.
+            for (int i = 0; i < vn;) {
+                if (row_stride_bytes != row_bytes) {
+                    HIP_TRY(hipMemcpy2DAsync((char*)ctx->staging + (size_t)i * epi_bytes, row_bytes, h_ptrs[v0 + i], row_stride_bytes,
+                                             row_bytes, vol->S, hipMemcpyHostToDevice, ctx->stream));
+                    i++;
+                    continue;
+                }
+                int n = 1;
+                while (i + n < vn && (const char*)h_ptrs[v0 + i + n] == (const char*)h_ptrs[v0 + i] + (size_t)n * epi_bytes)
+                    n++;
+                HIP_TRY(hipMemcpyAsync((char*)ctx->staging + (size_t)i * epi_bytes, h_ptrs[v0 + i], (size_t)n * epi_bytes,
+                                       hipMemcpyHostToDevice, ctx->stream));
+                i += n;
             }
         } else {
             // h_ptrs[s] -> V rows; staging [S][vn][U*C]
             for (int s = 0; s < vol->S; s++) {
                 if (!h_ptrs[s])
                     return fail(RSLF_ERR_INVALID_ARG, "h_imgs[%d] is NULL", s);
-                HIP_TRY(hipMemcpy2DAsync((char*)ctx->staging + (size_t)s * vn * row_bytes, row_bytes,
-                                         (const char*)h_ptrs[s] + (size_t)v0 * row_stride_bytes, row_stride_bytes, row_bytes, vn,
-                                         hipMemcpyHostToDevice, ctx->stream));
+                if (row_stride_bytes == row_bytes)   // dense rows: one run of bytes (see above)
+                    HIP_TRY(hipMemcpyAsync((char*)ctx->staging + (size_t)s * vn * row_bytes, (const char*)h_ptrs[s] + (size_t)v0 * row_bytes,
+                                           (size_t)vn * row_bytes, hipMemcpyHostToDevice, ctx->stream));
+                else
+                    HIP_TRY(hipMemcpy2DAsync((char*)ctx->staging + (size_t)s * vn * row_bytes, row_bytes,
+                                             (const char*)h_ptrs[s] + (size_t)v0 * row_stride_bytes, row_stride_bytes, row_bytes, vn,
+                                             hipMemcpyHostToDevice, ctx->stream));
             }
         }
         rc = pack_chunk<SrcT>(vol, (const SrcT*)ctx->staging, v0, vn, image_major, scale);
@@ -606,9 +624,13 @@ static int upload_images_xf(rslf_volume* vol, const SrcT* const* h_imgs, size_t 
         for (int i = 0; i < n_imgs; i++) {   // staging [n_imgs][vn][cols*C]
             if (!h_imgs[i])
                 return fail(RSLF_ERR_INVALID_ARG, "h_imgs[%d] is NULL", i);
-            HIP_TRY(hipMemcpy2DAsync((char*)ctx->staging + (size_t)i * vn * row_bytes, row_bytes,
-                                     (const char*)h_imgs[i] + (size_t)v0 * row_stride_bytes, row_stride_bytes, row_bytes, vn,
-                                     hipMemcpyHostToDevice, ctx->stream));
+            if (row_stride_bytes == row_bytes)
+                HIP_TRY(hipMemcpyAsync((char*)ctx->staging + (size_t)i * vn * row_bytes, (const char*)h_imgs[i] + (size_t)v0 * row_bytes,
+                                       (size_t)vn * row_bytes, hipMemcpyHostToDevice, ctx->stream));
+            else
+                HIP_TRY(hipMemcpy2DAsync((char*)ctx->staging + (size_t)i * vn * row_bytes, row_bytes,
+                                         (const char*)h_imgs[i] + (size_t)v0 * row_stride_bytes, row_stride_bytes, row_bytes, vn,
+                                         hipMemcpyHostToDevice, ctx->stream));
         }
         const size_t rows = (size_t)vn * vol->S;
         rc = ensure_partial(ctx, rows);
@@ -1907,8 +1929,11 @@ extern "C" int rslf_fine_to_coarse_run_host(rslf_ctx* ctx, const void* const* h_
         for (int v = 0; v < V; v++) {
             if (!h_epis[v])
                 return fail(RSLF_ERR_INVALID_ARG, "h_epis[%d] is NULL", v);
-            HIP_TRY(hipMemcpy2DAsync((char*)dst + (size_t)v * S * row_bytes, row_bytes, h_epis[v], row_stride_bytes, row_bytes, S,
-                                     hipMemcpyHostToDevice, st));
+            if (row_stride_bytes == row_bytes)   // dense rows: one run of bytes per EPI (upload_host)
+                HIP_TRY(hipMemcpyAsync((char*)dst + (size_t)v * S * row_bytes, h_epis[v], (size_t)S * row_bytes, hipMemcpyHostToDevice, st));
+            else
+                HIP_TRY(hipMemcpy2DAsync((char*)dst + (size_t)v * S * row_bytes, row_bytes, h_epis[v], row_stride_bytes, row_bytes, S,
+                                         hipMemcpyHostToDevice, st));
         }
         if (is_u8) {
             const size_t n = (size_t)V * S * U * C;
@@ -2088,6 +2113,8 @@ struct rslf_multi {
         int vol_rows[2] = {0, 0}, vol_S = 0, vol_U = 0, vol_C = 0;
         char* planes[2] = {nullptr, nullptr};
         size_t planes_cap = 0;
+        char* pin[2] = {nullptr, nullptr};   // pinned host staging for EPIs scattered over the heap (Vec<Mat>)
+        size_t pin_cap = 0;
     };
     std::vector<Dev> devs;
     int chunk_rows = 0;   // 0 = automatic
@@ -2102,6 +2129,7 @@ static void multi_free_dev(rslf_multi::Dev& d)
         if (d.vol[i])
             (void)rslf_volume_destroy(d.vol[i]);
         (void)hipFree(d.planes[i]);
+        (void)hipHostFree(d.pin[i]);
         if (d.done[i])
             (void)hipEventDestroy(d.done[i]);
     }
@@ -2244,14 +2272,54 @@ int multi_worker(rslf_multi::Dev& d, const MultiJob& j, int r0, int r1, int chun
         return RSLF_OK;
     rslf_ctx* ctx = d.ctx;
     MW_HIP(hipSetDevice(ctx->device));
+    // Do the EPIs follow one another in host memory (a stacked array) or are they scattered over the heap (a Vec<Mat>)?
+    const size_t in_row_bytes = (size_t)j.U * j.C * (j.is_u8 ? 1 : sizeof(float));
+    const size_t in_epi_bytes = in_row_bytes * j.S;
+    bool scattered = (j.row_stride_bytes ? j.row_stride_bytes : in_row_bytes) != in_row_bytes;
+    for (int i = r0 + 1; i < r1 && !scattered; i++)
+        scattered = j.h_epis[i] && j.h_epis[i - 1] && (const char*)j.h_epis[i] != (const char*)j.h_epis[i - 1] + in_epi_bytes;
+    // Chunks.  A given size: uniform.  Automatic: a short first chunk so that the kernels start early (its upload is the
+    // one copy nothing hides), then two large ones (stacked input; scattered input, which is gathered into pinned memory
+    // first, takes a middling second chunk and pieces of about V/3.5) -- a chunk's scan is a grid of its own, and a
+    // grid of 5.4 rounds of workgroups pays for 6 (eight equal chunks of a 1080-row field ran 16 % longer than one
+    // launch over the whole field; measured with rocprofv3 on the host-in / host-out path).
     std::vector<Chunk> chunks;
-    for (int a = r0; a < r1; a += chunk_rows) {
-        Chunk c;
-        c.a = a;
-        c.b = std::min(a + chunk_rows, r1);
-        c.lo = std::max(0, c.a - j.halo);
-        c.hi = std::min(j.V, c.b + j.halo);
-        chunks.push_back(c);
+    {
+        std::vector<int> sizes;
+        const int rows = r1 - r0;
+        if (chunk_rows > 0) {
+            for (int a = 0; a < rows; a += chunk_rows)
+                sizes.push_back(std::min(chunk_rows, rows - a));
+        } else {
+            int left = rows;
+            const int first = std::min(left, std::max(32, (rows + 15) / 16));
+            sizes.push_back(first);
+            left -= first;
+            if (left > 0 && scattered) {   // gathered through pinned memory first: smaller steps keep the kernels fed
+                const int second = std::min(left, std::max(32, (rows + 7) / 8));
+                sizes.push_back(second);
+                left -= second;
+            }
+            if (left > 0) {
+                // the chunk before has to cover the next one's upload with its scan
+                const int n = scattered ? std::max(1, (int)std::lround(left / (rows / 3.5))) : (left > 2 * first ? 2 : 1);
+                for (int i = 0; i < n; i++) {
+                    const int sz = (left + (n - i) - 1) / (n - i);
+                    sizes.push_back(sz);
+                    left -= sz;
+                }
+            }
+        }
+        int a = r0;
+        for (int sz : sizes) {
+            Chunk c;
+            c.a = a;
+            c.b = a + sz;
+            c.lo = std::max(0, c.a - j.halo);
+            c.hi = std::min(j.V, c.b + j.halo);
+            chunks.push_back(c);
+            a += sz;
+        }
     }
     int max_rows = 0;
     for (const Chunk& c : chunks)
@@ -2288,6 +2356,21 @@ int multi_worker(rslf_multi::Dev& d, const MultiJob& j, int r0, int r1, int chun
         d.planes_cap = bytes;
     }
     std::vector<int> counts((size_t)max_rows);
+    // pinned staging for scattered EPIs
+    const int pin_threads = std::max(1, std::min(8, (int)std::thread::hardware_concurrency() / 2));
+    {
+        const size_t need = (size_t)max_rows * in_epi_bytes;
+        if (scattered && need > d.pin_cap) {
+            for (int k = 0; k < 2; k++) {
+                (void)hipHostFree(d.pin[k]);
+                d.pin[k] = nullptr;
+            }
+            d.pin_cap = 0;
+            for (int k = 0; k < 2; k++)
+                MW_HIP(hipHostMalloc((void**)&d.pin[k], need, hipHostMallocDefault));
+            d.pin_cap = need;
+        }
+    }
 
     // a volume object of the chunk's height over the (larger or equal) allocation: rows beyond are simply unused
     auto upload = [&](int k) -> int {
@@ -2296,12 +2379,58 @@ int multi_worker(rslf_multi::Dev& d, const MultiJob& j, int r0, int r1, int chun
         vol->V = c.hi - c.lo;
         vol->bytes = (size_t)vol->V * vol->S * vol->C * vol->pitch * sizeof(float);
         ctx->stream = d.s_up;
+        // EPIs that follow one another in host memory go up as they are: one pageable copy per run, at the link's rate.
+        // EPIs scattered over the heap (a Vec<Mat>) would be one pageable copy each, and the runtime stages those through
+        // its own bounce buffer on the calling thread at ~10 GB/s -- slower than the kernels consume them.  They are
+        // gathered into a pinned buffer by a few host threads first (dense rows; ~25 GB/s per thread) and go up from there.
+        const size_t esz = j.is_u8 ? 1 : sizeof(float);
+        const size_t row_bytes = (size_t)j.U * j.C * esz;
+        const size_t stride = j.row_stride_bytes ? j.row_stride_bytes : row_bytes;
+        const size_t epi_bytes = row_bytes * j.S;
+        const int rows = c.hi - c.lo;
+        int runs = 1;
+        for (int i = 1; i < rows; i++)
+            if (stride != row_bytes || (const char*)j.h_epis[c.lo + i] != (const char*)j.h_epis[c.lo + i - 1] + epi_bytes)
+                runs++;
+        const void* const* src = j.h_epis + c.lo;
+        std::vector<const void*> staged;
+        size_t src_stride = j.row_stride_bytes;
+        if (runs > 8 && d.pin[k & 1]) {
+            char* pin = d.pin[k & 1];
+            const int nt = std::max(1, std::min(rows, pin_threads));
+            std::vector<std::thread> th;
+            bool null_epi = false;
+            for (int i = 0; i < rows; i++)
+                null_epi |= j.h_epis[c.lo + i] == nullptr;
+            if (null_epi)
+                return fail(RSLF_ERR_INVALID_ARG, "an EPI pointer is NULL");
+            for (int t = 0; t < nt; t++)
+                th.emplace_back([&, t] {
+                    const int i0 = (int)((long long)rows * t / nt), i1 = (int)((long long)rows * (t + 1) / nt);
+                    for (int i = i0; i < i1; i++) {
+                        const char* e = (const char*)j.h_epis[c.lo + i];
+                        char* o = pin + (size_t)i * epi_bytes;
+                        if (stride == row_bytes)
+                            memcpy(o, e, epi_bytes);
+                        else
+                            for (int r = 0; r < j.S; r++)
+                                memcpy(o + (size_t)r * row_bytes, e + (size_t)r * stride, row_bytes);
+                    }
+                });
+            for (auto& t : th)
+                t.join();
+            staged.resize((size_t)rows);
+            for (int i = 0; i < rows; i++)
+                staged[(size_t)i] = pin + (size_t)i * epi_bytes;
+            src = staged.data();
+            src_stride = row_bytes;
+        }
         int rc;
         if (j.is_u8)
-            rc = upload_host<uint8_t>(vol, (const uint8_t* const*)j.h_epis + c.lo, j.row_stride_bytes, false, (float)(1.0 / 255.0));
+            rc = upload_host<uint8_t>(vol, (const uint8_t* const*)src, src_stride, false, (float)(1.0 / 255.0));
         else
-            rc = upload_host<float>(vol, (const float* const*)j.h_epis + c.lo, j.row_stride_bytes, false, scale_of(j.scale_arg));
-        return rc;   // upload_host ends with a synchronisation of its stream (minmax_end)
+            rc = upload_host<float>(vol, (const float* const*)src, src_stride, false, scale_of(j.scale_arg));
+        return rc;   // upload_host ends with a synchronisation of its stream (minmax_end): the pinned buffer is free again
     };
     auto compute = [&](int k) -> int {
         const Chunk& c = chunks[k];
@@ -2427,8 +2556,7 @@ int multi_run(rslf_multi* m, MultiJob j, rslf_stats* stats)
     for (int i = 0; i < nd; i++) {
         const int r0 = (int)((long long)j.V * i / nd), r1 = (int)((long long)j.V * (i + 1) / nd);
         // chunks: enough of them to overlap the copies with the kernels, large enough to keep the halo's share small
-        int chunk = m->chunk_rows > 0 ? m->chunk_rows : std::max(32, (r1 - r0 + 7) / 8);
-        chunk = std::max(1, std::min(chunk, std::max(1, r1 - r0)));
+        int chunk = m->chunk_rows > 0 ? std::max(1, std::min(m->chunk_rows, std::max(1, r1 - r0))) : 0;   // 0: the graded plan
         th.emplace_back([&, i, r0, r1, chunk] {
             rcs[(size_t)i] = multi_worker(m->devs[(size_t)i], j, r0, r1, chunk, &scanned[(size_t)i], &kern[(size_t)i], &spads[(size_t)i],
                                           &errs[(size_t)i]);

@@ -104,3 +104,25 @@ def test_multi_device_out(rs):
         assert got[k].is_cuda
         assert np.array_equal(got[k].cpu().numpy(), ref[k]), k
     assert m.stats.pixels_scanned == comp.stats.pixels_scanned
+
+
+@pytest.mark.parametrize("C_,dtype", [(1, "f32"), (3, "u8")])
+def test_multi_scattered_epis_and_graded_chunks(rs, C_, dtype):
+    """A Vec<Mat>-like input: every EPI its own allocation (they are gathered into pinned memory by a few host threads
+    before they go up), 150 scanlines so that the automatic chunk plan has several chunks of different heights."""
+    V, S, U, D = 150, 7, 96, 10
+    vol = _field(V, S, U, C_, 31)
+    src = np.round(vol * 255.0).astype(np.uint8) if dtype == "u8" else vol
+    epis = [np.array(src[v] if C_ == 3 else src[v, :, :, 0], copy=True, order="C") for v in range(V)]
+    pad = [np.empty(1000 + 37 * v, np.uint8) for v in range(V)]          # keeps the allocations apart
+    assert any(epis[v + 1].ctypes.data != epis[v].ctypes.data + epis[v].nbytes for v in range(V - 1))
+    m = rs.MultiDevice([0])
+    got = m.depth1d_pile(epis, -1.0, 2.0, D, epi_scale_factor=-1.0 if dtype == "u8" else 1.0)
+    comp = rs.Depth1DComputer_pile(epis, -1.0, 2.0, D, epi_scale_factor=-1.0 if dtype == "u8" else 1.0)
+    comp.run()
+    ref = comp.results()
+    for k in PLANES:
+        assert np.array_equal(got[k], ref[k]), k
+    assert m.stats.pixels_scanned == comp.stats.pixels_scanned
+    m.close()
+    del pad
