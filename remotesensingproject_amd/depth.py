@@ -421,11 +421,14 @@ class MultiDevice:
         dt = first.dtype
         if dt not in (np.uint8, np.float32):
             raise TypeError("EPIs must be uint8 or float32 (dc.hpp:149-154)")
-        keep = [np.ascontiguousarray(e, dtype=dt) for e in epis]   # keeps the buffers alive over the call
+        # keeps the buffers alive over the call; a thousand EPIs: no per-array conversions or ctypes objects where none are needed
+        keep = [e if (type(e) is np.ndarray and e.dtype == dt and e.flags.c_contiguous) else np.ascontiguousarray(e, dtype=dt) for e in epis]
         V = len(keep)
         S, U = keep[0].shape[0], keep[0].shape[1]
         C_ = 1 if keep[0].ndim == 2 else keep[0].shape[2]
-        ptrs = (C.c_void_p * V)(*[e.ctypes.data for e in keep])
+        if any(e.shape != keep[0].shape for e in keep):
+            raise ValueError("every EPI must have the shape of the first, %s" % (keep[0].shape,))
+        ptrs = (C.c_void_p * V)(*[e.__array_interface__["data"][0] for e in keep])
         out = dict(edge_confidence=np.empty((V, U), np.float32), edge_mask=np.empty((V, U), np.uint8),
                    disp_confidence=np.empty((V, U), np.float32), depth=np.empty((V, U), np.float32),
                    rbar=np.empty((V, U, C_), np.float32), depth_idx=np.empty((V, U), np.int32),
