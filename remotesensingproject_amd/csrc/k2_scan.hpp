@@ -576,7 +576,7 @@ __global__ __launch_bounds__(256) void k2_kernel_column(ScanArgs a, const int32_
 #define RSLF_STREAM_GS 8      // samples per batch of the shared-tap tail (a multiple of 4)
 #endif
 #ifndef RSLF_STREAM_NRES_RGB
-#define RSLF_STREAM_NRES_RGB 64
+#define RSLF_STREAM_NRES_RGB 68
 #endif
 #ifndef RSLF_STREAM_NRES_1CH
 #define RSLF_STREAM_NRES_1CH 192
