@@ -221,22 +221,39 @@ __device__ __forceinline__ void combine_tile(const ScanArgs& a, int tile, int v,
 
 // Merge the waves' partial results in hypothesis order (first maximum wins, cv::minMaxLoc) and either
 // write the pixel (groups == 1) or leave this group's record -- the last group to finish merges the records.
+// Where the waves leave their results for wave 0: one block of 64 doubles (score sums) + (3 + C) x 64 floats per wave,
+// 2 KB for RGB.  DYN = false: a static array.  DYN = true (the streaming kernel, whose two workgroups per CU want every
+// byte of the 160 KiB for parked samples): the head of the wave's own dynamic region -- the offset table, dead once the
+// wave's hypotheses are done -- `wave_lds`, the regions `wave_stride` floats apart.
 template <int C>
-__device__ __forceinline__ void scan_epilogue(const ScanArgs& a, int lb, int v, int u, bool active, const Best<C>& mine)
+struct EpilogueBlock {
+    static constexpr int kDoubles = 64 + (3 + C) * 32;
+    double* sum;
+    float *score, *D, *rbar;
+    int* d;
+    __device__ __forceinline__ explicit EpilogueBlock(double* base)
+        : sum(base), score(reinterpret_cast<float*>(base + 64)), D(score + 64), rbar(D + 64), d(reinterpret_cast<int*>(rbar + C * 64)) {}
+};
+
+template <int C, bool DYN = false>
+__device__ __forceinline__ void scan_epilogue(const ScanArgs& a, int lb, int v, int u, bool active, const Best<C>& mine,
+                                              float* wave_lds = nullptr, int wave_stride = 0)
 {
-    __shared__ float s_score[kScanWaves][64];
-    __shared__ float s_D[kScanWaves][64];
-    __shared__ float s_rbar[kScanWaves][C][64];
-    __shared__ int s_d[kScanWaves][64];
-    __shared__ double s_sum[kScanWaves][64];
+    __shared__ double s_static[DYN ? 1 : kScanWaves][DYN ? 1 : EpilogueBlock<C>::kDoubles];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    s_score[wave][lane] = mine.score;
-    s_D[wave][lane] = mine.D;
-    s_d[wave][lane] = mine.d;
-    s_sum[wave][lane] = mine.sum;
+    auto block_of = [&](int w) {
+        return EpilogueBlock<C>(DYN ? reinterpret_cast<double*>(wave_lds + (long long)(w - wave) * wave_stride) : s_static[DYN ? 0 : w]);
+    };
+    {
+        const EpilogueBlock<C> me = block_of(wave);
+        me.score[lane] = mine.score;
+        me.D[lane] = mine.D;
+        me.d[lane] = mine.d;
+        me.sum[lane] = mine.sum;
 #pragma unroll
-    for (int c = 0; c < C; c++)
-        s_rbar[wave][c][lane] = mine.rbar[c];
+        for (int c = 0; c < C; c++)
+            me.rbar[c * 64 + lane] = mine.rbar[c];
+    }
     __syncthreads();
     if (wave != 0) {
         __syncthreads();   // wave 0 has read the arrays: the next item's epilogue may overwrite them
@@ -252,17 +269,18 @@ __device__ __forceinline__ void scan_epilogue(const ScanArgs& a, int lb, int v, 
     double sum = mine.sum;
 #pragma unroll
     for (int w = 1; w < kScanWaves; w++) {
-        const float sc = s_score[w][lane];
-        sum += s_sum[w][lane];
+        const EpilogueBlock<C> o = block_of(w);
+        const float sc = o.score[lane];
+        sum += o.sum[lane];
         // first maximum in hypothesis order: the lower wave holds the lower hypotheses (the index settles a tie
         // all the same).  A wave that scored nothing holds -1 and never wins
-        if (sc > best || (sc == best && s_d[w][lane] < best_d)) {
+        if (sc > best || (sc == best && o.d[lane] < best_d)) {
             best = sc;
-            best_d = s_d[w][lane];
-            best_D = s_D[w][lane];
+            best_d = o.d[lane];
+            best_D = o.D[lane];
 #pragma unroll
             for (int c = 0; c < C; c++)
-                best_rbar[c] = s_rbar[w][c][lane];
+                best_rbar[c] = o.rbar[c * 64 + lane];
         }
     }
     __syncthreads();       // (pairs with the other waves' second barrier)
@@ -500,7 +518,7 @@ __device__ __forceinline__ int packed_groups(int groups, int tiles, int adapt)
                 CHUNK(a, item % a.groups, d0, d1);                                      \
                 best.init();                                                            \
                 PACKED_CALL;                                                            \
-                scan_epilogue<C>(a, item, v, u, active, best);                          \
+                scan_epilogue<C, kEpiDyn>(a, item, v, u, active, best, epi_lds, epi_stride); \
             }                                                                           \
         }                                                                               \
     }
@@ -515,7 +533,7 @@ __device__ __forceinline__ int packed_groups(int groups, int tiles, int adapt)
         CHUNK(a, lb % a.groups, d0, d1);                                                \
         best.init();                                                                    \
         ROWS_CALL;                                                                      \
-        scan_epilogue<C>(a, lb, v, u, active, best);                                    \
+        scan_epilogue<C, kEpiDyn>(a, lb, v, u, active, best, epi_lds, epi_stride);      \
     }
 #define RSLF_SCAN_KERNEL_BODY_(CHUNK, ROWS_CALL, PACKED_CALL)                           \
     if (a.packed) {                                                                     \
@@ -528,6 +546,9 @@ __device__ __forceinline__ int packed_groups(int groups, int tiles, int adapt)
 template <int C>
 __global__ __launch_bounds__(64 * kScanWaves) void k2_scan_generic(ScanArgs a)
 {
+    constexpr bool kEpiDyn = false;
+    float* const epi_lds = nullptr;
+    const int epi_stride = 0;
     RSLF_SCAN_KERNEL_BODY((scan_generic_body<C>(a, v, u, d0, d1, best)), (scan_generic_body<C>(a, v, u, d0, d1, best)))
 }
 
@@ -1069,6 +1090,10 @@ __global__ __launch_bounds__(64 * kScanWaves) __attribute__((amdgpu_waves_per_eu
 {
     extern __shared__ __attribute__((aligned(16))) float s_stream_otab[];   // [kScanWaves][stream_wave_floats]
     float* otab = s_stream_otab + (size_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * a.stream_wave_floats;
+    // the waves' results for the epilogue go to the head of their own regions (EpilogueBlock): no static LDS at all
+    constexpr bool kEpiDyn = true;
+    float* const epi_lds = otab;
+    const int epi_stride = a.stream_wave_floats;
     // packed tiles: lanes sit on different scanlines, offsets are per lane (the <true, false> body)
     if (a.vol.S >= stream_resident_hi(C)) {
         RSLF_SCAN_KERNEL_BODY((scan_stream_rows<C, stream_resident_hi(C)>(a, v, u, active, d0, d1, best, otab)),
@@ -1432,6 +1457,9 @@ void k2_scan_reg(ScanArgs a)
 {
     __shared__ float s_otab[kScanWaves][SPAD];
     float* otab = s_otab[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)];
+    constexpr bool kEpiDyn = false;
+    float* const epi_lds = nullptr;
+    const int epi_stride = 0;
     RSLF_SCAN_ROW_TILE((scan_reg_rows<SPAD, C>(a, v, u, d0, d1, best, otab)))
 }
 
@@ -1450,6 +1478,9 @@ void k2_scan_reg_packed(ScanArgs a)
 {
     // (Tiles whose 64 entries sit on one scanline -- most of them on a visit that scans many pixels -- were also given
     // the row kernel's forms, scalar EPI base and shared offset table: no gain, not kept.)
+    constexpr bool kEpiDyn = false;
+    float* const epi_lds = nullptr;
+    const int epi_stride = 0;
     RSLF_SCAN_PACKED_LOOP((scan_reg_body<SPAD, C, true, false, packed_waves(SPAD, C) == 1, packed_gather_batch(SPAD, C)>(a, v, u, d0, d1, best, nullptr)))
 }
 

@@ -46,7 +46,7 @@ static int fail(int code, const char* fmt, ...)
 
 // Streaming scan kernel: two workgroups per CU (two waves per SIMD) share the CU's 160 KiB of LDS; each has
 // 8 KiB of static LDS (the merge of the four waves' results), so 72 KiB of dynamic LDS per workgroup.
-static constexpr size_t kStreamLdsBytes = (size_t)72 << 10;
+static constexpr size_t kStreamLdsBytes = (size_t)80 << 10;   // two workgroups per CU: all of its 160 KiB (the kernel has no static LDS)
 constexpr int kSweepGroups = 32;    // workgroups sharing a packed tile's hypotheses on a sweep's sparse visits
 // Dense launches of the streaming kernel: this many workgroups share one tile's hypotheses.  The workgroups an
 // XCD runs together then sit on two or three tiles instead of a whole scanline, and what they gather from
@@ -1080,6 +1080,7 @@ extern "C" int rslf_depth_epi_scan(rslf_ctx* ctx, const rslf_volume* vol, const 
         }
         a.stream_park = park;
         a.stream_wave_floats = (int)(s4 + (size_t)park * vol->C * 64);
+        a.stream_wave_floats = std::max(a.stream_wave_floats, 2 * (64 + (3 + vol->C) * 32));   // room for the wave's EpilogueBlock
         lds = (size_t)kScanWaves * a.stream_wave_floats * sizeof(float);
         if (!ctx->stream_attr_set) {   // more than the 64 KiB a kernel gets without asking
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k2_scan_stream<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
