@@ -665,7 +665,9 @@ __device__ __forceinline__ void scan_stream_body(const ScanArgs& a, int v, int u
         // resident prefix: samples [0, NRES) (the kernel picks NRES = stream_resident_for(S, C))
         float Rres[C][NRES > 0 ? NRES : 1];
         int card_res = 0;
-        if constexpr (NRES > 0) {
+        // `shared_tag` (DENSE tiles, regular hypothesis): one texel load per sample, the right tap from lane + 1, as in the tail
+        auto gather_resident = [&](auto shared_tag) {
+            constexpr bool SH = decltype(shared_tag)::value;
             constexpr int GR = (C == 1) ? 8 : 4;
             unsigned rowb = 0;
 #pragma unroll
@@ -692,10 +694,17 @@ __device__ __forceinline__ void scan_stream_body(const ScanArgs& a, int v, int u
                     }
                     const float* p = (const float*)((const char*)epi + (((unsigned)(i0 * C) << 2) + rowb));
                     rowb += stride_b;
+                    if constexpr (SH && C == 3) {
+                        typedef float f3u __attribute__((ext_vector_type(3), aligned(4)));
+                        const f3u t3 = *(const f3u*)p;
+                        e0[0][j] = t3.x, e0[1][j] = t3.y, e0[C - 1][j] = t3.z;
+                    } else {
 #pragma unroll
-                    for (int c = 0; c < C; c++) {
-                        e0[c][j] = p[c];
-                        e1[c][j] = p[C + c];
+                        for (int c = 0; c < C; c++) {
+                            e0[c][j] = p[c];
+                            if (!SH)
+                                e1[c][j] = p[C + c];
+                        }
                     }
                 }
 #pragma unroll
@@ -703,8 +712,11 @@ __device__ __forceinline__ void scan_stream_body(const ScanArgs& a, int v, int u
                     const float omt = 1.0f - tt[j];
 #pragma unroll
                     for (int c = 0; c < C; c++) {
+                        // 0x130 = wave_shl:1: lane i reads lane i + 1, the owner of this lane's right tap
+                        const float right = SH ? __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(e0[c][j]), 0x130, 0xf, 0xf, false))
+                                               : e1[c][j];
                         const float m0 = omt * e0[c][j];
-                        const float m1 = tt[j] * e1[c][j];
+                        const float m1 = tt[j] * right;
                         const float r = m0 + m1;
                         Rres[c][g * GR + j] = ok[j] ? r : kSentinel;
                     }
@@ -718,12 +730,19 @@ __device__ __forceinline__ void scan_stream_body(const ScanArgs& a, int v, int u
                         asm volatile("" : "+v"(Rres[c][g * GR + j]));
                 asm volatile("" : "+s"(rowb));
             }
+        };
+        if constexpr (NRES > 0) {
+            if (DENSE && shared_taps)
+                gather_resident(std::true_type{});
+            else
+                gather_resident(std::false_type{});
         }
         // parked samples [NRES, NRES + npark): gathered once per hypothesis like the resident ones, kept in LDS
         // ([sample][channel][lane], conflict-free) -- one LDS read instead of one gather per pass
         const int npark = (NRES > 0) ? a.stream_park : 0;
         float* park = otab + ((S + 3) & ~3);
-        if (NRES > 0 && npark > 0) {
+        auto gather_parked = [&](auto shared_tag) {
+            constexpr bool SH = decltype(shared_tag)::value;
             constexpr int GP = (C == 1) ? 8 : 4;
             unsigned rowb = (unsigned)NRES * stride_b;
 #pragma unroll 1
@@ -750,10 +769,17 @@ __device__ __forceinline__ void scan_stream_body(const ScanArgs& a, int v, int u
                     }
                     const float* p = (const float*)((const char*)epi + (((unsigned)(i0 * C) << 2) + rowb));
                     rowb += stride_b;
+                    if constexpr (SH && C == 3) {
+                        typedef float f3u __attribute__((ext_vector_type(3), aligned(4)));
+                        const f3u t3 = *(const f3u*)p;
+                        e0[0][j] = t3.x, e0[1][j] = t3.y, e0[C - 1][j] = t3.z;
+                    } else {
 #pragma unroll
-                    for (int c = 0; c < C; c++) {
-                        e0[c][j] = p[c];
-                        e1[c][j] = p[C + c];
+                        for (int c = 0; c < C; c++) {
+                            e0[c][j] = p[c];
+                            if (!SH)
+                                e1[c][j] = p[C + c];
+                        }
                     }
                 }
 #pragma unroll
@@ -761,8 +787,10 @@ __device__ __forceinline__ void scan_stream_body(const ScanArgs& a, int v, int u
                     const float omt = 1.0f - tt[j];
 #pragma unroll
                     for (int c = 0; c < C; c++) {
+                        const float right = SH ? __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(e0[c][j]), 0x130, 0xf, 0xf, false))
+                                               : e1[c][j];
                         const float m0 = omt * e0[c][j];
-                        const float m1 = tt[j] * e1[c][j];
+                        const float m1 = tt[j] * right;
                         const float r = m0 + m1;
                         park[((s0 - NRES + j) * C + c) * 64 + lane] = ok[j] ? r : kSentinel;
                     }
@@ -770,6 +798,12 @@ __device__ __forceinline__ void scan_stream_body(const ScanArgs& a, int v, int u
                         card_res += ok[j] ? 1 : 0;
                 }
             }
+        };
+        if (NRES > 0 && npark > 0) {
+            if (DENSE && shared_taps)
+                gather_parked(std::true_type{});
+            else
+                gather_parked(std::false_type{});
         }
         for (int it = 0; it < a.k.n_iter; it++) {        // core.hpp:584-610
             float A[C];
