@@ -1477,12 +1477,31 @@ template <int SPAD, int C>
 __device__ __forceinline__ void scan_reg_rows(const ScanArgs& a, int v, int u, int d0, int d1, Best<C>& best, float* otab)
 {
     constexpr bool PK = scan_reg_packed_math(SPAD, C);
-    if (wave_is_interior(a, u))
-        scan_reg_body<SPAD, C, false, true, PK>(a, v, u, d0, d1, best, otab);
-    else if (!a.dmin_vu)
-        scan_reg_body<SPAD, C, true, true, PK>(a, v, u, d0, d1, best, otab);
-    else
+    if (a.dmin_vu) {
         scan_reg_body<SPAD, C, true, false, PK>(a, v, u, d0, d1, best, otab);
+        return;
+    }
+    // the validity test is decided per hypothesis, as in the streaming kernel (scan_stream_rows): runs of hypotheses whose
+    // sample lines stay inside the row for every lane take the form without it, in ascending order
+    const float max_ds = (float)max(a.s_hat, a.vol.S - 1 - a.s_hat);
+    const float range = a.dmax - a.dmin, denom = (float)(a.dim_d - 1);
+    const float uf = (float)u, Um1 = (float)(a.vol.U - 1);
+    auto interior = [&](int d) -> bool {
+        const float reach = max_ds * fabsf(hypothesis(a.dmin, range, denom, d)) * fabsf(a.k.slope) + 2.0f;
+        return __all((uf - reach >= 0.0f) && (uf + reach <= Um1));
+    };
+    int d = d0;
+    while (d < d1) {
+        const bool in = interior(d);
+        int e = d + 1;
+        while (e < d1 && interior(e) == in)
+            e++;
+        if (in)
+            scan_reg_body<SPAD, C, false, true, PK>(a, v, u, d, e, best, otab);
+        else
+            scan_reg_body<SPAD, C, true, true, PK>(a, v, u, d, e, best, otab);
+        d = e;
+    }
 }
 
 template <int SPAD, int C>
