@@ -382,6 +382,20 @@ int rslf_fine_to_coarse_run_host(rslf_ctx* ctx, const void* const* h_epis, int i
                                  const rslf_params* p, int max_pyr_depth, int accept_all_last_scale,
                                  float* h_out_map_svu, uint8_t* h_out_valid_svu, int* n_levels, rslf_stats* stats);
 
+/* Depth2DComputer<T>'s constructor + run() + getters (rslf_depth_computation.hpp:651-805) over the context's devices,
+ * host EPIs in, host [S][V][U] planes out.  The 2-D sweep is cut into one block of scanlines per device; every visit
+ * exchanges the neighbours' boundary rows (median reach) of the visited view's raw disparities and edge mask by peer
+ * copy between the scan and the median -- the one exchange step of the path.  One host thread queues the work of all
+ * devices; events keep the order.  Planes may be NULL (not wanted).  Bit-identical to rslf_depth2d_run on one volume. */
+int rslf_multi_depth2d_run_f32(rslf_multi* m, const float* const* h_epis, size_t row_stride_bytes, int V, int S, int U, int C,
+                               float epi_scale_factor, float dmin, float dmax, int dim_d, const rslf_params* p,
+                               float* h_Ce_svu, uint8_t* h_Ce_mask_svu, float* h_Cd_svu, float* h_depth_svu,
+                               float* h_rbar_svu, uint8_t* h_scan_mask_svu, rslf_stats* stats, float* scale_used);
+int rslf_multi_depth2d_run_u8(rslf_multi* m, const uint8_t* const* h_epis, size_t row_stride_bytes, int V, int S, int U, int C,
+                              float dmin, float dmax, int dim_d, const rslf_params* p, float* h_Ce_svu,
+                              uint8_t* h_Ce_mask_svu, float* h_Cd_svu, float* h_depth_svu, float* h_rbar_svu,
+                              uint8_t* h_scan_mask_svu, rslf_stats* stats);
+
 /* ---- measurement ------------------------------------------------------ */
 /* Duration in milliseconds of the last scan-kernel launch (K2) of this
  * context, from HIP events recorded on the context's stream around that

@@ -348,16 +348,27 @@ public:
     Depth2DComputer(Context& ctx, const void* const* epis, bool is_u8, int dim_v, int dim_s, int dim_u, size_t row_stride_bytes,
                     float dmin, float dmax, int dim_d, float epi_scale_factor = -1,
                     const Depth1DParameters& parameters = Depth1DParameters::get_default())
-        : ctx_(ctx), vol_(nullptr), dim_v_(dim_v), dim_s_(dim_s), dim_u_(dim_u), m_dim_d(dim_d), m_dmin(dmin), m_dmax(dmax),
-          m_parameters(parameters)
+        : ctx_(&ctx), multi_(nullptr), vol_(nullptr), is_u8_(is_u8), stride_(row_stride_bytes), scale_(epi_scale_factor), dim_v_(dim_v),
+          dim_s_(dim_s), dim_u_(dim_u), m_dim_d(dim_d), m_dmin(dmin), m_dmax(dmax), m_parameters(parameters)
     {
         stats = rslf_stats();
-        check(rslf_volume_create(ctx_.get(), dim_v, dim_s, dim_u, CHANNELS, &vol_), "rslf_volume_create");
+        check(rslf_volume_create(ctx_->get(), dim_v, dim_s, dim_u, CHANNELS, &vol_), "rslf_volume_create");
         if (is_u8)
             check(rslf_volume_upload_epis_u8(vol_, (const uint8_t* const*)epis, row_stride_bytes), "rslf_volume_upload_epis_u8");
         else
             check(rslf_volume_upload_epis_f32(vol_, (const float* const*)epis, row_stride_bytes, epi_scale_factor, nullptr),
                   "rslf_volume_upload_epis_f32");
+    }
+    // The same on a MultiContext: the sweep is cut into one block of scanlines per device, the neighbours' boundary rows
+    // exchanged by peer copy on every visit (rslf_multi_depth2d_run_*).  The EPIs are read by run(): they must outlive it.
+    Depth2DComputer(MultiContext& multi, const void* const* epis, bool is_u8, int dim_v, int dim_s, int dim_u, size_t row_stride_bytes,
+                    float dmin, float dmax, int dim_d, float epi_scale_factor = -1,
+                    const Depth1DParameters& parameters = Depth1DParameters::get_default())
+        : ctx_(nullptr), multi_(&multi), vol_(nullptr), epis_(epis, epis + dim_v), is_u8_(is_u8), stride_(row_stride_bytes),
+          scale_(epi_scale_factor), dim_v_(dim_v), dim_s_(dim_s), dim_u_(dim_u), m_dim_d(dim_d), m_dmin(dmin), m_dmax(dmax),
+          m_parameters(parameters)
+    {
+        stats = rslf_stats();
     }
     ~Depth2DComputer() { rslf_volume_destroy(vol_); }
     Depth2DComputer(const Depth2DComputer&) = delete;
@@ -372,7 +383,22 @@ public:
         m_best_depth_s_v_u.assign(n, 0.f);
         m_rbar_s_v_u.assign(n * CHANNELS, 0.f);
         const rslf_params p = m_parameters.to_c();
-        check(rslf_depth2d_run_host(ctx_.get(), vol_, m_dmin, m_dmax, m_dim_d, &p, m_edge_confidence_s_v_u.data(),
+        if (multi_) {
+            if (is_u8_)
+                check(rslf_multi_depth2d_run_u8(multi_->get(), (const uint8_t* const*)epis_.data(), stride_, dim_v_, dim_s_, dim_u_, CHANNELS,
+                                                m_dmin, m_dmax, m_dim_d, &p, m_edge_confidence_s_v_u.data(),
+                                                m_edge_confidence_mask_s_v_u.data(), m_disp_confidence_s_v_u.data(),
+                                                m_best_depth_s_v_u.data(), m_rbar_s_v_u.data(), nullptr, &stats),
+                      "rslf_multi_depth2d_run_u8");
+            else
+                check(rslf_multi_depth2d_run_f32(multi_->get(), (const float* const*)epis_.data(), stride_, dim_v_, dim_s_, dim_u_, CHANNELS,
+                                                 scale_, m_dmin, m_dmax, m_dim_d, &p, m_edge_confidence_s_v_u.data(),
+                                                 m_edge_confidence_mask_s_v_u.data(), m_disp_confidence_s_v_u.data(),
+                                                 m_best_depth_s_v_u.data(), m_rbar_s_v_u.data(), nullptr, &stats, nullptr),
+                      "rslf_multi_depth2d_run_f32");
+            return;
+        }
+        check(rslf_depth2d_run_host(ctx_->get(), vol_, m_dmin, m_dmax, m_dim_d, &p, m_edge_confidence_s_v_u.data(),
                                     m_edge_confidence_mask_s_v_u.data(), m_disp_confidence_s_v_u.data(),
                                     m_best_depth_s_v_u.data(), m_rbar_s_v_u.data(), &stats),
               "rslf_depth2d_run_host");
@@ -387,8 +413,13 @@ public:
     rslf_stats stats;
 
 private:
-    Context& ctx_;
+    Context* ctx_;
+    MultiContext* multi_;
     rslf_volume* vol_;
+    std::vector<const void*> epis_;
+    bool is_u8_;
+    size_t stride_;
+    float scale_;
     int dim_v_, dim_s_, dim_u_, m_dim_d;
     float m_dmin, m_dmax;
     const Depth1DParameters m_parameters;

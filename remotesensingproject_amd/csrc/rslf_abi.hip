@@ -2635,3 +2635,246 @@ extern "C" int rslf_multi_depth1d_pile_u8(rslf_multi* m, const uint8_t* const* h
                   h_Ce_vu, h_Ce_mask_vu, h_Cd_vu, h_depth_vu, h_rbar_vu, h_idx_vu, h_score_vu, h_depth_raw_vu, 0, -1};
     return multi_run(m, j, stats);
 }
+
+// ---- Depth2DComputer::run over several devices (dc.hpp:748-805) -----------------------------------------------------
+// The 2-D sweep sharded by scanline behind the C-ABI: every device holds a block of scanlines (+ the median's halo) of the
+// volume and of the [S][rows][U] planes; a visit is scan on every device, then the neighbours' boundary rows of the visited
+// view's raw disparities and edge mask by peer copy (the one real exchange step of the path, as sharding.ShardedDepth2D
+// does it over RCCL), then median + propagation on every device.  ONE host thread drives all devices: every call only
+// queues work, the order between devices is kept by events -- a device's finish waits for its neighbours to have
+// fetched its boundary rows, because the apply pass rewrites them (core.hpp:1119-1121).
+namespace {
+
+struct Sweep2DDev {
+    rslf_volume* vol = nullptr;
+    float *Ce = nullptr, *Cd = nullptr, *depth = nullptr, *rbar = nullptr;
+    uint8_t *cem = nullptr, *scan_mask = nullptr;
+    int lo = 0, hi = 0, a = 0, b = 0;   // rows held [lo, hi), rows owned [a, b)
+    hipEvent_t ev_scan = nullptr, ev_fetch = nullptr;
+    bool begun = false;
+    hipStream_t saved_stream = nullptr;
+    bool stream_swapped = false;
+};
+
+void sweep2d_free(rslf_multi* m, std::vector<Sweep2DDev>& ds)
+{
+    for (size_t i = 0; i < ds.size(); i++) {
+        Sweep2DDev& d = ds[i];
+        rslf_ctx* ctx = m->devs[i].ctx;
+        (void)hipSetDevice(ctx->device);
+        if (d.begun)
+            (void)rslf_sweep_end(ctx, 0, 2, nullptr);
+        (void)hipStreamSynchronize(ctx->stream);
+        if (d.stream_swapped)
+            ctx->stream = d.saved_stream;
+        if (d.vol)
+            (void)rslf_volume_destroy(d.vol);
+        (void)hipFree(d.Ce);
+        (void)hipFree(d.Cd);
+        (void)hipFree(d.depth);
+        (void)hipFree(d.rbar);
+        (void)hipFree(d.cem);
+        (void)hipFree(d.scan_mask);
+        if (d.ev_scan)
+            (void)hipEventDestroy(d.ev_scan);
+        if (d.ev_fetch)
+            (void)hipEventDestroy(d.ev_fetch);
+    }
+}
+
+int multi_depth2d(rslf_multi* m, const void* const* h_epis, bool is_u8, size_t row_stride_bytes, int V, int S, int U, int C, float scale_arg,
+                  float dmin, float dmax, int dim_d, const rslf_params* p, float* h_Ce_svu, uint8_t* h_Ce_mask_svu, float* h_Cd_svu,
+                  float* h_depth_svu, float* h_rbar_svu, uint8_t* h_scan_mask_svu, rslf_stats* stats)
+{
+    if (!m || !h_epis)
+        return fail(RSLF_ERR_INVALID_ARG, "NULL argument");
+    if (V < 1 || S < 1 || U < 1 || (C != 1 && C != 3))
+        return fail(RSLF_ERR_INVALID_ARG, "bad dimensions V=%d S=%d U=%d C=%d", V, S, U, C);
+    int rc = check_params(p);
+    if (rc)
+        return rc;
+    for (int v = 0; v < V; v++)
+        if (!h_epis[v])
+            return fail(RSLF_ERR_INVALID_ARG, "h_epis[%d] is NULL", v);
+    const int h_med = (p->median_filter_size - 1) / 2;
+    const int halo = h_med + (p->edge_confidence_opening_size > 1 ? 2 * (p->edge_confidence_opening_size / 2) : 0);
+    int nd = (int)m->devs.size();
+    while (nd > 1 && V / nd < std::max(1, halo))   // a block must be able to fill its neighbours' halo rows
+        nd--;
+    std::vector<Sweep2DDev> ds((size_t)nd);
+#define S2_TRY(expr)                                  \
+    do {                                              \
+        int rc_ = (expr);                             \
+        if (rc_ != RSLF_OK) {                         \
+            const std::string msg_ = g_err;           \
+            sweep2d_free(m, ds);                      \
+            return fail(rc_, "%s", msg_.c_str());     \
+        }                                             \
+    } while (0)
+#define S2_HIP(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) {                                                                        \
+            sweep2d_free(m, ds);                                                                       \
+            return fail(RSLF_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+        }                                                                                              \
+    } while (0)
+    // set-up: rows, volume, planes, edge confidence, sweep state
+    for (int i = 0; i < nd; i++) {
+        Sweep2DDev& d = ds[(size_t)i];
+        rslf_ctx* ctx = m->devs[(size_t)i].ctx;
+        S2_HIP(hipSetDevice(ctx->device));
+        d.saved_stream = ctx->stream;
+        d.stream_swapped = true;
+        ctx->stream = m->devs[(size_t)i].s_comp;
+        d.a = (int)((long long)V * i / nd);
+        d.b = (int)((long long)V * (i + 1) / nd);
+        d.lo = std::max(0, d.a - halo);
+        d.hi = std::min(V, d.b + halo);
+        const int rows = d.hi - d.lo;
+        const size_t n = (size_t)S * rows * U;
+        S2_HIP(hipEventCreateWithFlags(&d.ev_scan, hipEventDisableTiming));
+        S2_HIP(hipEventCreateWithFlags(&d.ev_fetch, hipEventDisableTiming));
+        S2_TRY(rslf_volume_create(ctx, rows, S, U, C, &d.vol));
+        if (is_u8)
+            S2_TRY(upload_host<uint8_t>(d.vol, (const uint8_t* const*)h_epis + d.lo, row_stride_bytes, false, (float)(1.0 / 255.0)));
+        else
+            S2_TRY(upload_host<float>(d.vol, (const float* const*)h_epis + d.lo, row_stride_bytes, false, scale_of(scale_arg)));
+        S2_HIP(hipMalloc(&d.Ce, n * sizeof(float)));
+        S2_HIP(hipMalloc(&d.Cd, n * sizeof(float)));
+        S2_HIP(hipMalloc(&d.depth, n * sizeof(float)));
+        S2_HIP(hipMalloc(&d.rbar, n * C * sizeof(float)));
+        S2_HIP(hipMalloc(&d.cem, n));
+        S2_HIP(hipMalloc(&d.scan_mask, n));
+        hipStream_t st = ctx->stream;
+        S2_HIP(hipMemsetAsync(d.Ce, 0, n * sizeof(float), st));   // dc.hpp:733-750
+        S2_HIP(hipMemsetAsync(d.Cd, 0, n * sizeof(float), st));
+        S2_HIP(hipMemsetAsync(d.depth, 0, n * sizeof(float), st));
+        S2_HIP(hipMemsetAsync(d.rbar, 0, n * C * sizeof(float), st));
+        S2_TRY(rslf_edge_confidence_2d(ctx, d.vol, p, d.Ce, d.cem));                               // dc.hpp:772
+        S2_TRY(rslf_sweep_begin(ctx, d.vol, d.cem, d.scan_mask, dim_d, d.a - d.lo, d.b - d.lo));  // dc.hpp:780
+        d.begun = true;
+    }
+    // rows of plane `base` ([S][rows][U] elements of `esz` bytes) of view s_hat, local rows [r, r + h)
+    auto rows_of = [&](const Sweep2DDev& d, void* base, size_t esz, int s_hat, int r) -> char* {
+        return (char*)base + (((size_t)s_hat * (d.hi - d.lo) + r) * U) * esz;
+    };
+    for (int s_hat : sweep_order(S)) {   // core.hpp:981-990
+        for (int i = 0; i < nd; i++) {
+            Sweep2DDev& d = ds[(size_t)i];
+            rslf_ctx* ctx = m->devs[(size_t)i].ctx;
+            S2_HIP(hipSetDevice(ctx->device));
+            S2_TRY(rslf_sweep_visit_scan(ctx, d.vol, nullptr, nullptr, dmin, dmax, dim_d, s_hat, d.Ce, d.cem, d.Cd, d.depth, d.rbar, p));
+            S2_HIP(hipEventRecord(d.ev_scan, ctx->stream));
+        }
+        for (int i = 0; i < nd; i++) {   // fetch the neighbours' boundary rows into this device's halo rows
+            Sweep2DDev& d = ds[(size_t)i];
+            rslf_ctx* ctx = m->devs[(size_t)i].ctx;
+            S2_HIP(hipSetDevice(ctx->device));
+            for (int side = 0; side < 2 && h_med > 0; side++) {
+                const int k = side == 0 ? i - 1 : i + 1;
+                if (k < 0 || k >= nd)
+                    continue;
+                const Sweep2DDev& o = ds[(size_t)k];
+                rslf_ctx* octx = m->devs[(size_t)k].ctx;
+                S2_HIP(hipStreamWaitEvent(ctx->stream, o.ev_scan, 0));
+                // side 0: the h rows above my block = the last h own rows of device i-1; side 1: the first h own rows of i+1
+                const int dst_r = side == 0 ? (d.a - d.lo) - h_med : (d.b - d.lo);
+                const int src_r = side == 0 ? (o.b - o.lo) - h_med : (o.a - o.lo);
+                for (int pl = 0; pl < 2; pl++) {
+                    const size_t esz = pl == 0 ? sizeof(float) : 1;
+                    char* dst = rows_of(d, pl == 0 ? (void*)d.depth : (void*)d.cem, esz, s_hat, dst_r);
+                    const char* src = rows_of(o, pl == 0 ? (void*)o.depth : (void*)o.cem, esz, s_hat, src_r);
+                    const size_t bytes = (size_t)h_med * U * esz;
+                    if (octx->device == ctx->device)
+                        S2_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+                    else
+                        S2_HIP(hipMemcpyPeerAsync(dst, ctx->device, src, octx->device, bytes, ctx->stream));
+                }
+            }
+            S2_HIP(hipEventRecord(d.ev_fetch, ctx->stream));
+        }
+        for (int i = 0; i < nd; i++) {   // median + propagation, once the neighbours have my raw boundary rows
+            Sweep2DDev& d = ds[(size_t)i];
+            rslf_ctx* ctx = m->devs[(size_t)i].ctx;
+            S2_HIP(hipSetDevice(ctx->device));
+            if (i > 0)
+                S2_HIP(hipStreamWaitEvent(ctx->stream, ds[(size_t)i - 1].ev_fetch, 0));
+            if (i + 1 < nd)
+                S2_HIP(hipStreamWaitEvent(ctx->stream, ds[(size_t)i + 1].ev_fetch, 0));
+            S2_TRY(rslf_sweep_visit_finish(ctx, d.vol, s_hat, d.cem, d.Cd, d.depth, d.rbar, p));
+        }
+    }
+    // collect: every device's own rows of every view land at their place in the caller's [S][V][U] planes
+    long long scanned = 0;
+    for (int i = 0; i < nd; i++) {
+        Sweep2DDev& d = ds[(size_t)i];
+        rslf_ctx* ctx = m->devs[(size_t)i].ctx;
+        S2_HIP(hipSetDevice(ctx->device));
+        rslf_stats st_i;
+        memset(&st_i, 0, sizeof(st_i));
+        d.begun = false;
+        S2_TRY(rslf_sweep_end(ctx, 1, dim_d, &st_i));
+        scanned += st_i.pixels_scanned;
+        if (stats && i == 0) {
+            stats->scan_kernel = st_i.scan_kernel;
+            stats->s_pad = st_i.s_pad;
+        }
+        const int rows = d.hi - d.lo, own = d.b - d.a;
+        auto pull = [&](void* h, const void* dv, size_t esz) -> hipError_t {
+            if (!h)
+                return hipSuccess;
+            return hipMemcpy2DAsync((char*)h + (size_t)d.a * U * esz, (size_t)V * U * esz, (const char*)dv + (size_t)(d.a - d.lo) * U * esz,
+                                    (size_t)rows * U * esz, (size_t)own * U * esz, S, hipMemcpyDeviceToHost, ctx->stream);
+        };
+        S2_HIP(pull(h_Ce_svu, d.Ce, sizeof(float)));
+        S2_HIP(pull(h_Ce_mask_svu, d.cem, 1));
+        S2_HIP(pull(h_Cd_svu, d.Cd, sizeof(float)));
+        S2_HIP(pull(h_depth_svu, d.depth, sizeof(float)));
+        S2_HIP(pull(h_rbar_svu, d.rbar, sizeof(float) * C));
+        S2_HIP(pull(h_scan_mask_svu, d.scan_mask, 1));
+    }
+    for (int i = 0; i < nd; i++) {
+        S2_HIP(hipSetDevice(m->devs[(size_t)i].ctx->device));
+        S2_HIP(hipStreamSynchronize(m->devs[(size_t)i].ctx->stream));
+    }
+    sweep2d_free(m, ds);
+    if (stats) {
+        stats->pixels_scanned = scanned;
+        stats->units = scanned * dim_d;
+    }
+    return RSLF_OK;
+#undef S2_TRY
+#undef S2_HIP
+}
+
+}  // namespace
+
+extern "C" int rslf_multi_depth2d_run_f32(rslf_multi* m, const float* const* h_epis, size_t row_stride_bytes, int V, int S, int U, int C,
+                                          float epi_scale_factor, float dmin, float dmax, int dim_d, const rslf_params* p,
+                                          float* h_Ce_svu, uint8_t* h_Ce_mask_svu, float* h_Cd_svu, float* h_depth_svu,
+                                          float* h_rbar_svu, uint8_t* h_scan_mask_svu, rslf_stats* stats, float* scale_used)
+{
+    if (!m || !h_epis || V < 1 || S < 1 || U < 1)
+        return fail(RSLF_ERR_INVALID_ARG, "NULL argument");
+    const size_t row_elems = (size_t)U * C;
+    const size_t stride = row_stride_bytes ? row_stride_bytes : row_elems * sizeof(float);
+    for (int v = 0; v < V; v++)
+        if (!h_epis[v])
+            return fail(RSLF_ERR_INVALID_ARG, "h_epis[%d] is NULL", v);
+    if (epi_scale_factor < 0)   // dc.hpp:671-705: the maximum over ALL EPIs, taken once
+        epi_scale_factor = host_max_f32_parallel(h_epis, V, S, stride, row_elems, epi_scale_factor);
+    if (scale_used)
+        *scale_used = epi_scale_factor;
+    return multi_depth2d(m, (const void* const*)h_epis, false, stride, V, S, U, C, epi_scale_factor, dmin, dmax, dim_d, p, h_Ce_svu,
+                         h_Ce_mask_svu, h_Cd_svu, h_depth_svu, h_rbar_svu, h_scan_mask_svu, stats);
+}
+
+extern "C" int rslf_multi_depth2d_run_u8(rslf_multi* m, const uint8_t* const* h_epis, size_t row_stride_bytes, int V, int S, int U, int C,
+                                         float dmin, float dmax, int dim_d, const rslf_params* p, float* h_Ce_svu,
+                                         uint8_t* h_Ce_mask_svu, float* h_Cd_svu, float* h_depth_svu, float* h_rbar_svu,
+                                         uint8_t* h_scan_mask_svu, rslf_stats* stats)
+{
+    return multi_depth2d(m, (const void* const*)h_epis, true, row_stride_bytes, V, S, U, C, 255.0f, dmin, dmax, dim_d, p, h_Ce_svu,
+                         h_Ce_mask_svu, h_Cd_svu, h_depth_svu, h_rbar_svu, h_scan_mask_svu, stats);
+}

@@ -451,6 +451,41 @@ class MultiDevice:
         self.stats = st
         return out
 
+    def depth2d(self, epis: Sequence[np.ndarray], dmin: float, dmax: float, dim_d: int, epi_scale_factor: float = -1.0,
+                parameters: Depth1DParameters | None = None) -> dict:
+        """Depth2DComputer (constructor + run + getters) over this object's devices: the 2-D sweep cut into one block of
+        scanlines per device, the neighbours' boundary rows exchanged by peer copy on every visit
+        (rslf_multi_depth2d_run_f32 / _u8).  Host EPIs in, numpy planes [S, V, U] out."""
+        first = np.asarray(epis[0])
+        dt = first.dtype
+        if dt not in (np.uint8, np.float32):
+            raise TypeError("EPIs must be uint8 or float32 (dc.hpp:149-154)")
+        keep = [e if (type(e) is np.ndarray and e.dtype == dt and e.flags.c_contiguous) else np.ascontiguousarray(e, dtype=dt) for e in epis]
+        V = len(keep)
+        S, U = keep[0].shape[0], keep[0].shape[1]
+        C_ = 1 if keep[0].ndim == 2 else keep[0].shape[2]
+        if any(e.shape != keep[0].shape for e in keep):
+            raise ValueError("every EPI must have the shape of the first, %s" % (keep[0].shape,))
+        ptrs = (C.c_void_p * V)(*[e.__array_interface__["data"][0] for e in keep])
+        out = dict(edge_confidence=np.empty((S, V, U), np.float32), edge_mask=np.empty((S, V, U), np.uint8),
+                   disp_confidence=np.empty((S, V, U), np.float32), depth=np.empty((S, V, U), np.float32),
+                   rbar=np.empty((S, V, U, C_), np.float32), scan_mask=np.empty((S, V, U), np.uint8))
+        hp = [out[k].ctypes.data_as(C.c_void_p) for k in ("edge_confidence", "edge_mask", "disp_confidence", "depth", "rbar", "scan_mask")]
+        p = (parameters or Depth1DParameters()).to_c()
+        st = RslfStats()
+        L = _lib.lib()
+        if dt == np.uint8:
+            check(L.rslf_multi_depth2d_run_u8(self._h, ptrs, 0, V, S, U, C_, float(dmin), float(dmax), int(dim_d), C.byref(p), *hp,
+                                              C.byref(st)), "rslf_multi_depth2d_run_u8")
+            self.scale_used = 255.0
+        else:
+            su = C.c_float()
+            check(L.rslf_multi_depth2d_run_f32(self._h, ptrs, 0, V, S, U, C_, float(epi_scale_factor), float(dmin), float(dmax),
+                                               int(dim_d), C.byref(p), *hp, C.byref(st), C.byref(su)), "rslf_multi_depth2d_run_f32")
+            self.scale_used = float(su.value)
+        self.stats = st
+        return out
+
     def depth1d_pile_device_out(self, epis: Sequence[np.ndarray], dmin: float, dmax: float, dim_d: int, out_device: int = 0,
                                 s_hat: int = -1, epi_scale_factor: float = -1.0, parameters: Depth1DParameters | None = None) -> dict:
         """The same with the result planes left on `out_device` as CUDA tensors (float32 EPIs): every worker copies its

@@ -102,6 +102,16 @@ static int run_sweeps(rslfx::Context& ctx, const std::string& dir)
     dump(dir + "/f2c_valid.u8", valid);
     std::printf("sweeps: Depth2DComputer scanned %lld px, FineToCoarse %d levels, %lld px\n", (long long)d2.stats.pixels_scanned,
                 f2c.pyramid_depth(), (long long)f2c.stats.pixels_scanned);
+    // the sweep over a MultiContext (three workers on the one GPU, a neighbour exchange per visit): identical planes
+    rslfx::MultiContext multi(std::vector<int>(3, 0));
+    rslfx::Depth2DComputer<1> d2m(multi, ptrs.data(), false, V, S, U, 0, -1.0f, 1.0f, D);
+    d2m.run();
+    const bool same = d2m.get_depths_s_v_u() == d2.get_depths_s_v_u() && d2m.m_edge_confidence_mask_s_v_u == d2.m_edge_confidence_mask_s_v_u &&
+                      d2m.m_edge_confidence_s_v_u == d2.m_edge_confidence_s_v_u && d2m.m_disp_confidence_s_v_u == d2.m_disp_confidence_s_v_u &&
+                      d2m.m_rbar_s_v_u == d2.m_rbar_s_v_u && d2m.stats.pixels_scanned == d2.stats.pixels_scanned;
+    std::printf("sweeps: Depth2DComputer over %d workers: %s\n", multi.device_count(), same ? "planes identical" : "MISMATCH");
+    if (!same)
+        return 32;
     return f2c.pyramid_depth() == 3 ? 0 : 8;   // 44x64 -> 22x32 -> 11x16, then 6x8 stops the pyramid
 }
 

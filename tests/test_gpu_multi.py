@@ -126,3 +126,40 @@ def test_multi_scattered_epis_and_graded_chunks(rs, C_, dtype):
     assert m.stats.pixels_scanned == comp.stats.pixels_scanned
     m.close()
     del pad
+
+
+@pytest.mark.parametrize("devices,C_,dtype,V", [([0], 1, "f32", 21), ([0, 0], 1, "f32max", 24), ([0, 0, 0], 3, "u8", 31), ([0, 0, 0, 0], 1, "f32", 40)])
+def test_multi_depth2d_equals_single_volume(rs, devices, C_, dtype, V):
+    """The 2-D sweep behind the C-ABI over several devices (here: several contexts on the one GPU): scanline blocks with
+    the median's halo, the neighbours' boundary rows fetched by copy on every visit between the scan and the median,
+    events for the order -- every plane of every view equals Depth2DComputer's on one volume, bit for bit."""
+    S, U, D = 5, 70, 12
+    vol = _field(V, S, U, C_, 40 + V)
+    rng = np.random.default_rng(V)
+    vol[V // 3:V // 3 + 4] = rng.uniform(0.0, 1.0, size=vol[V // 3:V // 3 + 4].shape).astype(np.float32)   # noise across a cut
+    if dtype == "u8":
+        raw = np.round(vol * 255.0).astype(np.uint8)
+        scale = -1.0
+    elif dtype == "f32max":
+        raw = (vol * np.float32(97.0)).astype(np.float32)
+        raw[: V // 2] *= np.float32(0.5)
+        scale = -1.0
+    else:
+        raw, scale = vol, 1.0
+    epis = [raw[v] if C_ == 3 else raw[v, :, :, 0] for v in range(V)]
+    m = rs.MultiDevice(devices)
+    got = m.depth2d(epis, -1.0, 2.0, D, epi_scale_factor=scale)
+    comp = rs.Depth2DComputer(epis, -1.0, 2.0, D, epi_scale_factor=scale)
+    comp.run()
+    ref = comp.results()
+    for k in ref:
+        assert np.array_equal(got[k], ref[k]), k
+    assert m.stats.pixels_scanned == comp.stats.pixels_scanned
+    if dtype == "f32max":
+        assert m.scale_used == float(raw.max())
+    # the context is fit for the pile path afterwards (streams and sweep state restored)
+    again = m.depth1d_pile(epis, -1.0, 2.0, D, epi_scale_factor=scale)
+    pile = rs.Depth1DComputer_pile(epis, -1.0, 2.0, D, epi_scale_factor=scale)
+    pile.run()
+    assert np.array_equal(again["depth"], pile.results()["depth"])
+    m.close()
