@@ -396,6 +396,15 @@ int rslf_multi_depth2d_run_u8(rslf_multi* m, const uint8_t* const* h_epis, size_
                               uint8_t* h_Ce_mask_svu, float* h_Cd_svu, float* h_depth_svu, float* h_rbar_svu,
                               uint8_t* h_scan_mask_svu, rslf_stats* stats);
 
+/* FineToCoarse<T>'s constructor + run() + get_results() (rslf_fine_to_coarse.hpp:103-324) over the context's devices:
+ * every level's 2-D sweep runs sharded as in rslf_multi_depth2d_run_* (with the level's tightened per-pixel ranges); the
+ * pyramid, the bound tightening and the fusion run on the first device, the levels' planes passing through host memory.
+ * Arguments and results as rslf_fine_to_coarse_run_host; bit-identical to it. */
+int rslf_multi_fine_to_coarse_run_host(rslf_multi* m, const void* const* h_epis, int is_u8, int V, int S, int U, int C,
+                                       size_t row_stride_bytes, float d_min, float d_max, int dim_d, float epi_scale_factor,
+                                       const rslf_params* p, int max_pyr_depth, int accept_all_last_scale,
+                                       float* h_out_map_svu, uint8_t* h_out_valid_svu, int* n_levels, rslf_stats* stats);
+
 /* ---- measurement ------------------------------------------------------ */
 /* Duration in milliseconds of the last scan-kernel launch (K2) of this
  * context, from HIP events recorded on the context's stream around that

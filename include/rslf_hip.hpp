@@ -434,7 +434,18 @@ public:
                  float d_min, float d_max, int dim_d, float epi_scale_factor = -1,
                  const Depth1DParameters& parameters = Depth1DParameters::get_default(), int max_pyr_depth = -1,
                  bool accept_all_last_scale = true)
-        : ctx_(ctx), epis_(epis, epis + dim_v), is_u8_(is_u8), dim_v_(dim_v), dim_s_(dim_s), dim_u_(dim_u),
+        : ctx_(&ctx), multi_(nullptr), epis_(epis, epis + dim_v), is_u8_(is_u8), dim_v_(dim_v), dim_s_(dim_s), dim_u_(dim_u),
+          stride_(row_stride_bytes), d_min_(d_min), d_max_(d_max), dim_d_(dim_d), scale_(epi_scale_factor),
+          m_parameters(parameters), max_pyr_depth_(max_pyr_depth), accept_all_(accept_all_last_scale), n_levels_(0)
+    {
+        stats = rslf_stats();
+    }
+    // The same over a MultiContext's devices: every level's sweep sharded by scanline (rslf_multi_fine_to_coarse_run_host).
+    FineToCoarse(MultiContext& multi, const void* const* epis, bool is_u8, int dim_v, int dim_s, int dim_u, size_t row_stride_bytes,
+                 float d_min, float d_max, int dim_d, float epi_scale_factor = -1,
+                 const Depth1DParameters& parameters = Depth1DParameters::get_default(), int max_pyr_depth = -1,
+                 bool accept_all_last_scale = true)
+        : ctx_(nullptr), multi_(&multi), epis_(epis, epis + dim_v), is_u8_(is_u8), dim_v_(dim_v), dim_s_(dim_s), dim_u_(dim_u),
           stride_(row_stride_bytes), d_min_(d_min), d_max_(d_max), dim_d_(dim_d), scale_(epi_scale_factor),
           m_parameters(parameters), max_pyr_depth_(max_pyr_depth), accept_all_(accept_all_last_scale), n_levels_(0)
     {
@@ -446,7 +457,14 @@ public:
         out_map_s_v_u_.assign(n, 0.f);
         out_validity_s_v_u_.assign(n, 0);
         const rslf_params p = m_parameters.to_c();
-        check(rslf_fine_to_coarse_run_host(ctx_.get(), epis_.data(), is_u8_ ? 1 : 0, dim_v_, dim_s_, dim_u_, CHANNELS, stride_,
+        if (multi_) {
+            check(rslf_multi_fine_to_coarse_run_host(multi_->get(), epis_.data(), is_u8_ ? 1 : 0, dim_v_, dim_s_, dim_u_, CHANNELS, stride_,
+                                                     d_min_, d_max_, dim_d_, scale_, &p, max_pyr_depth_, accept_all_ ? 1 : 0,
+                                                     out_map_s_v_u_.data(), out_validity_s_v_u_.data(), &n_levels_, &stats),
+                  "rslf_multi_fine_to_coarse_run_host");
+            return;
+        }
+        check(rslf_fine_to_coarse_run_host(ctx_->get(), epis_.data(), is_u8_ ? 1 : 0, dim_v_, dim_s_, dim_u_, CHANNELS, stride_,
                                            d_min_, d_max_, dim_d_, scale_, &p, max_pyr_depth_, accept_all_ ? 1 : 0,
                                            out_map_s_v_u_.data(), out_validity_s_v_u_.data(), &n_levels_, &stats),
               "rslf_fine_to_coarse_run_host");
@@ -460,7 +478,8 @@ public:
     rslf_stats stats;
 
 private:
-    Context& ctx_;
+    Context* ctx_;
+    MultiContext* multi_;
     std::vector<const void*> epis_;
     bool is_u8_;
     int dim_v_, dim_s_, dim_u_;

@@ -20,7 +20,7 @@ SYMBOLS = [
     "rslf_ctx_create", "rslf_ctx_destroy", "rslf_ctx_set_stream", "rslf_ctx_synchronize", "rslf_ctx_set_debug",
     "rslf_multi_create", "rslf_multi_destroy", "rslf_multi_device_count", "rslf_multi_set_chunk_rows",
     "rslf_multi_depth1d_pile_f32", "rslf_multi_depth1d_pile_u8", "rslf_multi_depth1d_pile_f32_dev",
-    "rslf_multi_depth2d_run_f32", "rslf_multi_depth2d_run_u8",
+    "rslf_multi_depth2d_run_f32", "rslf_multi_depth2d_run_u8", "rslf_multi_fine_to_coarse_run_host",
     "rslf_volume_create", "rslf_volume_destroy", "rslf_volume_describe",
     "rslf_volume_upload_epis_f32", "rslf_volume_upload_epis_u8",
     "rslf_volume_upload_images_f32", "rslf_volume_upload_images_u8", "rslf_volume_pack_device_f32",
@@ -163,6 +163,8 @@ def lib():
                                              vp, vp, vp, vp, vp, vp, C.POINTER(RslfStats), C.POINTER(cf)]
     L.rslf_multi_depth2d_run_u8.argtypes = [vp, C.POINTER(vp), C.c_size_t, ci, ci, ci, ci, cf, cf, ci, C.POINTER(RslfParams),
                                             vp, vp, vp, vp, vp, vp, C.POINTER(RslfStats)]
+    L.rslf_multi_fine_to_coarse_run_host.argtypes = [vp, C.POINTER(vp), ci, ci, ci, ci, ci, C.c_size_t, cf, cf, ci, cf, C.POINTER(RslfParams),
+                                                     ci, ci, vp, vp, C.POINTER(ci), C.POINTER(RslfStats)]
     L.rslf_kernel_columns_pile.argtypes = [vp, vp, vp, vp, cf, cf, ci, ci, C.POINTER(RslfParams), vp, vp]
     L.rslf_depth2d_run_host.argtypes = [vp, vp, cf, cf, ci, C.POINTER(RslfParams), vp, vp, vp, vp, vp, C.POINTER(RslfStats)]
     L.rslf_fine_to_coarse_run_host.argtypes = [vp, C.POINTER(vp), ci, ci, ci, ci, ci, C.c_size_t, cf, cf, ci, cf, C.POINTER(RslfParams),

@@ -2648,6 +2648,7 @@ namespace {
 struct Sweep2DDev {
     rslf_volume* vol = nullptr;
     float *Ce = nullptr, *Cd = nullptr, *depth = nullptr, *rbar = nullptr;
+    float *dmin = nullptr, *dmax = nullptr;   // per-pixel hypothesis ranges over the held rows (a fine-to-coarse level), or NULL
     uint8_t *cem = nullptr, *scan_mask = nullptr;
     int lo = 0, hi = 0, a = 0, b = 0;   // rows held [lo, hi), rows owned [a, b)
     hipEvent_t ev_scan = nullptr, ev_fetch = nullptr;
@@ -2673,6 +2674,8 @@ void sweep2d_free(rslf_multi* m, std::vector<Sweep2DDev>& ds)
         (void)hipFree(d.Cd);
         (void)hipFree(d.depth);
         (void)hipFree(d.rbar);
+        (void)hipFree(d.dmin);
+        (void)hipFree(d.dmax);
         (void)hipFree(d.cem);
         (void)hipFree(d.scan_mask);
         if (d.ev_scan)
@@ -2684,10 +2687,13 @@ void sweep2d_free(rslf_multi* m, std::vector<Sweep2DDev>& ds)
 
 int multi_depth2d(rslf_multi* m, const void* const* h_epis, bool is_u8, size_t row_stride_bytes, int V, int S, int U, int C, float scale_arg,
                   float dmin, float dmax, int dim_d, const rslf_params* p, float* h_Ce_svu, uint8_t* h_Ce_mask_svu, float* h_Cd_svu,
-                  float* h_depth_svu, float* h_rbar_svu, uint8_t* h_scan_mask_svu, rslf_stats* stats)
+                  float* h_depth_svu, float* h_rbar_svu, uint8_t* h_scan_mask_svu, rslf_stats* stats,
+                  const float* h_dmin_svu = nullptr, const float* h_dmax_svu = nullptr)
 {
     if (!m || !h_epis)
         return fail(RSLF_ERR_INVALID_ARG, "NULL argument");
+    if ((h_dmin_svu == nullptr) != (h_dmax_svu == nullptr))
+        return fail(RSLF_ERR_INVALID_ARG, "h_dmin_svu and h_dmax_svu must both be given or both be NULL");
     if (V < 1 || S < 1 || U < 1 || (C != 1 && C != 3))
         return fail(RSLF_ERR_INVALID_ARG, "bad dimensions V=%d S=%d U=%d C=%d", V, S, U, C);
     int rc = check_params(p);
@@ -2747,6 +2753,13 @@ int multi_depth2d(rslf_multi* m, const void* const* h_epis, bool is_u8, size_t r
         S2_HIP(hipMalloc(&d.cem, n));
         S2_HIP(hipMalloc(&d.scan_mask, n));
         hipStream_t st = ctx->stream;
+        if (h_dmin_svu) {   // the held rows of every view's range planes
+            S2_HIP(hipMalloc(&d.dmin, n * sizeof(float)));
+            S2_HIP(hipMalloc(&d.dmax, n * sizeof(float)));
+            const size_t w = (size_t)rows * U * sizeof(float);
+            S2_HIP(hipMemcpy2DAsync(d.dmin, w, h_dmin_svu + (size_t)d.lo * U, (size_t)V * U * sizeof(float), w, S, hipMemcpyHostToDevice, st));
+            S2_HIP(hipMemcpy2DAsync(d.dmax, w, h_dmax_svu + (size_t)d.lo * U, (size_t)V * U * sizeof(float), w, S, hipMemcpyHostToDevice, st));
+        }
         S2_HIP(hipMemsetAsync(d.Ce, 0, n * sizeof(float), st));   // dc.hpp:733-750
         S2_HIP(hipMemsetAsync(d.Cd, 0, n * sizeof(float), st));
         S2_HIP(hipMemsetAsync(d.depth, 0, n * sizeof(float), st));
@@ -2764,7 +2777,7 @@ int multi_depth2d(rslf_multi* m, const void* const* h_epis, bool is_u8, size_t r
             Sweep2DDev& d = ds[(size_t)i];
             rslf_ctx* ctx = m->devs[(size_t)i].ctx;
             S2_HIP(hipSetDevice(ctx->device));
-            S2_TRY(rslf_sweep_visit_scan(ctx, d.vol, nullptr, nullptr, dmin, dmax, dim_d, s_hat, d.Ce, d.cem, d.Cd, d.depth, d.rbar, p));
+            S2_TRY(rslf_sweep_visit_scan(ctx, d.vol, d.dmin, d.dmax, dmin, dmax, dim_d, s_hat, d.Ce, d.cem, d.Cd, d.depth, d.rbar, p));
             S2_HIP(hipEventRecord(d.ev_scan, ctx->stream));
         }
         for (int i = 0; i < nd; i++) {   // fetch the neighbours' boundary rows into this device's halo rows
@@ -2849,6 +2862,207 @@ int multi_depth2d(rslf_multi* m, const void* const* h_epis, bool is_u8, size_t r
 }
 
 }  // namespace
+
+// FineToCoarse<T> (rslf_fine_to_coarse.hpp:103-324) over the context's devices.  Where the time goes -- every level's 2-D
+// sweep -- runs sharded (multi_depth2d, with the level's tightened per-pixel ranges); the pyramid, the bound tightening
+// and the fusion, cheap whole-image passes with non-local footprints, run on the first device.  The levels' planes pass
+// through host memory between the two (5 bytes per pixel and view down, 8 up): simple, and small beside the sweeps.
+extern "C" int rslf_multi_fine_to_coarse_run_host(rslf_multi* m, const void* const* h_epis, int is_u8, int V, int S, int U, int C,
+                                                  size_t row_stride_bytes, float d_min, float d_max, int dim_d, float epi_scale_factor,
+                                                  const rslf_params* p, int max_pyr_depth, int accept_all_last_scale,
+                                                  float* h_out_map_svu, uint8_t* h_out_valid_svu, int* n_levels, rslf_stats* stats)
+{
+    if (!m || !h_epis || !h_out_map_svu || !h_out_valid_svu || V < 1 || S < 1 || U < 1 || (C != 1 && C != 3))
+        return fail(RSLF_ERR_INVALID_ARG, "bad arguments");
+    int rc = check_params(p);
+    if (rc)
+        return rc;
+    rslf_ctx* ctx = m->devs[0].ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const size_t elem = is_u8 ? 1 : 4;
+    const size_t row_bytes = (size_t)U * C * elem;
+    if (row_stride_bytes == 0)
+        row_stride_bytes = row_bytes;
+
+    // the pyramid on the first device (constructor, f2c.hpp:103-159): every level's RAW volume comes back to the host,
+    // where the sharded sweep of the level takes its rows from
+    struct Level {
+        int V, U;
+        float scale;
+        rslf_params params;
+        std::vector<float> raw;             // [V][S][U][C] (levels below the finest)
+        std::vector<const void*> epis;      // V pointers into `raw`, or the caller's
+        std::vector<float> Ce, depth;       // [S][V][U]
+        std::vector<uint8_t> valid;
+    };
+    std::vector<Level> levels;
+    {
+        DevBuf raw;
+        HIP_TRY(raw.alloc((size_t)V * S * U * C * sizeof(float)));
+        {
+            DevBuf stage;
+            void* dst = raw.p;
+            if (is_u8) {
+                HIP_TRY(stage.alloc((size_t)V * S * row_bytes));
+                dst = stage.p;
+            }
+            for (int v = 0; v < V; v++) {
+                if (!h_epis[v])
+                    return fail(RSLF_ERR_INVALID_ARG, "h_epis[%d] is NULL", v);
+                if (row_stride_bytes == row_bytes)
+                    HIP_TRY(hipMemcpyAsync((char*)dst + (size_t)v * S * row_bytes, h_epis[v], (size_t)S * row_bytes, hipMemcpyHostToDevice, st));
+                else
+                    HIP_TRY(hipMemcpy2DAsync((char*)dst + (size_t)v * S * row_bytes, row_bytes, h_epis[v], row_stride_bytes, row_bytes, S,
+                                             hipMemcpyHostToDevice, st));
+            }
+            if (is_u8) {
+                const size_t n = (size_t)V * S * U * C;
+                hipLaunchKernelGGL(k_u8_to_f32, dim3(stream_blocks(n)), dim3(256), 0, st, (const uint8_t*)stage.p, (float*)raw.p, (long long)n);
+                HIP_TRY(hipGetLastError());
+            }
+            HIP_TRY(hipStreamSynchronize(st));
+        }
+        if (max_pyr_depth < 1)
+            max_pyr_depth = 1 << 30;
+        const int start_dim_u = U;
+        int dim_v = V, dim_u = U, counter = 0;
+        DevBuf cur;
+        float* cur_p = (float*)raw.p;
+        while (dim_v > 10 && dim_u > 10 && counter < max_pyr_depth) {   // _MIN_SPATIAL_DIM, f2c.hpp:8, :130
+            counter++;
+            levels.emplace_back();
+            Level& lv = levels.back();
+            lv.V = dim_v;
+            lv.U = dim_u;
+            lv.params = *p;
+            lv.params.slope_factor = (float)((0.0 + dim_u) / start_dim_u);   // f2c.hpp:139
+            lv.scale = 255.0f;                                                // dc.hpp:696-699 (uchar)
+            if (!is_u8) {
+                lv.scale = epi_scale_factor;
+                if (lv.scale < 0) {                                           // dc.hpp:671-690: this level's own max
+                    rc = rslf_device_max_f32(ctx, cur_p, (size_t)dim_v * S * dim_u * C, &lv.scale);
+                    if (rc)
+                        return rc;
+                }
+            }
+            if (counter == 1 && !is_u8 && row_stride_bytes == row_bytes) {
+                lv.epis.assign(h_epis, h_epis + V);                           // the finest level: the caller's float EPIs as they are
+            } else {
+                const size_t n = (size_t)dim_v * S * dim_u * C;
+                lv.raw.resize(n);
+                HIP_TRY(hipMemcpyAsync(lv.raw.data(), cur_p, n * sizeof(float), hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipStreamSynchronize(st));
+                lv.epis.resize((size_t)dim_v);
+                for (int v = 0; v < dim_v; v++)
+                    lv.epis[(size_t)v] = lv.raw.data() + (size_t)v * S * dim_u * C;
+            }
+            int v2, u2;
+            rslf_f2c_level_dims(dim_v, dim_u, &v2, &u2);
+            if (v2 < 1 || u2 < 1)
+                break;
+            DevBuf next;                                                      // f2c.hpp:145-147: the RAW EPIs go down
+            HIP_TRY(next.alloc((size_t)v2 * S * u2 * C * sizeof(float)));
+            rc = is_u8 ? rslf_downsample_epis_u8(ctx, cur_p, dim_v, S, dim_u, C, (float*)next.p)
+                       : rslf_downsample_epis_f32(ctx, cur_p, dim_v, S, dim_u, C, (float*)next.p);
+            if (rc)
+                return rc;
+            std::swap(cur.p, next.p);
+            cur_p = (float*)cur.p;
+            dim_v = v2;
+            dim_u = u2;
+        }
+    }
+    if (levels.empty())
+        return fail(RSLF_ERR_INVALID_ARG, "light field %dx%d is not larger than _MIN_SPATIAL_DIM: no pyramid level", V, U);
+    const int P = (int)levels.size();
+
+    // run(): f2c.hpp:171-299 -- the sweeps over all devices, the tightening on the first
+    int64_t pixels = 0;
+    rslf_stats st1;
+    memset(&st1, 0, sizeof(st1));
+    std::vector<float> h_lo, h_hi;
+    for (int l = 0; l < P; l++) {
+        Level& lv = levels[(size_t)l];
+        const size_t n = (size_t)S * lv.V * lv.U;
+        lv.Ce.resize(n);
+        lv.depth.resize(n);
+        lv.valid.resize(n);
+        const float *lo = nullptr, *hi = nullptr;
+        if (l > 0) {
+            Level& up = levels[(size_t)l - 1];
+            const size_t nu = (size_t)S * up.V * up.U;
+            HIP_TRY(hipSetDevice(ctx->device));
+            DevBuf d_depth, d_valid, d_lo, d_hi;
+            HIP_TRY(d_depth.alloc(nu * 4));
+            HIP_TRY(d_valid.alloc(nu));
+            HIP_TRY(d_lo.alloc(n * 4));
+            HIP_TRY(d_hi.alloc(n * 4));
+            HIP_TRY(hipMemcpyAsync(d_depth.p, up.depth.data(), nu * 4, hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMemcpyAsync(d_valid.p, up.valid.data(), nu, hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(k_fill_f32, dim3(stream_blocks(n)), dim3(256), 0, st, (float*)d_lo.p, (long long)n, d_min);
+            hipLaunchKernelGGL(k_fill_f32, dim3(stream_blocks(n)), dim3(256), 0, st, (float*)d_hi.p, (long long)n, d_max);
+            HIP_TRY(hipGetLastError());
+            rc = rslf_f2c_tighten_bounds(ctx, (const float*)d_depth.p, (const uint8_t*)d_valid.p, S, up.V, up.U, (float*)d_lo.p,
+                                         (float*)d_hi.p, lv.V, lv.U);
+            if (rc)
+                return rc;
+            h_lo.resize(n);
+            h_hi.resize(n);
+            HIP_TRY(hipMemcpyAsync(h_lo.data(), d_lo.p, n * 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(h_hi.data(), d_hi.p, n * 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            lo = h_lo.data();
+            hi = h_hi.data();
+        }
+        rc = multi_depth2d(m, lv.epis.data(), false, 0, lv.V, S, lv.U, C, lv.scale, d_min, d_max, dim_d, &lv.params, lv.Ce.data(), nullptr,
+                           nullptr, lv.depth.data(), nullptr, nullptr, &st1, lo, hi);
+        if (rc)
+            return rc;
+        pixels += st1.pixels_scanned;
+        // get_valid_depths_mask_s_v_u (dc.hpp:893-915): C_e > threshold; the last level accepts everything when asked to
+        const float thr = (accept_all_last_scale && l == P - 1) ? -1.0f : p->edge_score_threshold;
+        for (size_t i = 0; i < n; i++)
+            lv.valid[i] = lv.Ce[i] > thr ? 255 : 0;
+    }
+
+    // get_results(): f2c.hpp:302-324 on the first device
+    HIP_TRY(hipSetDevice(ctx->device));
+    std::vector<DevBuf> d_depth((size_t)P), d_valid((size_t)P);
+    std::vector<const float*> dp((size_t)P);
+    std::vector<const uint8_t*> vp((size_t)P);
+    std::vector<int> Vp((size_t)P), Up((size_t)P);
+    for (int l = 0; l < P; l++) {
+        Level& lv = levels[(size_t)l];
+        const size_t n = (size_t)S * lv.V * lv.U;
+        HIP_TRY(d_depth[(size_t)l].alloc(n * 4));
+        HIP_TRY(d_valid[(size_t)l].alloc(n));
+        HIP_TRY(hipMemcpyAsync(d_depth[(size_t)l].p, lv.depth.data(), n * 4, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(d_valid[(size_t)l].p, lv.valid.data(), n, hipMemcpyHostToDevice, st));
+        dp[(size_t)l] = (const float*)d_depth[(size_t)l].p;
+        vp[(size_t)l] = (const uint8_t*)d_valid[(size_t)l].p;
+        Vp[(size_t)l] = lv.V;
+        Up[(size_t)l] = lv.U;
+    }
+    const size_t n0 = (size_t)S * V * U;
+    DevBuf omap, ovalid;
+    HIP_TRY(omap.alloc(n0 * 4));
+    HIP_TRY(ovalid.alloc(n0));
+    rc = rslf_f2c_fuse(ctx, dp.data(), vp.data(), Vp.data(), Up.data(), P, S, (float*)omap.p, (uint8_t*)ovalid.p);
+    if (rc)
+        return rc;
+    HIP_TRY(hipMemcpyAsync(h_out_map_svu, omap.p, n0 * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(h_out_valid_svu, ovalid.p, n0, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (n_levels)
+        *n_levels = P;
+    if (stats) {
+        *stats = st1;
+        stats->pixels_scanned = pixels;
+        stats->units = pixels * dim_d;
+    }
+    return RSLF_OK;
+}
 
 extern "C" int rslf_multi_depth2d_run_f32(rslf_multi* m, const float* const* h_epis, size_t row_stride_bytes, int V, int S, int U, int C,
                                           float epi_scale_factor, float dmin, float dmax, int dim_d, const rslf_params* p,

@@ -486,6 +486,31 @@ class MultiDevice:
         self.stats = st
         return out
 
+    def fine_to_coarse(self, epis: Sequence[np.ndarray], d_min: float, d_max: float, dim_d: int, epi_scale_factor: float = -1.0,
+                       parameters: Depth1DParameters | None = None, max_pyr_depth: int = -1, accept_all_last_scale: bool = True):
+        """FineToCoarse (constructor + run + get_results) over this object's devices (rslf_multi_fine_to_coarse_run_host):
+        every level's sweep sharded by scanline.  Returns (out_map [S,V,U] f32, out_validity [S,V,U] u8, levels)."""
+        first = np.asarray(epis[0])
+        dt = first.dtype
+        if dt not in (np.uint8, np.float32):
+            raise TypeError("EPIs must be uint8 or float32 (dc.hpp:149-154)")
+        keep = [e if (type(e) is np.ndarray and e.dtype == dt and e.flags.c_contiguous) else np.ascontiguousarray(e, dtype=dt) for e in epis]
+        V = len(keep)
+        S, U = keep[0].shape[0], keep[0].shape[1]
+        C_ = 1 if keep[0].ndim == 2 else keep[0].shape[2]
+        ptrs = (C.c_void_p * V)(*[e.__array_interface__["data"][0] for e in keep])
+        out_map = np.empty((S, V, U), np.float32)
+        out_valid = np.empty((S, V, U), np.uint8)
+        p = (parameters or Depth1DParameters()).to_c()
+        st, nl = RslfStats(), C.c_int()
+        check(_lib.lib().rslf_multi_fine_to_coarse_run_host(self._h, ptrs, 1 if dt == np.uint8 else 0, V, S, U, C_, 0, float(d_min), float(d_max),
+                                                            int(dim_d), float(epi_scale_factor), C.byref(p), int(max_pyr_depth),
+                                                            1 if accept_all_last_scale else 0, out_map.ctypes.data_as(C.c_void_p),
+                                                            out_valid.ctypes.data_as(C.c_void_p), C.byref(nl), C.byref(st)),
+              "rslf_multi_fine_to_coarse_run_host")
+        self.stats = st
+        return out_map, out_valid, int(nl.value)
+
     def depth1d_pile_device_out(self, epis: Sequence[np.ndarray], dmin: float, dmax: float, dim_d: int, out_device: int = 0,
                                 s_hat: int = -1, epi_scale_factor: float = -1.0, parameters: Depth1DParameters | None = None) -> dict:
         """The same with the result planes left on `out_device` as CUDA tensors (float32 EPIs): every worker copies its

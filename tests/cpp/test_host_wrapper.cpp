@@ -112,6 +112,16 @@ static int run_sweeps(rslfx::Context& ctx, const std::string& dir)
     std::printf("sweeps: Depth2DComputer over %d workers: %s\n", multi.device_count(), same ? "planes identical" : "MISMATCH");
     if (!same)
         return 32;
+    rslfx::FineToCoarse<1> f2cm(multi, ptrs.data(), false, V, S, U, 0, -1.0f, 1.0f, D);
+    f2cm.run();
+    std::vector<float> map_m;
+    std::vector<uint8_t> valid_m;
+    f2cm.get_results(map_m, valid_m);
+    const bool same_f2c = map_m == map && valid_m == valid && f2cm.pyramid_depth() == f2c.pyramid_depth() &&
+                          f2cm.stats.pixels_scanned == f2c.stats.pixels_scanned;
+    std::printf("sweeps: FineToCoarse over %d workers: %s\n", multi.device_count(), same_f2c ? "fused map identical" : "MISMATCH");
+    if (!same_f2c)
+        return 64;
     return f2c.pyramid_depth() == 3 ? 0 : 8;   // 44x64 -> 22x32 -> 11x16, then 6x8 stops the pyramid
 }
 
