@@ -2116,6 +2116,8 @@ struct rslf_multi {
         size_t planes_cap = 0;
         char* pin[2] = {nullptr, nullptr};   // pinned host staging for EPIs scattered over the heap (Vec<Mat>)
         size_t pin_cap = 0;
+        char* arena = nullptr;               // the sweep forms' planes, kept from call to call (and from level to level)
+        size_t arena_cap = 0;
     };
     std::vector<Dev> devs;
     int chunk_rows = 0;   // 0 = automatic
@@ -2131,6 +2133,8 @@ static void multi_free_dev(rslf_multi::Dev& d)
             (void)rslf_volume_destroy(d.vol[i]);
         (void)hipFree(d.planes[i]);
         (void)hipHostFree(d.pin[i]);
+        if (i == 0)
+            (void)hipFree(d.arena);
         if (d.done[i])
             (void)hipEventDestroy(d.done[i]);
     }
@@ -2670,14 +2674,7 @@ void sweep2d_free(rslf_multi* m, std::vector<Sweep2DDev>& ds)
             ctx->stream = d.saved_stream;
         if (d.vol)
             (void)rslf_volume_destroy(d.vol);
-        (void)hipFree(d.Ce);
-        (void)hipFree(d.Cd);
-        (void)hipFree(d.depth);
-        (void)hipFree(d.rbar);
-        (void)hipFree(d.dmin);
-        (void)hipFree(d.dmax);
-        (void)hipFree(d.cem);
-        (void)hipFree(d.scan_mask);
+        // (the planes live in the device's arena, which stays)
         if (d.ev_scan)
             (void)hipEventDestroy(d.ev_scan);
         if (d.ev_fetch)
@@ -2746,16 +2743,31 @@ int multi_depth2d(rslf_multi* m, const void* const* h_epis, bool is_u8, size_t r
             S2_TRY(upload_host<uint8_t>(d.vol, (const uint8_t* const*)h_epis + d.lo, row_stride_bytes, false, (float)(1.0 / 255.0)));
         else
             S2_TRY(upload_host<float>(d.vol, (const float* const*)h_epis + d.lo, row_stride_bytes, false, scale_of(scale_arg)));
-        S2_HIP(hipMalloc(&d.Ce, n * sizeof(float)));
-        S2_HIP(hipMalloc(&d.Cd, n * sizeof(float)));
-        S2_HIP(hipMalloc(&d.depth, n * sizeof(float)));
-        S2_HIP(hipMalloc(&d.rbar, n * C * sizeof(float)));
-        S2_HIP(hipMalloc(&d.cem, n));
-        S2_HIP(hipMalloc(&d.scan_mask, n));
+        {   // planes: one allocation per device, grown when a larger field comes (allocation calls synchronise the device)
+            rslf_multi::Dev& md = m->devs[(size_t)i];
+            const size_t nf = (n + 63) & ~(size_t)63;   // floats per plane, 256-byte aligned
+            const size_t need = nf * sizeof(float) * (3 + (size_t)C + (h_dmin_svu ? 2 : 0)) + 2 * nf;
+            if (need > md.arena_cap) {
+                (void)hipFree(md.arena);
+                md.arena = nullptr;
+                md.arena_cap = 0;
+                S2_HIP(hipMalloc(&md.arena, need));
+                md.arena_cap = need;
+            }
+            float* f = reinterpret_cast<float*>(md.arena);
+            d.Ce = f, f += nf;
+            d.Cd = f, f += nf;
+            d.depth = f, f += nf;
+            d.rbar = f, f += nf * C;
+            if (h_dmin_svu) {
+                d.dmin = f, f += nf;
+                d.dmax = f, f += nf;
+            }
+            d.cem = reinterpret_cast<uint8_t*>(f);
+            d.scan_mask = d.cem + nf;
+        }
         hipStream_t st = ctx->stream;
         if (h_dmin_svu) {   // the held rows of every view's range planes
-            S2_HIP(hipMalloc(&d.dmin, n * sizeof(float)));
-            S2_HIP(hipMalloc(&d.dmax, n * sizeof(float)));
             const size_t w = (size_t)rows * U * sizeof(float);
             S2_HIP(hipMemcpy2DAsync(d.dmin, w, h_dmin_svu + (size_t)d.lo * U, (size_t)V * U * sizeof(float), w, S, hipMemcpyHostToDevice, st));
             S2_HIP(hipMemcpy2DAsync(d.dmax, w, h_dmax_svu + (size_t)d.lo * U, (size_t)V * U * sizeof(float), w, S, hipMemcpyHostToDevice, st));
