@@ -398,7 +398,8 @@ int rslf_multi_depth2d_run_u8(rslf_multi* m, const uint8_t* const* h_epis, size_
 
 /* FineToCoarse<T>'s constructor + run() + get_results() (rslf_fine_to_coarse.hpp:103-324) over the context's devices:
  * every level's 2-D sweep runs sharded as in rslf_multi_depth2d_run_* (with the level's tightened per-pixel ranges); the
- * pyramid, the bound tightening and the fusion run on the first device, the levels' planes passing through host memory.
+ * pyramid, the bound tightening and the fusion run on the first device, which also holds every level's planes: the
+ * other devices fetch their rows from it and return their results to it by peer copies.
  * Arguments and results as rslf_fine_to_coarse_run_host; bit-identical to it. */
 int rslf_multi_fine_to_coarse_run_host(rslf_multi* m, const void* const* h_epis, int is_u8, int V, int S, int U, int C,
                                        size_t row_stride_bytes, float d_min, float d_max, int dim_d, float epi_scale_factor,

@@ -10,6 +10,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <deque>
 #include <new>
 #include <string>
 #include <vector>
@@ -1701,6 +1702,11 @@ struct DevBuf {   // scoped device scratch for the once-per-level helpers
     void* p = nullptr;
     ~DevBuf() { (void)hipFree(p); }
     hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
+    void release()
+    {
+        (void)hipFree(p);
+        p = nullptr;
+    }
 };
 }  // namespace
 
@@ -2682,21 +2688,34 @@ void sweep2d_free(rslf_multi* m, std::vector<Sweep2DDev>& ds)
     }
 }
 
+// The fine-to-coarse form of a sweep: nothing passes through host memory.  The level's RAW volume, its per-pixel ranges
+// and the two planes the next steps need live on the FIRST device; every device takes the rows it holds from there and
+// leaves its own rows of the results there, by peer copies (plain device copies where it is the first device itself).
+struct FirstDevicePlanes {
+    const float* raw_vsuc = nullptr;   // [V][S][U][C] raw values of the level (replaces the host EPIs)
+    const float* dmin_svu = nullptr;   // [S][V][U] ranges, or NULL for the scalar range
+    const float* dmax_svu = nullptr;
+    float* Ce_svu = nullptr;           // [S][V][U] results
+    float* depth_svu = nullptr;
+};
+
 int multi_depth2d(rslf_multi* m, const void* const* h_epis, bool is_u8, size_t row_stride_bytes, int V, int S, int U, int C, float scale_arg,
                   float dmin, float dmax, int dim_d, const rslf_params* p, float* h_Ce_svu, uint8_t* h_Ce_mask_svu, float* h_Cd_svu,
                   float* h_depth_svu, float* h_rbar_svu, uint8_t* h_scan_mask_svu, rslf_stats* stats,
-                  const float* h_dmin_svu = nullptr, const float* h_dmax_svu = nullptr)
+                  const FirstDevicePlanes* first = nullptr)
 {
-    if (!m || !h_epis)
+    if (!m || (!h_epis && !(first && first->raw_vsuc)))
         return fail(RSLF_ERR_INVALID_ARG, "NULL argument");
-    if ((h_dmin_svu == nullptr) != (h_dmax_svu == nullptr))
-        return fail(RSLF_ERR_INVALID_ARG, "h_dmin_svu and h_dmax_svu must both be given or both be NULL");
+    if (first && ((first->dmin_svu == nullptr) != (first->dmax_svu == nullptr)))
+        return fail(RSLF_ERR_INVALID_ARG, "dmin_svu and dmax_svu must both be given or both be NULL");
+    const bool ranges = first && first->dmin_svu;
+    const int dev0 = m->devs[0].ctx->device;
     if (V < 1 || S < 1 || U < 1 || (C != 1 && C != 3))
         return fail(RSLF_ERR_INVALID_ARG, "bad dimensions V=%d S=%d U=%d C=%d", V, S, U, C);
     int rc = check_params(p);
     if (rc)
         return rc;
-    for (int v = 0; v < V; v++)
+    for (int v = 0; h_epis && v < V; v++)
         if (!h_epis[v])
             return fail(RSLF_ERR_INVALID_ARG, "h_epis[%d] is NULL", v);
     const int h_med = (p->median_filter_size - 1) / 2;
@@ -2739,14 +2758,29 @@ int multi_depth2d(rslf_multi* m, const void* const* h_epis, bool is_u8, size_t r
         S2_HIP(hipEventCreateWithFlags(&d.ev_scan, hipEventDisableTiming));
         S2_HIP(hipEventCreateWithFlags(&d.ev_fetch, hipEventDisableTiming));
         S2_TRY(rslf_volume_create(ctx, rows, S, U, C, &d.vol));
-        if (is_u8)
+        // a copy between this device and the first one (either direction), queued on this device's stream
+        auto copy01 = [&](void* dst, int dst_dev, const void* src, int src_dev, size_t bytes) -> hipError_t {
+            return dst_dev == src_dev ? hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream)
+                                      : hipMemcpyPeerAsync(dst, dst_dev, src, src_dev, bytes, ctx->stream);
+        };
+        if (first && first->raw_vsuc) {   // the held rows of the level's raw volume: from the first device
+            const size_t row_floats = (size_t)S * U * C;
+            const float* src = first->raw_vsuc + (size_t)d.lo * row_floats;
+            if (ctx->device != dev0) {
+                S2_TRY(ensure_staging(ctx, (size_t)rows * row_floats * sizeof(float)));
+                S2_HIP(copy01(ctx->staging, ctx->device, src, dev0, (size_t)rows * row_floats * sizeof(float)));
+                src = (const float*)ctx->staging;
+            }
+            S2_TRY(rslf_volume_pack_device_f32(d.vol, src, scale_arg, nullptr));
+        } else if (is_u8) {
             S2_TRY(upload_host<uint8_t>(d.vol, (const uint8_t* const*)h_epis + d.lo, row_stride_bytes, false, (float)(1.0 / 255.0)));
-        else
+        } else {
             S2_TRY(upload_host<float>(d.vol, (const float* const*)h_epis + d.lo, row_stride_bytes, false, scale_of(scale_arg)));
+        }
         {   // planes: one allocation per device, grown when a larger field comes (allocation calls synchronise the device)
             rslf_multi::Dev& md = m->devs[(size_t)i];
             const size_t nf = (n + 63) & ~(size_t)63;   // floats per plane, 256-byte aligned
-            const size_t need = nf * sizeof(float) * (3 + (size_t)C + (h_dmin_svu ? 2 : 0)) + 2 * nf;
+            const size_t need = nf * sizeof(float) * (3 + (size_t)C + (ranges ? 2 : 0)) + 2 * nf;
             if (need > md.arena_cap) {
                 (void)hipFree(md.arena);
                 md.arena = nullptr;
@@ -2759,7 +2793,7 @@ int multi_depth2d(rslf_multi* m, const void* const* h_epis, bool is_u8, size_t r
             d.Cd = f, f += nf;
             d.depth = f, f += nf;
             d.rbar = f, f += nf * C;
-            if (h_dmin_svu) {
+            if (ranges) {
                 d.dmin = f, f += nf;
                 d.dmax = f, f += nf;
             }
@@ -2767,10 +2801,12 @@ int multi_depth2d(rslf_multi* m, const void* const* h_epis, bool is_u8, size_t r
             d.scan_mask = d.cem + nf;
         }
         hipStream_t st = ctx->stream;
-        if (h_dmin_svu) {   // the held rows of every view's range planes
-            const size_t w = (size_t)rows * U * sizeof(float);
-            S2_HIP(hipMemcpy2DAsync(d.dmin, w, h_dmin_svu + (size_t)d.lo * U, (size_t)V * U * sizeof(float), w, S, hipMemcpyHostToDevice, st));
-            S2_HIP(hipMemcpy2DAsync(d.dmax, w, h_dmax_svu + (size_t)d.lo * U, (size_t)V * U * sizeof(float), w, S, hipMemcpyHostToDevice, st));
+        if (ranges) {   // the held rows of every view's range planes: one run of bytes per view
+            const size_t w = (size_t)rows * U;
+            for (int sv = 0; sv < S; sv++) {
+                S2_HIP(copy01(d.dmin + (size_t)sv * w, ctx->device, first->dmin_svu + ((size_t)sv * V + d.lo) * U, dev0, w * sizeof(float)));
+                S2_HIP(copy01(d.dmax + (size_t)sv * w, ctx->device, first->dmax_svu + ((size_t)sv * V + d.lo) * U, dev0, w * sizeof(float)));
+            }
         }
         S2_HIP(hipMemsetAsync(d.Ce, 0, n * sizeof(float), st));   // dc.hpp:733-750
         S2_HIP(hipMemsetAsync(d.Cd, 0, n * sizeof(float), st));
@@ -2852,6 +2888,20 @@ int multi_depth2d(rslf_multi* m, const void* const* h_epis, bool is_u8, size_t r
             return hipMemcpy2DAsync((char*)h + (size_t)d.a * U * esz, (size_t)V * U * esz, (const char*)dv + (size_t)(d.a - d.lo) * U * esz,
                                     (size_t)rows * U * esz, (size_t)own * U * esz, S, hipMemcpyDeviceToHost, ctx->stream);
         };
+        if (first && first->Ce_svu) {   // this device's own rows of the two planes the next steps read: to the first device
+            const size_t w = (size_t)own * U;
+            for (int sv = 0; sv < S; sv++) {
+                const size_t src = ((size_t)sv * rows + (d.a - d.lo)) * U, dst = ((size_t)sv * V + d.a) * U;
+                hipError_t e = ctx->device == dev0
+                                   ? hipMemcpyAsync(first->Ce_svu + dst, d.Ce + src, w * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream)
+                                   : hipMemcpyPeerAsync(first->Ce_svu + dst, dev0, d.Ce + src, ctx->device, w * sizeof(float), ctx->stream);
+                S2_HIP(e);
+                e = ctx->device == dev0
+                        ? hipMemcpyAsync(first->depth_svu + dst, d.depth + src, w * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream)
+                        : hipMemcpyPeerAsync(first->depth_svu + dst, dev0, d.depth + src, ctx->device, w * sizeof(float), ctx->stream);
+                S2_HIP(e);
+            }
+        }
         S2_HIP(pull(h_Ce_svu, d.Ce, sizeof(float)));
         S2_HIP(pull(h_Ce_mask_svu, d.cem, 1));
         S2_HIP(pull(h_Cd_svu, d.Cd, sizeof(float)));
@@ -2877,8 +2927,9 @@ int multi_depth2d(rslf_multi* m, const void* const* h_epis, bool is_u8, size_t r
 
 // FineToCoarse<T> (rslf_fine_to_coarse.hpp:103-324) over the context's devices.  Where the time goes -- every level's 2-D
 // sweep -- runs sharded (multi_depth2d, with the level's tightened per-pixel ranges); the pyramid, the bound tightening
-// and the fusion, cheap whole-image passes with non-local footprints, run on the first device.  The levels' planes pass
-// through host memory between the two (5 bytes per pixel and view down, 8 up): simple, and small beside the sweeps.
+// and the fusion, cheap whole-image passes with non-local footprints, run on the first device, where every level's raw
+// volume, ranges, disparities and confidences stay: the devices take their rows from there and leave their results there
+// by peer copies (FirstDevicePlanes).  The host sees the EPIs going up once and the fused map coming down.
 extern "C" int rslf_multi_fine_to_coarse_run_host(rslf_multi* m, const void* const* h_epis, int is_u8, int V, int S, int U, int C,
                                                   size_t row_stride_bytes, float d_min, float d_max, int dim_d, float epi_scale_factor,
                                                   const rslf_params* p, int max_pyr_depth, int accept_all_last_scale,
@@ -2897,53 +2948,49 @@ extern "C" int rslf_multi_fine_to_coarse_run_host(rslf_multi* m, const void* con
     if (row_stride_bytes == 0)
         row_stride_bytes = row_bytes;
 
-    // the pyramid on the first device (constructor, f2c.hpp:103-159): every level's RAW volume comes back to the host,
-    // where the sharded sweep of the level takes its rows from
     struct Level {
-        int V, U;
-        float scale;
+        int V = 0, U = 0;
+        float scale = 1.0f;
         rslf_params params;
-        std::vector<float> raw;             // [V][S][U][C] (levels below the finest)
-        std::vector<const void*> epis;      // V pointers into `raw`, or the caller's
-        std::vector<float> Ce, depth;       // [S][V][U]
-        std::vector<uint8_t> valid;
+        DevBuf raw;                 // [V][S][U][C] raw values, on the first device
+        DevBuf Ce, depth, valid;    // [S][V][U], on the first device
     };
-    std::vector<Level> levels;
+    std::deque<Level> levels;       // (a deque: the levels own device buffers and must not move)
+    // constructor (f2c.hpp:103-159): the pyramid on the first device, every level's RAW volume kept there
     {
-        DevBuf raw;
-        HIP_TRY(raw.alloc((size_t)V * S * U * C * sizeof(float)));
-        {
-            DevBuf stage;
-            void* dst = raw.p;
-            if (is_u8) {
-                HIP_TRY(stage.alloc((size_t)V * S * row_bytes));
-                dst = stage.p;
-            }
-            for (int v = 0; v < V; v++) {
-                if (!h_epis[v])
-                    return fail(RSLF_ERR_INVALID_ARG, "h_epis[%d] is NULL", v);
-                if (row_stride_bytes == row_bytes)
-                    HIP_TRY(hipMemcpyAsync((char*)dst + (size_t)v * S * row_bytes, h_epis[v], (size_t)S * row_bytes, hipMemcpyHostToDevice, st));
-                else
-                    HIP_TRY(hipMemcpy2DAsync((char*)dst + (size_t)v * S * row_bytes, row_bytes, h_epis[v], row_stride_bytes, row_bytes, S,
-                                             hipMemcpyHostToDevice, st));
-            }
-            if (is_u8) {
-                const size_t n = (size_t)V * S * U * C;
-                hipLaunchKernelGGL(k_u8_to_f32, dim3(stream_blocks(n)), dim3(256), 0, st, (const uint8_t*)stage.p, (float*)raw.p, (long long)n);
-                HIP_TRY(hipGetLastError());
-            }
-            HIP_TRY(hipStreamSynchronize(st));
+        levels.emplace_back();
+        Level& l0 = levels.back();
+        HIP_TRY(l0.raw.alloc((size_t)V * S * U * C * sizeof(float)));
+        DevBuf stage;
+        void* dst = l0.raw.p;
+        if (is_u8) {
+            HIP_TRY(stage.alloc((size_t)V * S * row_bytes));
+            dst = stage.p;
         }
-        if (max_pyr_depth < 1)
-            max_pyr_depth = 1 << 30;
+        for (int v = 0; v < V; v++) {
+            if (!h_epis[v])
+                return fail(RSLF_ERR_INVALID_ARG, "h_epis[%d] is NULL", v);
+            if (row_stride_bytes == row_bytes)
+                HIP_TRY(hipMemcpyAsync((char*)dst + (size_t)v * S * row_bytes, h_epis[v], (size_t)S * row_bytes, hipMemcpyHostToDevice, st));
+            else
+                HIP_TRY(hipMemcpy2DAsync((char*)dst + (size_t)v * S * row_bytes, row_bytes, h_epis[v], row_stride_bytes, row_bytes, S,
+                                         hipMemcpyHostToDevice, st));
+        }
+        if (is_u8) {
+            const size_t n = (size_t)V * S * U * C;
+            hipLaunchKernelGGL(k_u8_to_f32, dim3(stream_blocks(n)), dim3(256), 0, st, (const uint8_t*)stage.p, (float*)l0.raw.p, (long long)n);
+            HIP_TRY(hipGetLastError());
+        }
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    if (max_pyr_depth < 1)
+        max_pyr_depth = 1 << 30;
+    {
         const int start_dim_u = U;
         int dim_v = V, dim_u = U, counter = 0;
-        DevBuf cur;
-        float* cur_p = (float*)raw.p;
+        bool have = true;   // levels.back() holds the raw volume of the level being described
         while (dim_v > 10 && dim_u > 10 && counter < max_pyr_depth) {   // _MIN_SPATIAL_DIM, f2c.hpp:8, :130
             counter++;
-            levels.emplace_back();
             Level& lv = levels.back();
             lv.V = dim_v;
             lv.U = dim_u;
@@ -2953,37 +3000,32 @@ extern "C" int rslf_multi_fine_to_coarse_run_host(rslf_multi* m, const void* con
             if (!is_u8) {
                 lv.scale = epi_scale_factor;
                 if (lv.scale < 0) {                                           // dc.hpp:671-690: this level's own max
-                    rc = rslf_device_max_f32(ctx, cur_p, (size_t)dim_v * S * dim_u * C, &lv.scale);
+                    rc = rslf_device_max_f32(ctx, (const float*)lv.raw.p, (size_t)dim_v * S * dim_u * C, &lv.scale);
                     if (rc)
                         return rc;
                 }
             }
-            if (counter == 1 && !is_u8 && row_stride_bytes == row_bytes) {
-                lv.epis.assign(h_epis, h_epis + V);                           // the finest level: the caller's float EPIs as they are
-            } else {
-                const size_t n = (size_t)dim_v * S * dim_u * C;
-                lv.raw.resize(n);
-                HIP_TRY(hipMemcpyAsync(lv.raw.data(), cur_p, n * sizeof(float), hipMemcpyDeviceToHost, st));
-                HIP_TRY(hipStreamSynchronize(st));
-                lv.epis.resize((size_t)dim_v);
-                for (int v = 0; v < dim_v; v++)
-                    lv.epis[(size_t)v] = lv.raw.data() + (size_t)v * S * dim_u * C;
-            }
+            have = false;
             int v2, u2;
             rslf_f2c_level_dims(dim_v, dim_u, &v2, &u2);
             if (v2 < 1 || u2 < 1)
                 break;
-            DevBuf next;                                                      // f2c.hpp:145-147: the RAW EPIs go down
-            HIP_TRY(next.alloc((size_t)v2 * S * u2 * C * sizeof(float)));
-            rc = is_u8 ? rslf_downsample_epis_u8(ctx, cur_p, dim_v, S, dim_u, C, (float*)next.p)
-                       : rslf_downsample_epis_f32(ctx, cur_p, dim_v, S, dim_u, C, (float*)next.p);
+            if (!(v2 > 10 && u2 > 10 && counter < max_pyr_depth))
+                break;                                                        // no further level: nothing to build
+            levels.emplace_back();
+            Level& nx = levels.back();
+            Level& cur = levels[levels.size() - 2];
+            HIP_TRY(nx.raw.alloc((size_t)v2 * S * u2 * C * sizeof(float)));   // f2c.hpp:145-147: the RAW EPIs go down
+            rc = is_u8 ? rslf_downsample_epis_u8(ctx, (const float*)cur.raw.p, dim_v, S, dim_u, C, (float*)nx.raw.p)
+                       : rslf_downsample_epis_f32(ctx, (const float*)cur.raw.p, dim_v, S, dim_u, C, (float*)nx.raw.p);
             if (rc)
                 return rc;
-            std::swap(cur.p, next.p);
-            cur_p = (float*)cur.p;
+            have = true;
             dim_v = v2;
             dim_u = u2;
         }
+        if (have)            // the loop never described the last buffer (the field itself is below _MIN_SPATIAL_DIM)
+            levels.pop_back();
     }
     if (levels.empty())
         return fail(RSLF_ERR_INVALID_ARG, "light field %dx%d is not larger than _MIN_SPATIAL_DIM: no pyramid level", V, U);
@@ -2993,68 +3035,56 @@ extern "C" int rslf_multi_fine_to_coarse_run_host(rslf_multi* m, const void* con
     int64_t pixels = 0;
     rslf_stats st1;
     memset(&st1, 0, sizeof(st1));
-    std::vector<float> h_lo, h_hi;
     for (int l = 0; l < P; l++) {
         Level& lv = levels[(size_t)l];
         const size_t n = (size_t)S * lv.V * lv.U;
-        lv.Ce.resize(n);
-        lv.depth.resize(n);
-        lv.valid.resize(n);
-        const float *lo = nullptr, *hi = nullptr;
+        HIP_TRY(hipSetDevice(ctx->device));
+        HIP_TRY(lv.Ce.alloc(n * 4));
+        HIP_TRY(lv.depth.alloc(n * 4));
+        HIP_TRY(lv.valid.alloc(n));
+        DevBuf d_lo, d_hi;
+        FirstDevicePlanes first;
+        first.raw_vsuc = (const float*)lv.raw.p;
+        first.Ce_svu = (float*)lv.Ce.p;
+        first.depth_svu = (float*)lv.depth.p;
         if (l > 0) {
             Level& up = levels[(size_t)l - 1];
-            const size_t nu = (size_t)S * up.V * up.U;
-            HIP_TRY(hipSetDevice(ctx->device));
-            DevBuf d_depth, d_valid, d_lo, d_hi;
-            HIP_TRY(d_depth.alloc(nu * 4));
-            HIP_TRY(d_valid.alloc(nu));
             HIP_TRY(d_lo.alloc(n * 4));
             HIP_TRY(d_hi.alloc(n * 4));
-            HIP_TRY(hipMemcpyAsync(d_depth.p, up.depth.data(), nu * 4, hipMemcpyHostToDevice, st));
-            HIP_TRY(hipMemcpyAsync(d_valid.p, up.valid.data(), nu, hipMemcpyHostToDevice, st));
             hipLaunchKernelGGL(k_fill_f32, dim3(stream_blocks(n)), dim3(256), 0, st, (float*)d_lo.p, (long long)n, d_min);
             hipLaunchKernelGGL(k_fill_f32, dim3(stream_blocks(n)), dim3(256), 0, st, (float*)d_hi.p, (long long)n, d_max);
             HIP_TRY(hipGetLastError());
-            rc = rslf_f2c_tighten_bounds(ctx, (const float*)d_depth.p, (const uint8_t*)d_valid.p, S, up.V, up.U, (float*)d_lo.p,
+            rc = rslf_f2c_tighten_bounds(ctx, (const float*)up.depth.p, (const uint8_t*)up.valid.p, S, up.V, up.U, (float*)d_lo.p,
                                          (float*)d_hi.p, lv.V, lv.U);
             if (rc)
                 return rc;
-            h_lo.resize(n);
-            h_hi.resize(n);
-            HIP_TRY(hipMemcpyAsync(h_lo.data(), d_lo.p, n * 4, hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipMemcpyAsync(h_hi.data(), d_hi.p, n * 4, hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipStreamSynchronize(st));
-            lo = h_lo.data();
-            hi = h_hi.data();
+            first.dmin_svu = (const float*)d_lo.p;
+            first.dmax_svu = (const float*)d_hi.p;
         }
-        rc = multi_depth2d(m, lv.epis.data(), false, 0, lv.V, S, lv.U, C, lv.scale, d_min, d_max, dim_d, &lv.params, lv.Ce.data(), nullptr,
-                           nullptr, lv.depth.data(), nullptr, nullptr, &st1, lo, hi);
+        HIP_TRY(hipStreamSynchronize(st));   // what the other devices' streams are about to read is complete
+        rc = multi_depth2d(m, nullptr, false, 0, lv.V, S, lv.U, C, lv.scale, d_min, d_max, dim_d, &lv.params, nullptr, nullptr, nullptr,
+                           nullptr, nullptr, nullptr, &st1, &first);
         if (rc)
             return rc;
         pixels += st1.pixels_scanned;
         // get_valid_depths_mask_s_v_u (dc.hpp:893-915): C_e > threshold; the last level accepts everything when asked to
-        const float thr = (accept_all_last_scale && l == P - 1) ? -1.0f : p->edge_score_threshold;
-        for (size_t i = 0; i < n; i++)
-            lv.valid[i] = lv.Ce[i] > thr ? 255 : 0;
+        HIP_TRY(hipSetDevice(ctx->device));
+        const bool all = accept_all_last_scale && l == P - 1;
+        hipLaunchKernelGGL(k_valid_mask, dim3(stream_blocks(n)), dim3(256), 0, st, (const float*)lv.Ce.p, (uint8_t*)lv.valid.p, (long long)n,
+                           all ? -1.0f : p->edge_score_threshold);
+        HIP_TRY(hipGetLastError());
+        lv.raw.release();   // the level's raw volume has been taken by every device
     }
 
     // get_results(): f2c.hpp:302-324 on the first device
-    HIP_TRY(hipSetDevice(ctx->device));
-    std::vector<DevBuf> d_depth((size_t)P), d_valid((size_t)P);
     std::vector<const float*> dp((size_t)P);
     std::vector<const uint8_t*> vp((size_t)P);
     std::vector<int> Vp((size_t)P), Up((size_t)P);
     for (int l = 0; l < P; l++) {
-        Level& lv = levels[(size_t)l];
-        const size_t n = (size_t)S * lv.V * lv.U;
-        HIP_TRY(d_depth[(size_t)l].alloc(n * 4));
-        HIP_TRY(d_valid[(size_t)l].alloc(n));
-        HIP_TRY(hipMemcpyAsync(d_depth[(size_t)l].p, lv.depth.data(), n * 4, hipMemcpyHostToDevice, st));
-        HIP_TRY(hipMemcpyAsync(d_valid[(size_t)l].p, lv.valid.data(), n, hipMemcpyHostToDevice, st));
-        dp[(size_t)l] = (const float*)d_depth[(size_t)l].p;
-        vp[(size_t)l] = (const uint8_t*)d_valid[(size_t)l].p;
-        Vp[(size_t)l] = lv.V;
-        Up[(size_t)l] = lv.U;
+        dp[(size_t)l] = (const float*)levels[(size_t)l].depth.p;
+        vp[(size_t)l] = (const uint8_t*)levels[(size_t)l].valid.p;
+        Vp[(size_t)l] = levels[(size_t)l].V;
+        Up[(size_t)l] = levels[(size_t)l].U;
     }
     const size_t n0 = (size_t)S * V * U;
     DevBuf omap, ovalid;
