@@ -59,8 +59,8 @@ struct ScanArgs {
     // Hypothesis groups: `groups` workgroups share one tile, each taking a contiguous slice of the
     // hypothesis range (its 4 waves a quarter of the slice each).  groups == 1: the workgroup writes the
     // pixel itself.  groups > 1 (launches expected to be sparse, where the launch lasts as long as ONE
-    // wave's walk over its hypotheses): each workgroup leaves a partial record and k2_scan_combine merges
-    // them in hypothesis order.
+    // wave's walk over its hypotheses): each workgroup leaves a partial record and the last one to finish merges
+    // them in hypothesis order (scan_epilogue / combine_tile).
     int groups;
     struct Partial* partial;   // [tile][group][64]
     int* ticket;               // [tile], zero between launches: the group that draws the last ticket merges the tile

@@ -45,9 +45,10 @@ static int fail(int code, const char* fmt, ...)
 
 // ---- objects --------------------------------------------------------------
 
-// Streaming scan kernel: two workgroups per CU (two waves per SIMD) share the CU's 160 KiB of LDS; each has
-// 8 KiB of static LDS (the merge of the four waves' results), so 72 KiB of dynamic LDS per workgroup.
-static constexpr size_t kStreamLdsBytes = (size_t)80 << 10;   // two workgroups per CU: all of its 160 KiB (the kernel has no static LDS)
+// Streaming scan kernel: two workgroups per CU (two waves per SIMD) share the CU's 160 KiB of LDS.  The kernel has no
+// static LDS (the merge of the four waves' results uses the head of their dynamic regions, EpilogueBlock), so each
+// workgroup gets 80 KiB of dynamic LDS.
+static constexpr size_t kStreamLdsBytes = (size_t)80 << 10;
 constexpr int kSweepGroups = 32;    // workgroups sharing a packed tile's hypotheses on a sweep's sparse visits
 // Dense launches of the streaming kernel: this many workgroups share one tile's hypotheses.  The workgroups an
 // XCD runs together then sit on two or three tiles instead of a whole scanline, and what they gather from
