@@ -171,28 +171,42 @@ __global__ __launch_bounds__(256) void k5_max_partial(const float* __restrict__ 
 }
 
 // ---- bound tightening (rslf_fine_to_coarse.hpp:202-294) -----------------------------------------
-// Pass 1, one thread per finer-level row (s, v): nearest valid column strictly left (never column 0,
+// Pass 1, one wave per finer-level row (s, v): nearest valid column strictly left (never column 0,
 // the reference's `while (u_left > 1)`) and strictly right of every column, -1 if none.
-__global__ __launch_bounds__(64) void k5_nearest_valid(const uint8_t* __restrict__ mask_up, long long rows, int U,
-                                                      int* __restrict__ left, int* __restrict__ right)
+__global__ __launch_bounds__(256) void k5_nearest_valid(const uint8_t* __restrict__ mask_up, long long rows, int U,
+                                                       int* __restrict__ left, int* __restrict__ right)
 {
-    const long long row = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    // one WAVE per row, 64 columns at a time: a ballot of the chunk's valid columns answers every lane at once (highest
+    // set bit below the lane / lowest above it), and what lies beyond the chunk is carried in a scalar -- coalesced,
+    // where a thread walking its own row was neither parallel nor coalesced
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows)
         return;
+    const int lane = threadIdx.x & 63;
     const uint8_t* m = mask_up + row * U;
     int* L = left + row * U;
     int* R = right + row * U;
-    int last = -1;
-    for (int u = 0; u < U; u++) {
-        L[u] = last;                       // nearest valid column in [1, u-1]
-        if (u >= 1 && m[u] > 0)
-            last = u;
+    int carry = -1;                               // nearest valid column of the chunks before (never column 0)
+    for (int u0 = 0; u0 < U; u0 += 64) {
+        const int u = u0 + lane;
+        const bool v = u < U && u >= 1 && m[u] > 0;
+        const unsigned long long b = __ballot(v);
+        const unsigned long long below = b & ((1ull << lane) - 1ull);
+        if (u < U)
+            L[u] = below ? u0 + 63 - __clzll((long long)below) : carry;   // nearest valid column in [1, u-1]
+        if (b)
+            carry = u0 + 63 - __clzll((long long)b);
     }
-    last = -1;
-    for (int u = U - 1; u >= 0; u--) {
-        R[u] = last;                       // nearest valid column in [u+1, U-1]
-        if (m[u] > 0)
-            last = u;
+    carry = -1;                                   // nearest valid column of the chunks after
+    for (int u0 = ((U - 1) / 64) * 64; u0 >= 0; u0 -= 64) {
+        const int u = u0 + lane;
+        const bool v = u < U && m[u] > 0;
+        const unsigned long long b = __ballot(v);
+        const unsigned long long above = lane == 63 ? 0ull : (b >> (lane + 1));
+        if (u < U)
+            R[u] = above ? u + 1 + __ffsll((long long)above) - 1 : carry;   // nearest valid column in [u+1, U-1]
+        if (b)
+            carry = u0 + __ffsll((long long)b) - 1;
     }
 }
 

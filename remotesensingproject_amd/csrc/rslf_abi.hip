@@ -1799,7 +1799,7 @@ extern "C" int rslf_f2c_tighten_bounds(rslf_ctx* ctx, const float* d_depth_up_sv
         return rc;
     hipStream_t st = ctx->stream;
     const long long rows = (long long)S * V_up;
-    hipLaunchKernelGGL(k5_nearest_valid, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, st, d_valid_up_svu, rows, U_up,
+    hipLaunchKernelGGL(k5_nearest_valid, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, d_valid_up_svu, rows, U_up,
                        (int*)left_p, (int*)right_p);
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(k5_tighten, dim3((U_down + 255) / 256, V_down, S), dim3(256), 0, st, d_depth_up_svu, (const int*)left_p,
