@@ -1465,6 +1465,7 @@ constexpr int scan_reg_waves(int spad, int c)
     // ... and where the working set is smaller than the 64 / 96 assumed, the extra wave costs no scratch at all
     if (c == 1 && (spad == 48 || spad == 40)) return 5;   // 40: c2 (33 views) +2 %
     if (c == 3 && spad == 24) return 4;
+    if (c == 1 && spad == 16) return 7;    // c1 (9 views) +2.5 %
     return w > 8 ? 8 : (w < 1 ? 1 : w);
 }
 
