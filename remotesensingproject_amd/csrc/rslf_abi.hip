@@ -75,6 +75,7 @@ struct rslf_ctx {
     bool ev_valid = false;
     int last_spad = 0;   // register-scan slot count of the last K2 launch, 0 = none
     int last_kernel = 0; // RSLF_SCAN_* of the last K2 launch
+    int num_cus = 0;           // compute units of the device (how many workgroups a launch needs to fill it)
     bool keep_total = false;   // the 2-D sweep sums the scanned pixels of all its visits
     int scan_groups = 1;       // hypothesis groups per tile for the next scan launches (the 2-D sweep raises it)
     bool scan_packed = false;  // next scan launches use one packed pixel list (sparse visits of the 2-D sweep)
@@ -294,6 +295,7 @@ extern "C" int rslf_ctx_create(int device, rslf_ctx** out)
     if (!ctx)
         return fail(RSLF_ERR_ALLOC, "out of host memory");
     ctx->device = device;
+    (void)hipDeviceGetAttribute(&ctx->num_cus, hipDeviceAttributeMultiprocessorCount, device);
     hipError_t e = hipMalloc(&ctx->total, 2 * sizeof(unsigned long long));   // [0] scanned pixels, [1] packed-list length (int)
     if (e == hipSuccess)
         e = hipMalloc(&ctx->minmax, 2 * sizeof(float));
@@ -974,6 +976,20 @@ extern "C" int rslf_depth_epi_scan(rslf_ctx* ctx, const rslf_volume* vol, const 
     // workgroups gather from at any one time fits its L2 (kStreamGroups)
     if (use_stream && groups == 1 && !packed)
         groups = ctx->stream_groups > 0 ? ctx->stream_groups : kStreamGroups;
+    // A dense launch of a register kernel whose grid is only a few rounds of workgroups pays for its last, partly empty
+    // round: 139 scanlines of c3 (one GPU's share of eight) are 5.4 rounds and took 9.3 ms where 8.5 would do.  Sharing
+    // each tile's hypotheses among 2-8 workgroups makes the rounds shorter and more numerous (measured on that shard:
+    // 9.25 / 8.73 / 8.58 / 8.46 ms with 1 / 2 / 4 / 8 groups; a quarter of the field 17.2 -> 16.6 ms with 4).
+    if (spad && groups == 1 && !packed && ctx->num_cus > 0) {
+        const long long tiles = (long long)vol->V * ((vol->U + 63) / 64);
+        const long long resident = (long long)ctx->num_cus * scan_reg_waves(spad, vol->C);
+        // ... as long as a wave keeps at least eight hypotheses and ~256 (hypothesis, view) pairs: below that its fixed
+        // costs per tile (offset table, merge) outweigh the shorter rounds (c1, 64 hypotheses over 9 views: +25 % with
+        // eight groups, +3 % with two)
+        while (groups < 8 && tiles * groups < 40 * resident && dim_d >= 8 * kScanWaves * 2 * groups &&
+               (long long)(dim_d / (kScanWaves * 2 * groups)) * vol->S >= 256)
+            groups *= 2;
+    }
     if (ctx->force_groups > 0)   // parity tests: sparse-launch shapes on the pile path too (rslf_ctx_set_debug)
         groups = std::min(64, ctx->force_groups);
     if (ctx->force_packed >= 0)
