@@ -15,8 +15,10 @@
  *
  * Conventions
  *  - plain C, no C++/torch/OpenCV types; every function returns an rslf_status
- *    (0 = ok, <0 = error) and never throws across the boundary.  (The
- *    reference returns void and has no error convention: SURVEY.md 8b.)
+ *    (0 = ok, <0 = error) and never throws across the boundary: every entry
+ *    point is a function-try-block (std::bad_alloc -> RSLF_ERR_ALLOC, anything
+ *    else -> RSLF_ERR_INTERNAL), and worker threads are joined on every path.
+ *    (The reference returns void and has no error convention: SURVEY.md 8b.)
  *  - pointers named d_* are DEVICE pointers, h_* are HOST pointers; all
  *    buffers are caller-owned; planes are dense row-major [V][U].
  *  - work is enqueued on the context's stream (rslf_ctx_set_stream, a
@@ -35,7 +37,7 @@
 extern "C" {
 #endif
 
-#define RSLF_ABI_VERSION 4
+#define RSLF_ABI_VERSION 5
 
 typedef enum rslf_status {
     RSLF_OK = 0,
@@ -43,7 +45,8 @@ typedef enum rslf_status {
     RSLF_ERR_UNSUPPORTED = -2,   /* channel count other than 1 or 3, filter sizes the kernels do not cover */
     RSLF_ERR_HIP = -3,           /* a HIP runtime call failed; see rslf_last_error() */
     RSLF_ERR_NO_DEVICE = -4,     /* no gfx950 device visible */
-    RSLF_ERR_ALLOC = -5
+    RSLF_ERR_ALLOC = -5,         /* device or host memory could not be had (hipMalloc, std::bad_alloc) */
+    RSLF_ERR_INTERNAL = -6       /* a C++ exception was stopped at the boundary; its text is in rslf_last_error() */
 } rslf_status;
 
 /* Mirrors rslf::Depth1DParameters<T> -- include/rslf_depth_computation_core.hpp:66-142
@@ -132,6 +135,11 @@ int rslf_ctx_synchronize(rslf_ctx* ctx);
  *   "stream_lds_kib" dynamic LDS of one streaming workgroup, KiB (default 72)
  * Results never depend on these (the parity tests drive every combination); speed does. */
 int rslf_ctx_set_debug(rslf_ctx* ctx, const char* key, int value);
+/* Fault injection for the tests of the error paths (process-wide, off unless armed): the next `count` visits of `site`
+ * fail as if the runtime had -- "worker": a device worker of rslf_multi_* throws std::runtime_error; "thread_create":
+ * std::thread cannot be started (the work then runs on the calling thread); "alloc": std::bad_alloc in a worker.
+ * The entry point reports a status; nothing is left running, nothing leaks.  count = 0 disarms. */
+int rslf_debug_inject(const char* site, int count);
 
 /* ---- volume: replaces Depth1DComputer_pile's constructor --------------- */
 /* include/rslf_depth_computation.hpp:425-477: the constructor copies the
@@ -270,6 +278,10 @@ typedef struct rslf_multi rslf_multi;
 int rslf_multi_create(const int* devices, int n_devices, rslf_multi** out);
 int rslf_multi_destroy(rslf_multi* m);
 int rslf_multi_device_count(const rslf_multi* m);
+/* 1 if worker `from` can map worker `to`'s memory (hipDeviceCanAccessPeer) and the access has been enabled -- copies
+ * between them then go device to device over xGMI; 0 if the copies stage through the host (still correct); 1 for two
+ * workers on one GPU; <0 on a bad index.  rslf_multi_create enables peer access for every pair that allows it. */
+int rslf_multi_peer_access(const rslf_multi* m, int from, int to);
 int rslf_multi_set_chunk_rows(rslf_multi* m, int rows);   /* scanlines per chunk; 0 = automatic (about 8 chunks per device) */
 int rslf_multi_depth1d_pile_f32(rslf_multi* m, const float* const* h_epis, size_t row_stride_bytes, int V, int S, int U, int C,
                                 float epi_scale_factor, float dmin, float dmax, int dim_d, int s_hat, const rslf_params* p,

@@ -12,13 +12,13 @@ from . import build as _build
 
 _LIB = None
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 # every symbol include/rslf_hip.h declares
 SYMBOLS = [
     "rslf_abi_version", "rslf_status_string", "rslf_last_error", "rslf_device_count", "rslf_default_params",
-    "rslf_ctx_create", "rslf_ctx_destroy", "rslf_ctx_set_stream", "rslf_ctx_synchronize", "rslf_ctx_set_debug",
-    "rslf_multi_create", "rslf_multi_destroy", "rslf_multi_device_count", "rslf_multi_set_chunk_rows",
+    "rslf_ctx_create", "rslf_ctx_destroy", "rslf_ctx_set_stream", "rslf_ctx_synchronize", "rslf_ctx_set_debug", "rslf_debug_inject",
+    "rslf_multi_create", "rslf_multi_destroy", "rslf_multi_device_count", "rslf_multi_set_chunk_rows", "rslf_multi_peer_access",
     "rslf_multi_depth1d_pile_f32", "rslf_multi_depth1d_pile_u8", "rslf_multi_depth1d_pile_f32_dev",
     "rslf_multi_depth2d_run_f32", "rslf_multi_depth2d_run_u8", "rslf_multi_fine_to_coarse_run_host",
     "rslf_volume_create", "rslf_volume_destroy", "rslf_volume_describe",
@@ -153,6 +153,8 @@ def lib():
     L.rslf_multi_destroy.argtypes = [vp]
     L.rslf_multi_device_count.argtypes = [vp]
     L.rslf_multi_set_chunk_rows.argtypes = [vp, ci]
+    L.rslf_multi_peer_access.argtypes = [vp, ci, ci]
+    L.rslf_debug_inject.argtypes = [C.c_char_p, ci]
     L.rslf_multi_depth1d_pile_f32.argtypes = [vp, C.POINTER(vp), C.c_size_t, ci, ci, ci, ci, cf, cf, cf, ci, ci, C.POINTER(RslfParams),
                                               vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(RslfStats), C.POINTER(cf)]
     L.rslf_multi_depth1d_pile_f32_dev.argtypes = [vp, C.POINTER(vp), C.c_size_t, ci, ci, ci, ci, cf, cf, cf, ci, ci, C.POINTER(RslfParams), ci,

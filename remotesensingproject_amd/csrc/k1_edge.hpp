@@ -1,146 +1,15 @@
-// K0 (pack), K1 (edge confidence) and the confident-pixel compaction.
+// K1 (edge confidence, optional opening of its mask) and the confident-pixel compaction.  (K0: k0_pack.hpp.)
+// Included by rslf_pile.hip only (the non-template kernels: one definition per library).
 //
 // These touch each voxel / pixel a constant number of times: HBM-bound,
 // coalesced along u, negligible next to the scan.
 #pragma once
 
 #include "rslf_device.hpp"
+#include "rslf_plan.hpp"   // MorphElement
+#include "k_compact.hpp"
 
 namespace rslf {
-
-// ---- K0: normalise + copy into the slab --------------------------------------
-// Replaces Depth1DComputer_pile's constructor copy/convertTo
-// (include/rslf_depth_computation.hpp:463-477) and, for the image-major source,
-// rslf::build_epis_from_imgs (src/rslf_io.cpp:194-227).
-// The slab row of (v, s) is pitch pixels x C interleaved channels (rslf_device.hpp).
-//   EPI-major   source: element (v,s,u,c) at src[((v*S + s)*U + u)*C + c]
-//   image-major source: element (v,s,u,c) at src[((s*V + v)*U + u)*C + c]
-// One block per (v, s) row; block-level min/max partials for the volume range.
-template <typename SrcT, bool IMAGE_MAJOR>
-__global__ __launch_bounds__(256) void k0_pack(const SrcT* __restrict__ src, float* __restrict__ dst,
-                                              int V0, int Vn, int Vsrc, int S, int U, int C, int pitch,
-                                              float scale, float* __restrict__ partial_minmax)
-{
-    const int row = blockIdx.x;   // over Vn * S
-    const int vl = row / S;       // local scanline of this chunk
-    const int s = row - vl * S;
-    const int v = V0 + vl;
-    const long long src_row = IMAGE_MAJOR ? ((long long)s * Vsrc + vl) : ((long long)vl * S + s);
-    const SrcT* in = src + src_row * (long long)U * C;
-    float* out = dst + ((long long)v * S + s) * (long long)C * pitch;
-
-    float mn = INFINITY, mx = -INFINITY;
-    // source and slab rows are both pixel-major with interleaved channels: a scaled copy, then zero padding
-    for (int i = threadIdx.x; i < pitch * C; i += blockDim.x) {
-        float x = 0.0f;   // zero padding beyond U (a 0-weight tap must stay finite)
-        if (i < U * C) {
-            // dc.hpp:470 / :474: convertTo with a float scale
-            x = (float)in[i] * scale;
-            mn = (x != x) ? -INFINITY : fminf(mn, x);   // a NaN radiance sends the scan to the generic kernel,
-            mx = fmaxf(mx, x);                          // the only variant that keeps NaNs apart (fminf would skip it)
-        }
-        out[i] = x;
-    }
-    // block reduce
-    for (int o = 32; o > 0; o >>= 1) {
-        mn = fminf(mn, __shfl_xor(mn, o));
-        mx = fmaxf(mx, __shfl_xor(mx, o));
-    }
-    __shared__ float smn[4], smx[4];
-    const int w = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) {
-        smn[w] = mn;
-        smx[w] = mx;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int i = 1; i < (int)(blockDim.x >> 6); i++) {
-            mn = fminf(mn, smn[i]);
-            mx = fmaxf(mx, smx[i]);
-        }
-        partial_minmax[2 * (long long)row] = mn;
-        partial_minmax[2 * (long long)row + 1] = mx;
-    }
-}
-
-// Image-major source with the per-EPI options of rslf::build_epis_from_imgs (src/rslf_io.cpp:194-227): the EPI
-// of scanline v is E[i][x] = img_i(v, x); `transpose` makes the slab hold E^T (views = image columns, columns =
-// images), `rotate_180` then turns the result by 180 degrees (both axes reversed).  src: [n_imgs][Vn][cols*C] of
-// this chunk.  One block per slab row (v, s); the reads are strided when transposed -- a one-off pass.
-template <typename SrcT>
-__global__ __launch_bounds__(256) void k0_pack_images_xf(const SrcT* __restrict__ src, float* __restrict__ dst, int V0, int Vn,
-                                                        int n_imgs, int cols, int S, int U, int C, int pitch, float scale,
-                                                        int transpose, int rotate_180, float* __restrict__ partial_minmax)
-{
-    const int row = blockIdx.x;   // over Vn * S
-    const int vl = row / S;
-    const int s = row - vl * S;
-    const int v = V0 + vl;
-    float* out = dst + ((long long)v * S + s) * (long long)C * pitch;
-    float mn = INFINITY, mx = -INFINITY;
-    for (int i = threadIdx.x; i < pitch * C; i += blockDim.x) {
-        const int u = i / C, c = i - u * C;
-        float x = 0.0f;
-        if (u < U) {
-            const int sr = rotate_180 ? S - 1 - s : s;      // position in the un-rotated EPI
-            const int ur = rotate_180 ? U - 1 - u : u;
-            const int img = transpose ? ur : sr;            // E^T[s][u] = E[u][s]
-            const int col = transpose ? sr : ur;
-            x = (float)src[(((long long)img * Vn + vl) * cols + col) * C + c] * scale;
-            mn = (x != x) ? -INFINITY : fminf(mn, x);   // a NaN radiance sends the scan to the generic kernel,
-            mx = fmaxf(mx, x);                          // the only variant that keeps NaNs apart (fminf would skip it)
-        }
-        out[i] = x;
-    }
-    for (int o = 32; o > 0; o >>= 1) {
-        mn = fminf(mn, __shfl_xor(mn, o));
-        mx = fmaxf(mx, __shfl_xor(mx, o));
-    }
-    __shared__ float smn[4], smx[4];
-    const int w = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) {
-        smn[w] = mn;
-        smx[w] = mx;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int i = 1; i < (int)(blockDim.x >> 6); i++) {
-            mn = fminf(mn, smn[i]);
-            mx = fmaxf(mx, smx[i]);
-        }
-        partial_minmax[2 * (long long)row] = mn;
-        partial_minmax[2 * (long long)row + 1] = mx;
-    }
-}
-
-// Folds the per-row partials into minmax[0..1] (running values, so chunks chain).
-__global__ __launch_bounds__(256) void k0_minmax_final(const float* __restrict__ partial, int n, float* __restrict__ minmax)
-{
-    float mn = INFINITY, mx = -INFINITY;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        mn = fminf(mn, partial[2 * i]);
-        mx = fmaxf(mx, partial[2 * i + 1]);
-    }
-    for (int o = 32; o > 0; o >>= 1) {
-        mn = fminf(mn, __shfl_xor(mn, o));
-        mx = fmaxf(mx, __shfl_xor(mx, o));
-    }
-    __shared__ float smn[4], smx[4];
-    const int w = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) {
-        smn[w] = mn;
-        smx[w] = mx;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int i = 1; i < 4; i++) {
-            mn = fminf(mn, smn[i]);
-            mx = fmaxf(mx, smx[i]);
-        }
-        minmax[0] = fminf(minmax[0], mn);
-        minmax[1] = fmaxf(minmax[1], mx);
-    }
-}
 
 // ---- K1: edge confidence ---------------------------------------------------
 // rslf::compute_1D_edge_confidence (core.hpp:426-478) for every scanline
@@ -266,11 +135,6 @@ __global__ __launch_bounds__(256) void k1_edge_confidence_compact(VolView vol, i
 // One pass = erosion (min) or dilation (max) over the element's set pixels around the anchor (k/2, k/2);
 // pixels outside the plane never win (morphologyDefaultBorderValue).  The element arrives as one bit row
 // per kernel row (k <= 31).  HBM-bound byte work: k*k mask reads per pixel, served by L1/L2.
-struct MorphElement {
-    int k;
-    unsigned rows[31];
-};
-
 __global__ __launch_bounds__(256) void k1_morph_pass(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int V, int U,
                                                     MorphElement el, int dilate)
 {
@@ -344,65 +208,7 @@ __global__ __launch_bounds__(256) void k_compact_mask(const uint8_t* __restrict_
     }
 }
 
-// Packed variant for sparse launches: ONE list of pixel indices v*U + u over all scanlines, so that a
-// scan wavefront is full even when a scanline holds two or three pixels.  A block counts its row, claims
-// a range of the list with one atomic (rows land in arrival order; a pixel's result does not depend on
-// where in the list it sits), then writes the row's ascending u.  *packed_n must be 0 on entry.
-__device__ __forceinline__ void compact_row_packed(int v, const uint8_t* __restrict__ edge_mask, uint8_t* scan_mask, int U,
-                                                   int* __restrict__ list, int* __restrict__ count,
-                                                   unsigned long long* __restrict__ total, int* __restrict__ packed_n)
-{
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    __shared__ int wave_tot[4];
-    __shared__ int base_s;
-    int mine = 0;
-    for (int u = threadIdx.x; u < U; u += 256) {
-        uint8_t m = edge_mask[(long long)v * U + u];
-        if (scan_mask)
-            m &= scan_mask[(long long)v * U + u];
-        mine += m != 0;
-    }
-    for (int o = 32; o > 0; o >>= 1)
-        mine += __shfl_xor(mine, o);
-    if (lane == 0)
-        wave_tot[w] = mine;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const int row = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
-        count[v] = row;
-        base_s = row ? atomicAdd(packed_n, row) : 0;
-        if (row)
-            atomicAdd(total, (unsigned long long)row);
-    }
-    __syncthreads();
-    for (int u0 = 0; u0 < U; u0 += 256) {
-        const int u = u0 + threadIdx.x;
-        bool f = false;
-        if (u < U) {
-            uint8_t m = edge_mask[(long long)v * U + u];
-            if (scan_mask) {
-                m &= scan_mask[(long long)v * U + u];
-                scan_mask[(long long)v * U + u] = m;
-            }
-            f = m != 0;
-        }
-        const unsigned long long b = __ballot(f);
-        const int rank = __popcll(b & ((1ull << lane) - 1ull));
-        if (lane == 0)
-            wave_tot[w] = __popcll(b);
-        __syncthreads();
-        int off = base_s;
-        for (int i = 0; i < w; i++)
-            off += wave_tot[i];
-        if (f)
-            list[off + rank] = (int)((unsigned)v * (unsigned)U + (unsigned)u);
-        __syncthreads();
-        if (threadIdx.x == 0)
-            base_s += wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
-        __syncthreads();
-    }
-}
-
+// (compact_row_packed: k_compact.hpp -- the 2-D sweep's apply pass lists the next visit's pixels with it too)
 __global__ __launch_bounds__(256) void k_compact_mask_packed(const uint8_t* __restrict__ edge_mask, uint8_t* __restrict__ scan_mask,
                                                             int U, int* __restrict__ list, int* __restrict__ count,
                                                             unsigned long long* __restrict__ total, int* __restrict__ packed_n)

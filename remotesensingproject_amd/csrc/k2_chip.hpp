@@ -1,0 +1,339 @@
+// K2, on-chip variant (k2_scan_chip): RGB light fields with more views than two waves per SIMD can hold on chip --
+// BASELINE.json's 201-view RGB config (c5).
+//
+// The streaming variant (k2_stream.hpp) runs two waves per SIMD: 256 registers and 20 KiB of LDS per wave hold 92 of a
+// unit's 201 RGB samples, and the other 109 are re-gathered on each of the ten mean-shift passes -- 34 vector
+// instructions and a 12-byte L1 read per sample and pass against 19 for a sample that is at hand; three quarters of
+// its time.  Here a wave has its SIMD to itself: 512 registers (the unified file: 256 VGPRs + 256 AGPRs) and a quarter
+// of the CU's 160 KiB of LDS hold EVERY sample of a unit --
+//     [0, NV)              in VGPRs, as register pairs (s, s+1) per channel
+//     [NV, NV + NA)        in AGPRs: one v_accvgpr_read_b32 per value and pass (VALU operands cannot name an AGPR)
+//     [NV + NA, .. + NL)   in LDS, [pair][channel][lane] as 8-byte pairs: one conflict-free ds_read_b64 per pair and channel
+//     the rest (S - NV - NA - NL samples, 1 at c5) re-gathered per pass, as the streaming kernel's tail is
+// -- gathered ONCE per hypothesis.  A wave alone on its SIMD issues one instruction every ~5 clocks whatever it is
+// (tools/ubench_valu.hip), so the pass runs in packed fp32 on sample pairs: v_pk_add / v_pk_mul do two samples' work per
+// issue slot, each half the scalar instruction's IEEE operation (tools/ubench_pk.hip).  The two running sums still take
+// one sample at a time in ascending s (core.hpp:602-603).  No scratch: the kernel's HBM traffic is the slab read once.
+//
+// Dense row-tile launches with one hypothesis grid for all pixels only (no per-pixel [dmin, dmax] planes, no packed
+// lists): everything else stays with the streaming kernel.
+#pragma once
+
+#include "k2_scan.hpp"
+
+namespace rslf {
+
+// samples per tier (all even: the pass works on pairs).  NV: 3 * NV VGPRs beside ~60 of working state; NA: 3 * NA <= 256
+// AGPRs; NL: what a quarter of the CU's LDS holds behind the wave's offset table.
+#ifndef RSLF_CHIP_NV
+#define RSLF_CHIP_NV 60
+#endif
+#ifndef RSLF_CHIP_NA
+#define RSLF_CHIP_NA 84
+#endif
+#ifndef RSLF_CHIP_NL
+#define RSLF_CHIP_NL 52
+#endif
+constexpr int kChipNV = RSLF_CHIP_NV, kChipNA = RSLF_CHIP_NA, kChipNL = RSLF_CHIP_NL;
+constexpr int kChipOnChip = kChipNV + kChipNA + kChipNL;
+constexpr size_t kChipLdsBytes = (size_t)160 << 10;   // one workgroup per CU takes all of it
+static_assert(kChipNV % 4 == 0 && kChipNA % 4 == 0 && kChipNL % 4 == 0, "gather batches of four samples, pairs in the pass");
+static_assert(3 * kChipNA <= 256, "AGPR tier");
+
+// floats of dynamic LDS per wave: [view offsets, S rounded up to 4][NL samples x 3 channels x 64 lanes]
+__host__ __device__ constexpr int chip_wave_floats(int S) { return ((S + 3) & ~3) + kChipNL * 3 * 64; }
+// the kernel takes volumes whose on-chip tiers are all in use and whose per-wave LDS share fits
+__host__ __device__ constexpr bool chip_takes(int S, int C)
+{
+    return C == 3 && S >= kChipOnChip && (size_t)chip_wave_floats(S) * 4 * kScanWaves <= kChipLdsBytes;
+}
+
+__device__ __forceinline__ float agpr_put(float v)
+{
+    float a;
+    asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(a) : "v"(v));
+    return a;
+}
+__device__ __forceinline__ float agpr_get(float a)
+{
+    float v;
+    asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(a));
+    return v;
+}
+
+// One pair of samples (s, s+1) of one RGB pass in packed fp32: per channel delta = R - rbar, t = kq * delta,
+// q = t * delta; qs = (q0 + q2) + q1 (OpenCV 3.x reduceC_); K = clamp(1 - qs); P_c = R_c * K.  rbar arrives as two
+// register pairs {rbar0, rbar1}, {rbar2, -} and is broadcast to both halves by op_sel; 15 packed instructions.
+__device__ __forceinline__ void chip_pair(f2 r0, f2 r1, f2 r2, f2 m01, f2 m2x, f2 kq, f2& P0, f2& P1, f2& P2, f2& K)
+{
+    f2 d0, d1, d2;
+    asm("v_pk_add_f32 %[d0], %[r0], %[m01] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 %[d1], %[r1], %[m01] op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 %[d2], %[r2], %[m2x] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_mul_f32 %[t0], %[kq], %[d0] op_sel_hi:[0,1]\n\t"
+        "v_pk_mul_f32 %[t1], %[kq], %[d1] op_sel_hi:[0,1]\n\t"
+        "v_pk_mul_f32 %[t2], %[kq], %[d2] op_sel_hi:[0,1]\n\t"
+        "v_pk_mul_f32 %[d0], %[d0], %[t0]\n\t"
+        "v_pk_mul_f32 %[d2], %[d2], %[t2]\n\t"
+        "v_pk_mul_f32 %[d1], %[d1], %[t1]\n\t"
+        "v_pk_add_f32 %[d0], %[d0], %[d2]\n\t"
+        "v_pk_add_f32 %[d0], %[d0], %[d1]\n\t"
+        "v_pk_add_f32 %[k], 1.0, %[d0] op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1] clamp\n\t"
+        "v_pk_mul_f32 %[t0], %[r0], %[k]\n\t"
+        "v_pk_mul_f32 %[t1], %[r1], %[k]\n\t"
+        "v_pk_mul_f32 %[t2], %[r2], %[k]"
+        : [d0] "=&v"(d0), [d1] "=&v"(d1), [d2] "=&v"(d2), [t0] "=&v"(P0), [t1] "=&v"(P1), [t2] "=&v"(P2), [k] "=&v"(K)
+        : [r0] "v"(r0), [r1] "v"(r1), [r2] "v"(r2), [m01] "v"(m01), [m2x] "v"(m2x), [kq] "v"(kq));
+}
+
+// the sums take sample s, then sample s + 1 (core.hpp:602-603), one IEEE add each
+__device__ __forceinline__ void chip_accumulate(const f2& P0, const f2& P1, const f2& P2, const f2& K, float (&A)[3], float& B)
+{
+    A[0] = A[0] + P0.x;
+    A[1] = A[1] + P1.x;
+    A[2] = A[2] + P2.x;
+    B = B + K.x;
+    A[0] = A[0] + P0.y;
+    A[1] = A[1] + P1.y;
+    A[2] = A[2] + P2.y;
+    B = B + K.y;
+}
+
+// BORDER: some sample line of this wave may leave [0, U-1] for some hypothesis of the run: test validity per sample.
+template <bool BORDER>
+__device__ __forceinline__ void scan_chip_body(const ScanArgs& a, int v, int u, int d0, int d1, Best<3>& best, float* __restrict__ otab)
+{
+    constexpr int C = 3, NV = kChipNV, NA = kChipNA, NL = kChipNL, GB = 4;
+    const VolView& vol = a.vol;
+    const float* epi = vol.row(v, 0);
+    const float uf = (float)u;
+    const unsigned Um1_bits = __float_as_uint((float)(vol.U - 1));
+    const int S = vol.S;
+    const int lane = threadIdx.x & 63;
+    const float range = a.dmax - a.dmin;
+    const float denom = (float)(a.dim_d - 1);
+    const float slope = a.k.slope;
+    const f2 kq2 = {a.k.inv_h2, a.k.inv_h2};
+    const unsigned stride_b = (unsigned)vol.stride_s << 2;
+    const float* centre_p = epi + (long long)a.s_hat * vol.stride_s + u * C;
+    // LDS tier: [pair][channel][lane] as f2 behind the offset table
+    f2* park = reinterpret_cast<f2*>(otab + ((S + 3) & ~3)) + lane;
+
+    // one sample's two taps and its blend (interp.hpp:179-190); `rowb` = byte offset of view s's row in the EPI
+    auto taps = [&](int s, unsigned rowb, float (&e0)[C], float (&e1)[C], float& tt, bool& ok) {
+        float x = otab[s];                       // fl(fl(float(s_hat - s) * D[d]) * slope), one broadcast read for the wave
+        x = x + uf;                              // core.hpp:552
+        tt = lerp_weight(x);                     // interp.hpp:181
+        int i0 = floor_to_int(x);                // interp.hpp:179
+        ok = true;
+        if (BORDER) {
+            ok = __float_as_uint(x) <= Um1_bits; // interp.hpp:182 (x is never -0)
+            i0 = ok ? i0 : 0;
+        }
+        const float* p = (const float*)((const char*)epi + (__umul24((unsigned)i0, 4u * C) + rowb));
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            e0[c] = p[c];
+            e1[c] = p[C + c];
+        }
+    };
+    auto blend = [&](const float (&e0)[C], const float (&e1)[C], float tt, bool ok, float (&r)[C]) {
+        const float omt = 1.0f - tt;
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            const float m0 = omt * e0[c];        // interp.hpp:184
+            const float m1 = tt * e1[c];
+            const float rr = m0 + m1;
+            r[c] = (BORDER && !ok) ? kSentinel : rr;   // interp.hpp:189 stand-in: K = 0 and r * K = 0 exactly
+        }
+    };
+
+#pragma unroll 1
+    for (int d = d0; d < d1; d++) {
+        const float Dd = hypothesis(a.dmin, range, denom, d);
+        for (int s = lane; s < S; s += 64) {
+            float off = (float)(a.s_hat - s) * Dd;   // core.hpp:542,550
+            off = off * slope;                       // core.hpp:551
+            otab[s] = off;
+        }
+        __builtin_amdgcn_wave_barrier();
+        int card = BORDER ? 0 : S;
+
+        f2 Rv[C][NV / 2];
+        float Ra[C][NA];
+        unsigned rowb = 0;
+        asm volatile("" : "+s"(rowb));
+        // ---- gather, once per hypothesis: batches of four samples, all eight loads in flight before the first blend
+#pragma unroll
+        for (int g = 0; g < (NV + NA) / GB; g++) {
+            float e0[GB][C], e1[GB][C], tt[GB], r[GB][C];
+            bool ok[GB];
+#pragma unroll
+            for (int j = 0; j < GB; j++) {
+                taps(g * GB + j, rowb, e0[j], e1[j], tt[j], ok[j]);
+                rowb += stride_b;
+            }
+#pragma unroll
+            for (int j = 0; j < GB; j++) {
+                blend(e0[j], e1[j], tt[j], ok[j], r[j]);
+                if (BORDER)
+                    card += ok[j] ? 1 : 0;
+            }
+#pragma unroll
+            for (int j = 0; j < GB; j++) {
+                const int s = g * GB + j;
+#pragma unroll
+                for (int c = 0; c < C; c++) {
+                    if (s < NV) {
+                        if (s & 1)
+                            Rv[c][s >> 1].y = r[j][c];
+                        else
+                            Rv[c][s >> 1].x = r[j][c];
+                    } else {
+                        Ra[c][s - NV] = agpr_put(r[j][c]);
+                    }
+                }
+            }
+            // pin the batch: its values exist here, and the next batch's address state is opaque -- else hipcc turns the
+            // unrolled gather into "all loads, then all blends" and parks the texels in scratch (k2_reg.hpp)
+            if (g * GB < NV) {
+#pragma unroll
+                for (int c = 0; c < C; c++)
+                    asm volatile("" : "+v"(Rv[c][g * GB / 2]), "+v"(Rv[c][g * GB / 2 + 1]));
+            }
+            asm volatile("" : "+s"(rowb), "+v"(card));
+        }
+        // the LDS tier, a rolled loop: pairs go out as 8-byte stores
+#pragma unroll 1
+        for (int s0 = NV + NA; s0 < NV + NA + NL; s0 += GB) {
+            float e0[GB][C], e1[GB][C], tt[GB], r[GB][C];
+            bool ok[GB];
+#pragma unroll
+            for (int j = 0; j < GB; j++) {
+                taps(s0 + j, rowb, e0[j], e1[j], tt[j], ok[j]);
+                rowb += stride_b;
+            }
+#pragma unroll
+            for (int j = 0; j < GB; j++) {
+                blend(e0[j], e1[j], tt[j], ok[j], r[j]);
+                if (BORDER)
+                    card += ok[j] ? 1 : 0;
+            }
+            const int p0 = (s0 - NV - NA) >> 1;
+#pragma unroll
+            for (int j = 0; j < GB; j += 2)
+#pragma unroll
+                for (int c = 0; c < C; c++)
+                    park[((p0 + (j >> 1)) * C + c) * 64] = f2{r[j][c], r[j + 1][c]};
+        }
+
+        float rbar[C];
+#pragma unroll
+        for (int c = 0; c < C; c++)
+            rbar[c] = centre_p[c];                   // core.hpp:577: R[s_hat] = E[s_hat][u] exactly (re-read: L1 / L2)
+        float B = 0.0f;
+        int ncard = card;
+#pragma unroll 1
+        for (int it = 0; it < a.k.n_iter; it++) {    // core.hpp:584-610
+            float A[C] = {0.0f, 0.0f, 0.0f};
+            B = 0.0f;
+            const f2 m01 = {rbar[0], rbar[1]}, m2x = {rbar[2], rbar[2]};
+            f2 P0, P1, P2, K;
+            // VGPR tier
+#pragma unroll
+            for (int p = 0; p < NV / 2; p++) {
+                chip_pair(Rv[0][p], Rv[1][p], Rv[2][p], m01, m2x, kq2, P0, P1, P2, K);
+                chip_accumulate(P0, P1, P2, K, A, B);
+            }
+            // AGPR tier
+#pragma unroll
+            for (int p = 0; p < NA / 2; p++) {
+                const f2 r0 = {agpr_get(Ra[0][2 * p]), agpr_get(Ra[0][2 * p + 1])};
+                const f2 r1 = {agpr_get(Ra[1][2 * p]), agpr_get(Ra[1][2 * p + 1])};
+                const f2 r2 = {agpr_get(Ra[2][2 * p]), agpr_get(Ra[2][2 * p + 1])};
+                chip_pair(r0, r1, r2, m01, m2x, kq2, P0, P1, P2, K);
+                chip_accumulate(P0, P1, P2, K, A, B);
+            }
+            // LDS tier
+#pragma unroll 2
+            for (int p = 0; p < NL / 2; p++) {
+                const f2 r0 = park[(p * C + 0) * 64], r1 = park[(p * C + 1) * 64], r2 = park[(p * C + 2) * 64];
+                chip_pair(r0, r1, r2, m01, m2x, kq2, P0, P1, P2, K);
+                chip_accumulate(P0, P1, P2, K, A, B);
+            }
+            // what no tier holds: re-gathered on every pass, one sample at a time (1 of 201 at c5)
+            ncard = card;
+#pragma unroll 1
+            for (int s = NV + NA + NL; s < S; s++) {
+                float e0[C], e1[C], tt, r[C], q[C];
+                bool ok;
+                taps(s, (unsigned)s * stride_b, e0, e1, tt, ok);
+                blend(e0, e1, tt, ok, r);
+#pragma unroll
+                for (int c = 0; c < C; c++) {
+                    const float delta = r[c] - rbar[c];     // core.hpp:591
+                    const float tq = a.k.inv_h2 * delta;    // kernels.cpp:43
+                    q[c] = tq * delta;
+                }
+                float qs = q[0] + q[2];                     // OpenCV 3.x reduceC_: (q0 + q2) + q1
+                qs = qs + q[1];
+                const float Kw = kernel_weight(qs);         // kernels.cpp:51-53
+#pragma unroll
+                for (int c = 0; c < C; c++) {
+                    const float pr = r[c] * Kw;             // core.cpp:36
+                    A[c] = A[c] + pr;                       // core.hpp:602
+                }
+                B = B + Kw;                                 // core.hpp:603
+                if (BORDER)
+                    ncard += ok ? 1 : 0;
+            }
+#pragma unroll
+            for (int c = 0; c < C; c++) {
+                const float qd = (B != 0.0f) ? (A[c] / B) : 0.0f;   // core.cpp:50, OpenCV 3.x: /0 -> 0
+                rbar[c] = (qd > 0.0f) ? qd : 0.0f;                  // core.hpp:609
+            }
+        }
+        const float cardf = (float)ncard;
+        float sc = (ncard != 0) ? (B / cardf) : 0.0f;   // core.hpp:616-620: the last pass's sum of K
+        sc = (sc > 0.0f) ? sc : 0.0f;                   // core.hpp:622
+        best.offer(sc, d, Dd, rbar);
+    }
+}
+
+// Runs of hypotheses whose sample lines stay inside the row for every lane take the form without the validity test
+// (as scan_stream_rows / scan_reg_rows), in ascending order: first maximum wins (core.hpp:636-645).
+__device__ __forceinline__ void scan_chip_rows(const ScanArgs& a, int v, int u, int d0, int d1, Best<3>& best, float* otab)
+{
+    const float max_ds = (float)max(a.s_hat, a.vol.S - 1 - a.s_hat);
+    const float range = a.dmax - a.dmin, denom = (float)(a.dim_d - 1);
+    const float uf = (float)u, Um1 = (float)(a.vol.U - 1);
+    auto interior = [&](int d) -> bool {
+        const float reach = max_ds * fabsf(hypothesis(a.dmin, range, denom, d)) * fabsf(a.k.slope) + 2.0f;
+        return __all((uf - reach >= 0.0f) && (uf + reach <= Um1));
+    };
+    int d = d0;
+    while (d < d1) {
+        const bool in = interior(d);
+        int e = d + 1;
+        while (e < d1 && interior(e) == in)
+            e++;
+        if (in)
+            scan_chip_body<false>(a, v, u, d, e, best, otab);
+        else
+            scan_chip_body<true>(a, v, u, d, e, best, otab);
+        d = e;
+    }
+}
+
+__global__ __launch_bounds__(64 * kScanWaves) __attribute__((amdgpu_waves_per_eu(1, 1))) void k2_scan_chip(ScanArgs a)
+{
+    constexpr int C = 3;
+    extern __shared__ __attribute__((aligned(16))) float s_chip_lds[];   // [kScanWaves][stream_wave_floats]
+    float* otab = s_chip_lds + (size_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * a.stream_wave_floats;
+    constexpr bool kEpiDyn = true;   // the waves' results for the epilogue go to the head of their own regions
+    float* const epi_lds = otab;
+    const int epi_stride = a.stream_wave_floats;
+    RSLF_SCAN_ROW_TILE((scan_chip_rows(a, v, u, d0, d1, best, otab)))
+}
+
+}  // namespace rslf

@@ -12,10 +12,10 @@
 #pragma once
 
 #include "rslf_device.hpp"
+#include "rslf_plan.hpp"   // kMedianMaxSize
 
 namespace rslf {
 
-constexpr int kMedianMaxSize = 7;   // window side; 49 LDS slots per thread
 
 // The median of one mask pixel (v, u); `cand` is the block's [size*size][256] LDS array.
 template <int C>

@@ -13,7 +13,7 @@
 // Both passes are HBM-bound streaming kernels (a few bytes per (s, v, u)).
 #pragma once
 
-#include "k1_edge.hpp"
+#include "k_compact.hpp"
 #include "k3_median.hpp"
 #include "rslf_device.hpp"
 

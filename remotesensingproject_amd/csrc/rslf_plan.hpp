@@ -1,0 +1,534 @@
+// Host-side planning of the gfx950 EPI depth scan: pure functions, no HIP, no device state.
+//
+// Everything the library decides on the host before it queues work lives here, so that it can be compiled with g++
+// alone and unit-tested under AddressSanitizer / UBSan on a box without a GPU (tests/cpp/test_plan.cpp,
+// tests/test_plan_cpu.py): which scanlines a device and a chunk take and with what halo, in which order a sweep
+// visits the views, how many hypothesis groups and row blocks a scan launch uses and how many records that costs,
+// how the streaming kernel's LDS is shared out, which copies a chunk's upload needs, how the pyramid's levels are
+// sized, and in which order the devices of a sharded sweep wait for one another.  The .hip translation units only
+// turn these plans into launches and copies.
+#pragma once
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+namespace rslf {
+
+// cv::getStructuringElement result as one bit row per kernel row (k <= 31); the device side is k1_morph_pass
+struct MorphElement {
+    int k;
+    unsigned rows[31];
+};
+
+constexpr int kMedianMaxSize = 7;   // selective median: window side; 49 candidate slots per thread (k3_median.hpp)
+
+namespace plan {
+
+// ---- constants of the launch shapes -------------------------------------------------------------------------------
+
+constexpr int kScanWavesPerTile = 4;                               // waves of a scan workgroup = hypothesis chunks per tile
+constexpr size_t kPartialRecordBytes = 32;                         // sizeof(rslf::Partial), checked in k2_scan.hpp
+constexpr size_t kPartialBudget = (size_t)256 << 20;               // bytes of (tile, group, lane) records per grouped scan launch
+constexpr size_t kAutoGroupBudget = (size_t)96 << 20;              // ... of which the AUTOMATIC groups of short register launches may take
+constexpr int kPackedItemTarget = 2048;                            // packed launches: (tile, group) items the device aims for
+constexpr int kSweepGroups = 32;                                   // workgroups sharing a packed tile on a sweep's sparse visits
+constexpr int kStreamGroups = 16;                                  // dense launches of the streaming kernel: workgroups per tile
+constexpr size_t kStreamLdsBytes = (size_t)80 << 10;               // dynamic LDS of one streaming workgroup (two per CU)
+constexpr size_t kStagingBudget = (size_t)256 << 20;               // device staging buffer of the chunked host upload
+constexpr int kMinSpatialDim = 10;                                 // _MIN_SPATIAL_DIM, rslf_fine_to_coarse.hpp:8
+
+// Register-variant slot counts compiled into the library (multiples of 8), per channel count: those that run at two or
+// more waves per SIMD.  Beyond them the streaming / on-chip kernels take over (k2_scan.hpp).
+#ifndef RSLF_SPAD_LIST_1CH
+#define RSLF_SPAD_LIST_1CH(X) X(8) X(16) X(24) X(32) X(40) X(48) X(56) X(64) X(72) X(80) X(88) X(96) X(104) X(112) X(120) X(128) \
+    X(144) X(160) X(176) X(192)
+#endif
+#ifndef RSLF_SPAD_LIST_3CH
+#define RSLF_SPAD_LIST_3CH(X) X(8) X(16) X(24) X(32) X(40) X(48)
+#endif
+
+// Smallest compiled slot count >= S (0 = none: another kernel runs).
+inline int pick_spad(int S, int C)
+{
+    int best = 0;
+#define RSLF_PICK(N) \
+    if (N >= S && best == 0) best = N;
+    if (C == 1) {
+        RSLF_SPAD_LIST_1CH(RSLF_PICK)
+    } else if (C == 3) {
+        RSLF_SPAD_LIST_3CH(RSLF_PICK)
+    }
+#undef RSLF_PICK
+    return best;
+}
+
+// ---- small reference rules ----------------------------------------------------------------------------------------
+
+// dc.hpp:490-494 (pile) / :303-311 (single EPI): an s_hat outside the views means the middle one
+inline int resolve_s_hat(int s_hat, int S)
+{
+    if (s_hat < 0 || s_hat > S - 1)
+        return (int)std::floor((0.0 + S) / 2);
+    return s_hat;
+}
+
+// core.hpp:584: `for (int i = 0; i < par_mean_shift_max_iter; i++)` with a FLOAT bound
+inline int mean_shift_passes(float max_iter)
+{
+    int n = 0;
+    while ((float)n < max_iter && n < (1 << 20))
+        n++;
+    return n;
+}
+
+// core.hpp:981-990: the centre view, then outwards, alternating (an even view count never reaches view 0)
+inline std::vector<int> sweep_order(int S)
+{
+    std::vector<int> order;
+    if (S < 1)
+        return order;
+    const int s_mid = (int)std::floor(S / 2.0);
+    order.push_back(s_mid);
+    for (int off = 1; off < S - s_mid; off++) {
+        order.push_back(s_mid + off);
+        if (s_mid - off > -1)
+            order.push_back(s_mid - off);
+    }
+    return order;
+}
+
+inline int sweep_view_after(int S, int s_hat)
+{
+    const std::vector<int> order = sweep_order(S);
+    for (size_t i = 0; i + 1 < order.size(); i++)
+        if (order[i] == s_hat)
+            return order[i + 1];
+    return -1;
+}
+
+// cv::getStructuringElement(shape, Size(k, k)) with the default anchor, as OpenCV 3.x builds it (imgproc/src/morph.cpp):
+// RECT every column; CROSS the anchor row entirely, elsewhere the anchor column; ELLIPSE the columns
+// [c - dx, c + dx + 1), dx = cvRound(c * sqrt((r*r - dy*dy) / (r*r))), r = c = k/2, dy = i - r.
+inline MorphElement structuring_element(int shape, int k)
+{
+    MorphElement el;
+    el.k = k;
+    const int r = k / 2, c = k / 2;
+    const double inv_r2 = r ? 1.0 / ((double)r * r) : 0.0;
+    for (int i = 0; i < 31; i++)
+        el.rows[i] = 0;
+    for (int i = 0; i < k && i < 31; i++) {
+        int j1 = 0, j2 = 0;
+        if (shape == 0 || (shape == 1 && i == k / 2)) {
+            j2 = k;
+        } else if (shape == 1) {
+            j1 = k / 2;
+            j2 = j1 + 1;
+        } else {
+            const int dy = i - r;
+            if (std::abs(dy) <= r) {
+                const int dx = (int)std::lrint(c * std::sqrt((r * r - dy * dy) * inv_r2));
+                j1 = std::max(c - dx, 0);
+                j2 = std::min(c + dx + 1, k);
+            }
+        }
+        for (int j = j1; j < j2 && j < 31; j++)
+            el.rows[i] |= 1u << j;
+    }
+    return el;
+}
+
+// cvRound(x * 0.5): ties to even (fine_to_coarse_core.cpp:47-48)
+inline void f2c_level_dims(int V, int U, int* V2, int* U2)
+{
+    *V2 = (int)std::lrint(V * 0.5);
+    *U2 = (int)std::lrint(U * 0.5);
+}
+
+struct LevelDims {
+    int V, U;
+};
+
+// The pyramid of FineToCoarse's constructor (rslf_fine_to_coarse.hpp:130-154): levels while both sides exceed
+// _MIN_SPATIAL_DIM and the depth limit allows (max_depth < 1: no limit).
+inline std::vector<LevelDims> f2c_pyramid(int V, int U, int max_depth)
+{
+    std::vector<LevelDims> levels;
+    if (max_depth < 1)
+        max_depth = 1 << 30;
+    int dim_v = V, dim_u = U, counter = 0;
+    while (dim_v > kMinSpatialDim && dim_u > kMinSpatialDim && counter < max_depth) {
+        counter++;
+        levels.push_back(LevelDims{dim_v, dim_u});
+        int v2, u2;
+        f2c_level_dims(dim_v, dim_u, &v2, &u2);
+        if (v2 < 1 || u2 < 1)
+            break;
+        dim_v = v2;
+        dim_u = u2;
+    }
+    return levels;
+}
+
+// ---- scanline partitions ------------------------------------------------------------------------------------------
+
+// rows either side of a block that must be recomputed (pile path) or exchanged (sweep) for the block's own rows to come
+// out exact: the median reads +-(size-1)/2 rows (core.hpp:686), and through the optional opening +-2*(k/2) rows more
+// (core.hpp:759-768)
+inline int median_halo(int median_filter_size) { return (median_filter_size - 1) / 2; }
+inline int halo_rows(int median_filter_size, int opening_size)
+{
+    return median_halo(median_filter_size) + (opening_size > 1 ? 2 * (opening_size / 2) : 0);
+}
+
+struct RowBlock {
+    int a, b;     // owned rows [a, b) of the whole field
+    int lo, hi;   // held / computed rows: owned + halo, clipped to the field
+};
+
+// block i of n over V scanlines: contiguous, sizes differ by at most one, together they cover [0, V) exactly
+inline RowBlock row_block(int V, int i, int n, int halo)
+{
+    RowBlock r;
+    r.a = (int)((long long)V * i / n);
+    r.b = (int)((long long)V * (i + 1) / n);
+    r.lo = std::max(0, r.a - halo);
+    r.hi = std::min(V, r.b + halo);
+    return r;
+}
+
+// A sharded sweep's blocks must be able to fill their neighbours' halo rows from rows they own: fewer devices otherwise.
+inline int sweep_devices_for(int V, int n_devices, int halo)
+{
+    int nd = std::max(1, n_devices);
+    while (nd > 1 && V / nd < std::max(1, halo))
+        nd--;
+    return nd;
+}
+
+// Chunks of one device's rows [r0, r1) on the pipelined host path.  A given size: uniform.  Automatic (chunk_rows <= 0):
+// a short first chunk so that the kernels start early (its upload is the one copy nothing hides), then two large ones
+// (stacked input; scattered input, which is gathered into pinned memory first, takes a middling second chunk and pieces
+// of about rows/3.5) -- a chunk's scan is a grid of its own, and a grid of 5.4 rounds of workgroups pays for 6.
+inline std::vector<RowBlock> chunk_plan(int r0, int r1, int V, int halo, int chunk_rows, bool scattered)
+{
+    std::vector<RowBlock> chunks;
+    const int rows = r1 - r0;
+    if (rows <= 0)
+        return chunks;
+    std::vector<int> sizes;
+    if (chunk_rows > 0) {
+        for (int a = 0; a < rows; a += chunk_rows)
+            sizes.push_back(std::min(chunk_rows, rows - a));
+    } else {
+        int left = rows;
+        const int first = std::min(left, std::max(32, (rows + 15) / 16));
+        sizes.push_back(first);
+        left -= first;
+        if (left > 0 && scattered) {   // gathered through pinned memory first: smaller steps keep the kernels fed
+            const int second = std::min(left, std::max(32, (rows + 7) / 8));
+            sizes.push_back(second);
+            left -= second;
+        }
+        if (left > 0) {
+            // the chunk before has to cover the next one's upload with its scan
+            const int n = scattered ? std::max(1, (int)std::lround(left / (rows / 3.5))) : (left > 2 * first ? 2 : 1);
+            for (int i = 0; i < n; i++) {
+                const int sz = (left + (n - i) - 1) / (n - i);
+                sizes.push_back(sz);
+                left -= sz;
+            }
+        }
+    }
+    int a = r0;
+    for (int sz : sizes) {
+        if (sz <= 0)
+            continue;
+        RowBlock c;
+        c.a = a;
+        c.b = a + sz;
+        c.lo = std::max(0, c.a - halo);
+        c.hi = std::min(V, c.b + halo);
+        chunks.push_back(c);
+        a += sz;
+    }
+    return chunks;
+}
+
+inline int max_held_rows(const std::vector<RowBlock>& chunks)
+{
+    int m = 0;
+    for (const RowBlock& c : chunks)
+        m = std::max(m, c.hi - c.lo);
+    return m;
+}
+
+// worker t of nt over `rows` items: [first, last)
+inline void split_range(int rows, int t, int nt, int* first, int* last)
+{
+    *first = (int)((long long)rows * t / nt);
+    *last = (int)((long long)rows * (t + 1) / nt);
+}
+
+// ---- host copies --------------------------------------------------------------------------------------------------
+
+// Number of maximal runs of EPIs that follow one another in host memory among ptrs[0..rows): each run is one 1-D copy.
+// Rows with a stride (row_stride != row_bytes) are a run each.
+inline int count_runs(const void* const* ptrs, int rows, size_t row_stride_bytes, size_t row_bytes, size_t epi_bytes)
+{
+    if (rows <= 0)
+        return 0;
+    int runs = 1;
+    for (int i = 1; i < rows; i++)
+        if (row_stride_bytes != row_bytes || (const char*)ptrs[i] != (const char*)ptrs[i - 1] + epi_bytes)
+            runs++;
+    return runs;
+}
+
+// Are the EPIs [r0, r1) scattered over the heap (a Vec<Mat>) rather than stacked in one array?
+inline bool epis_scattered(const void* const* ptrs, int r0, int r1, size_t row_stride_bytes, size_t row_bytes, size_t epi_bytes)
+{
+    if (row_stride_bytes != row_bytes)
+        return true;
+    for (int i = r0 + 1; i < r1; i++)
+        if (ptrs[i] && ptrs[i - 1] && (const char*)ptrs[i] != (const char*)ptrs[i - 1] + epi_bytes)
+            return true;
+    return false;
+}
+
+// A chunk goes through the pinned staging buffer when it is broken into more than 8 runs AND the buffer holds it
+// (the buffer is sized from the scattered-ness of the device's own rows; a chunk's halo rows can add breaks of their
+// own, so the capacity is checked per chunk -- ADVICE r2).
+inline bool use_pinned_gather(int runs, int rows, size_t epi_bytes, size_t pin_cap)
+{
+    return runs > 8 && pin_cap > 0 && (size_t)rows * epi_bytes <= pin_cap;
+}
+
+// rows per pass of the chunked host upload through the bounded device staging buffer
+inline int staging_chunk_rows(size_t epi_bytes, int V, size_t budget = kStagingBudget)
+{
+    const size_t c = std::max<size_t>(1, budget / std::max<size_t>(1, epi_bytes));
+    return (int)std::min<size_t>(c, (size_t)std::max(1, V));
+}
+
+// ---- result planes of one chunk, carved from one block ------------------------------------------------------------
+
+struct PlaneLayout {   // byte offsets into the block, for n pixels and C channels
+    size_t Ce, Cd, depth, raw, score, rbar, idx, mask, counts, bytes;
+};
+
+inline PlaneLayout plane_layout(size_t n, int C, int count_rows)
+{
+    PlaneLayout q;
+    q.Ce = 0;
+    q.Cd = q.Ce + n * 4;
+    q.depth = q.Cd + n * 4;
+    q.raw = q.depth + n * 4;
+    q.score = q.raw + n * 4;
+    q.rbar = q.score + n * 4;
+    q.idx = q.rbar + n * 4 * (size_t)C;
+    q.mask = q.idx + n * 4;
+    q.counts = (q.mask + n + 15) & ~(size_t)15;
+    q.bytes = q.counts + (size_t)count_rows * sizeof(int);
+    return q;
+}
+
+// ---- scan launches ------------------------------------------------------------------------------------------------
+
+// largest fraction below 1 that cannot round a position up to the next integer: 1 - ulp(largest position the scan forms)
+inline float stream_frac_max(int U)
+{
+    int e = 0;
+    (void)std::frexp((float)U + 2.0f, &e);   // U + 2 < 2^e
+    return 1.0f - std::ldexp(1.0f, std::max(e - 24, -24));
+}
+
+struct ScanRequest {
+    int V, U, S, C, dim_d;
+    int spad;              // register kernel's slot count, 0 = none
+    bool use_stream;       // streaming kernel
+    int reg_waves;         // waves per SIMD of the register kernel (scan_reg_waves), 0 if unknown
+    int num_cus;           // compute units of the device, 0 if unknown
+    int ctx_groups;        // groups the caller asked for (the sweep's sparse visits), >= 1
+    bool ctx_packed;       // the caller asked for one packed pixel list
+    int precompacted;      // 0: the scan compacts; 1: row lists are in place (K1); 2: the packed list is (sweep)
+    int force_groups;      // debug hooks: 0 / -1 = automatic
+    int force_packed;
+    int stream_groups;     // 0 = kStreamGroups
+    bool stream_share;     // 63-pixel row tiles (shared taps)
+    size_t stream_lds_bytes;
+};
+
+struct ScanPlan {
+    int groups;            // workgroups sharing one tile's hypotheses
+    bool packed;           // one packed list over all scanlines
+    bool packed_adapt;     // the device settles the group count from the list length
+    int tile_w;            // 63 or 64 entries per row tile
+    int tiles_per_row;
+    int rows_per_launch;   // grouped row-tile launches go by blocks of scanlines
+    size_t records;        // 32-byte records the launches need (0 when groups == 1)
+    size_t tickets;        // one int per tile of a launch
+    // streaming kernel
+    int stream_park;       // samples per lane parked in LDS
+    int stream_wave_floats;
+    size_t lds_bytes;
+};
+
+inline int stream_resident_hi(int C, int nres_1ch, int nres_rgb) { return C == 1 ? nres_1ch : nres_rgb; }
+
+// `nres` = the streaming kernel's resident prefix for this volume (stream_resident_for), needed only with use_stream.
+inline ScanPlan plan_scan(const ScanRequest& r, int nres)
+{
+    ScanPlan p;
+    const size_t n = (size_t)r.V * r.U;
+    int groups = std::max(1, r.ctx_groups);
+    bool packed = r.ctx_packed;
+    // the streaming kernel's dense launches share tiles so that what an XCD's workgroups gather from fits its L2
+    if (r.use_stream && groups == 1 && !packed)
+        groups = r.stream_groups > 0 ? r.stream_groups : kStreamGroups;
+    // A dense launch of a register kernel whose grid is only a few rounds of workgroups pays for its last, partly empty
+    // round: sharing each tile's hypotheses among 2-8 workgroups makes the rounds shorter and more numerous -- as long
+    // as a wave keeps at least eight hypotheses and ~256 (hypothesis, view) pairs.
+    if (r.spad && groups == 1 && !packed && r.num_cus > 0 && r.reg_waves > 0) {
+        const long long tiles = (long long)r.V * ((r.U + 63) / 64);
+        const long long resident = (long long)r.num_cus * r.reg_waves;
+        // (and the records stay a modest scratch: the groups are a convenience here, not the kernel's locality)
+        while (groups < 8 && tiles * groups < 40 * resident && r.dim_d >= 8 * kScanWavesPerTile * 2 * groups &&
+               (long long)(r.dim_d / (kScanWavesPerTile * 2 * groups)) * r.S >= 256 &&
+               (size_t)tiles * (size_t)(groups * 2) * 64 * kPartialRecordBytes <= kAutoGroupBudget)
+            groups *= 2;
+    }
+    if (r.force_groups > 0)
+        groups = std::min(64, r.force_groups);
+    if (r.force_packed >= 0)
+        packed = r.force_packed != 0;
+    if (n > (size_t)INT32_MAX || r.precompacted == 1)
+        packed = false;   // entry counts are ints; precompacted: the row lists are what K1 wrote
+    if (r.precompacted == 2)
+        packed = true;    // the previous visit's apply pass left the packed list and its length
+    // enough hypotheses to share out?
+    while (groups > 1 && r.dim_d < 2 * kScanWavesPerTile * groups)
+        groups /= 2;
+
+    p.tile_w = (r.use_stream && !packed && r.stream_share) ? 63 : 64;
+    // 63-entry tiles: a row's last tile takes up to 64 entries (scan_tile)
+    p.tiles_per_row = p.tile_w == 63 ? std::max(1, (r.U + 61) / 63) : (r.U + p.tile_w - 1) / p.tile_w;
+    p.packed_adapt = packed && !r.use_stream;
+    p.rows_per_launch = r.V;
+    if (groups > 1 && !packed) {
+        const size_t per_row = (size_t)p.tiles_per_row * groups * 64 * kPartialRecordBytes;
+        p.rows_per_launch = (int)std::min<size_t>((size_t)r.V, std::max<size_t>(1, kPartialBudget / per_row));
+    }
+    if (packed && r.use_stream)
+        while (groups > 1 && ((n + 63) / 64) * groups * 64 * kPartialRecordBytes > kPartialBudget)
+            groups /= 2;
+    p.groups = groups;
+    p.packed = packed;
+    p.records = 0;
+    p.tickets = 0;
+    if (groups > 1) {
+        const size_t tiles_all = (n + 63) / 64;
+        const size_t tiles_max = !packed ? (size_t)p.rows_per_launch * p.tiles_per_row
+                                         : p.packed_adapt ? std::min<size_t>(tiles_all, kPackedItemTarget / 2) : tiles_all;
+        p.records = (packed && p.packed_adapt) ? std::min<size_t>(tiles_all * groups, kPackedItemTarget) * 64 : tiles_max * groups * 64;
+        p.tickets = tiles_max;
+    }
+    p.stream_park = 0;
+    p.stream_wave_floats = 0;
+    p.lds_bytes = 0;
+    if (r.use_stream) {
+        // LDS per wave: the S view offsets (rounded up to 4) and as many batches of parked samples as the workgroup's
+        // share leaves room for (never past the end of the views)
+        const int batch = r.C == 1 ? 8 : 4;
+        const size_t s4 = ((size_t)r.S + 3) & ~(size_t)3;
+        int park = 0;
+        if (nres > 0) {
+            size_t room = r.stream_lds_bytes / kScanWavesPerTile / sizeof(float);   // floats per wave
+            room -= std::min(room, s4);
+            park = (int)(room / ((size_t)r.C * 64));
+            park = std::min(park, r.S - nres);
+            park = std::max(park, 0);
+            park -= park % batch;
+        }
+        p.stream_park = park;
+        p.stream_wave_floats = (int)(s4 + (size_t)park * r.C * 64);
+        p.stream_wave_floats = std::max(p.stream_wave_floats, 2 * (64 + (3 + r.C) * 32));   // room for the wave's EpilogueBlock
+        p.lds_bytes = (size_t)kScanWavesPerTile * p.stream_wave_floats * sizeof(float);
+    }
+    return p;
+}
+
+// The records a sweep's sparse visits will need, sized before the first visit (no allocation in the middle of the sequence)
+inline void sweep_record_plan(size_t n_pixels, int dim_d, bool stream, size_t* records, size_t* tickets)
+{
+    int g = kSweepGroups;
+    while (g > 1 && dim_d < 2 * kScanWavesPerTile * g)
+        g /= 2;
+    const size_t tiles_all = (n_pixels + 63) / 64;
+    if (stream)
+        while (g > 1 && tiles_all * g * 64 * kPartialRecordBytes > kPartialBudget)
+            g /= 2;
+    *records = 0;
+    *tickets = 0;
+    if (g > 1 && n_pixels <= (size_t)INT32_MAX) {
+        if (stream) {
+            *records = tiles_all * g * 64;
+            *tickets = tiles_all;
+        } else {
+            *records = std::min<size_t>(tiles_all * g, kPackedItemTarget) * 64;
+            *tickets = std::min<size_t>(tiles_all, kPackedItemTarget / 2);
+        }
+    }
+}
+
+// ---- one visit of a sweep sharded over several devices of one process ---------------------------------------------
+//
+// scan on every device; every device fetches its neighbours' boundary rows (needs the neighbour's scan); every device
+// finishes (median + propagation) once BOTH neighbours have fetched its rows, because its apply pass rewrites them
+// (core.hpp:1119-1121).  One host thread queues the ops in this order; `waits` are the cross-device event waits an op's
+// stream makes before it runs (same-device order is the stream's own).
+struct VisitOp {
+    enum Kind { SCAN, FETCH, FINISH } kind;
+    int dev;
+    int neighbour;                    // FETCH: the device whose rows are read, else -1
+    std::vector<int> wait_scan_of;    // devices whose SCAN event this op waits for
+    std::vector<int> wait_fetch_of;   // devices whose (last) FETCH event this op waits for
+};
+
+inline std::vector<VisitOp> sweep_visit_schedule(int nd, int h_med)
+{
+    std::vector<VisitOp> ops;
+    for (int i = 0; i < nd; i++)
+        ops.push_back(VisitOp{VisitOp::SCAN, i, -1, {}, {}});
+    for (int i = 0; i < nd; i++)
+        for (int side = 0; side < 2 && h_med > 0; side++) {
+            const int k = side == 0 ? i - 1 : i + 1;
+            if (k < 0 || k >= nd)
+                continue;
+            ops.push_back(VisitOp{VisitOp::FETCH, i, k, {k}, {}});
+        }
+    for (int i = 0; i < nd; i++) {
+        VisitOp f{VisitOp::FINISH, i, -1, {}, {}};
+        if (i > 0)
+            f.wait_fetch_of.push_back(i - 1);
+        if (i + 1 < nd)
+            f.wait_fetch_of.push_back(i + 1);
+        ops.push_back(f);
+    }
+    return ops;
+}
+
+// Local row numbers of a boundary-row fetch: device `d` (block bd) reads h rows owned by its neighbour (block bo).
+// side 0: the h rows above d's block = the last h own rows of the block before; side 1: the first h own rows of the next.
+inline void fetch_rows(const RowBlock& bd, const RowBlock& bo, int side, int h, int* dst_row, int* src_row)
+{
+    *dst_row = side == 0 ? (bd.a - bd.lo) - h : (bd.b - bd.lo);
+    *src_row = side == 0 ? (bo.b - bo.lo) - h : (bo.a - bo.lo);
+}
+
+}  // namespace plan
+}  // namespace rslf

@@ -414,6 +414,12 @@ class MultiDevice:
     def set_chunk_rows(self, rows: int) -> None:
         check(_lib.lib().rslf_multi_set_chunk_rows(self._h, int(rows)), "rslf_multi_set_chunk_rows")
 
+    def peer_access(self) -> list:
+        """n x n matrix: [i][k] = 1 if worker i reaches worker k's memory directly (same GPU, or peer access enabled over
+        xGMI), 0 if copies between them stage through the host (rslf_multi_peer_access)."""
+        n = self.device_count()
+        return [[int(_lib.lib().rslf_multi_peer_access(self._h, i, k)) for k in range(n)] for i in range(n)]
+
     def depth1d_pile(self, epis: Sequence[np.ndarray], dmin: float, dmax: float, dim_d: int, s_hat: int = -1,
                      epi_scale_factor: float = -1.0, parameters: Depth1DParameters | None = None) -> dict:
         """epis: the reference's Vec<Mat> -- V arrays [S,U] or [S,U,3], all uint8 or all float32."""
