@@ -113,6 +113,8 @@ typedef struct rslf_stats {
 #define RSLF_SCAN_GENERIC   0  /* any S, C in {1,3}, any sign: re-gathers every mean-shift pass */
 #define RSLF_SCAN_STREAM    2  /* volume >= 0, any S: a resident prefix of the samples (registers + LDS), the rest re-gathered every pass */
 #define RSLF_SCAN_REG       1  /* volume >= 0 and C=1, S<=192 or C=3, S<=48: every sample held in registers */
+#define RSLF_SCAN_CHIP      3  /* volume >= 0, C=3, S>=196, dense launch with one hypothesis grid: one wave per SIMD, every sample
+                                  of a unit on chip (VGPRs + AGPRs + LDS), packed-fp32 passes */
 
 int         rslf_abi_version(void);
 const char* rslf_status_string(int status);
@@ -127,7 +129,7 @@ int rslf_ctx_destroy(rslf_ctx* ctx);
 int rslf_ctx_set_stream(rslf_ctx* ctx, void* hip_stream);   /* NULL = default stream */
 int rslf_ctx_synchronize(rslf_ctx* ctx);
 /* Test and tuning hooks of ONE context (nothing process-global, no environment variable is read):
- *   "force_scan"     0 automatic | 1 generic scan kernel | 2 streaming scan kernel
+ *   "force_scan"     0 automatic | 1 generic scan kernel | 2 streaming scan kernel (never the on-chip one)
  *   "force_groups"   0 automatic | 1..64 hypothesis groups per tile
  *   "force_packed"   -1 automatic | 0 row tiles | 1 one packed pixel list
  *   "stream_share"   1 (default) 63-pixel tiles sharing taps between lanes in the streaming kernel | 0 off

@@ -48,6 +48,23 @@ __host__ __device__ constexpr bool chip_takes(int S, int C)
     return C == 3 && S >= kChipOnChip && (size_t)chip_wave_floats(S) * 4 * kScanWaves <= kChipLdsBytes;
 }
 
+// f(integral_constant<int, G>) for G = 0 .. N-1, in order: a loop unrolled by the type system -- `#pragma unroll` leaves the
+// 49-batch gather rolled, and a rolled loop cannot index registers
+template <int G, int N>
+struct ChipUnroll {
+    template <class F>
+    static __device__ __forceinline__ void run(F& f)
+    {
+        f(std::integral_constant<int, G>{});
+        ChipUnroll<G + 1, N>::run(f);
+    }
+};
+template <int N>
+struct ChipUnroll<N, N> {
+    template <class F>
+    static __device__ __forceinline__ void run(F&) {}
+};
+
 __device__ __forceinline__ float agpr_put(float v)
 {
     float a;
@@ -62,41 +79,123 @@ __device__ __forceinline__ float agpr_get(float a)
 }
 
 // One pair of samples (s, s+1) of one RGB pass in packed fp32: per channel delta = R - rbar, t = kq * delta,
-// q = t * delta; qs = (q0 + q2) + q1 (OpenCV 3.x reduceC_); K = clamp(1 - qs); P_c = R_c * K.  rbar arrives as two
-// register pairs {rbar0, rbar1}, {rbar2, -} and is broadcast to both halves by op_sel; 15 packed instructions.
-__device__ __forceinline__ void chip_pair(f2 r0, f2 r1, f2 r2, f2 m01, f2 m2x, f2 kq, f2& P0, f2& P1, f2& P2, f2& K)
+// q = t * delta; qs = (q0 + q2) + q1 (OpenCV 3.x reduceC_); K = clamp(1 - qs); P_c = R_c * K -- 15 packed instructions;
+// rbar arrives as two register pairs {rbar0, rbar1}, {rbar2, -} and is broadcast to both halves by op_sel.
+// A wave alone on its SIMD issues in order, one instruction per ~5 clocks, and an instruction that reads its
+// predecessor's result waits longer: so the block is SKEWED -- it also makes the eight sequential adds of the PREVIOUS
+// pair's P and K (core.hpp:602-603: sample s, then s + 1, one IEEE add each), placed where the packed chain would stall.
+// `prev` = the previous pair's results (zeros before the first pair of a pass: +0 added to a sum changes nothing).
+struct ChipPK {
+    f2 P0, P1, P2, K;
+};
+
+// between the three subtractions and the three products R * K: the same text in every form of the block
+#define RSLF_CHIP_PAIR_MID \
+    "v_pk_mul_f32 %[t0], %[kq], %[d0] op_sel_hi:[0,1]\n\t" \
+    "v_pk_mul_f32 %[t1], %[kq], %[d1] op_sel_hi:[0,1]\n\t" \
+    "v_pk_mul_f32 %[t2], %[kq], %[d2] op_sel_hi:[0,1]\n\t" \
+    "v_pk_mul_f32 %[d0], %[d0], %[t0]\n\t" \
+    "v_pk_mul_f32 %[d2], %[d2], %[t2]\n\t" \
+    "v_pk_mul_f32 %[d1], %[d1], %[t1]\n\t" \
+    "v_add_f32 %[A0], %[A0], %[p0x]\n\t" \
+    "v_add_f32 %[A1], %[A1], %[p1x]\n\t" \
+    "v_pk_add_f32 %[d0], %[d0], %[d2]\n\t" \
+    "v_add_f32 %[A2], %[A2], %[p2x]\n\t" \
+    "v_add_f32 %[B], %[B], %[kx]\n\t" \
+    "v_add_f32 %[A0], %[A0], %[p0y]\n\t" \
+    "v_pk_add_f32 %[d0], %[d0], %[d1]\n\t" \
+    "v_add_f32 %[A1], %[A1], %[p1y]\n\t" \
+    "v_add_f32 %[A2], %[A2], %[p2y]\n\t" \
+    "v_add_f32 %[B], %[B], %[ky]\n\t" \
+    "v_pk_add_f32 %[k], 1.0, %[d0] op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1] clamp\n\t"
+
+#define RSLF_CHIP_PAIR_OUTS(n)                                                                                        \
+    [d0] "=&v"(d0), [d1] "=&v"(d1), [d2] "=&v"(d2), [t0] "=&v"(n.P0), [t1] "=&v"(n.P1), [t2] "=&v"(n.P2), [k] "=&v"(n.K), \
+        [A0] "+v"(A[0]), [A1] "+v"(A[1]), [A2] "+v"(A[2]), [B] "+v"(B)
+#define RSLF_CHIP_PAIR_PREV(p)                                                                                        \
+    [p0x] "v"(p.P0.x), [p0y] "v"(p.P0.y), [p1x] "v"(p.P1.x), [p1y] "v"(p.P1.y), [p2x] "v"(p.P2.x), [p2y] "v"(p.P2.y),    \
+        [kx] "v"(p.K.x), [ky] "v"(p.K.y)
+
+// samples in VGPR pairs (the VGPR tier, and the LDS tier once its ds_read_b64 have landed)
+__device__ __forceinline__ ChipPK chip_pair(f2 r0, f2 r1, f2 r2, f2 m01, f2 m2x, f2 kq, const ChipPK& prev, float (&A)[3], float& B)
 {
+    ChipPK n;
     f2 d0, d1, d2;
     asm("v_pk_add_f32 %[d0], %[r0], %[m01] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
         "v_pk_add_f32 %[d1], %[r1], %[m01] op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
         "v_pk_add_f32 %[d2], %[r2], %[m2x] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
-        "v_pk_mul_f32 %[t0], %[kq], %[d0] op_sel_hi:[0,1]\n\t"
-        "v_pk_mul_f32 %[t1], %[kq], %[d1] op_sel_hi:[0,1]\n\t"
-        "v_pk_mul_f32 %[t2], %[kq], %[d2] op_sel_hi:[0,1]\n\t"
-        "v_pk_mul_f32 %[d0], %[d0], %[t0]\n\t"
-        "v_pk_mul_f32 %[d2], %[d2], %[t2]\n\t"
-        "v_pk_mul_f32 %[d1], %[d1], %[t1]\n\t"
-        "v_pk_add_f32 %[d0], %[d0], %[d2]\n\t"
-        "v_pk_add_f32 %[d0], %[d0], %[d1]\n\t"
-        "v_pk_add_f32 %[k], 1.0, %[d0] op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1] clamp\n\t"
+        RSLF_CHIP_PAIR_MID
         "v_pk_mul_f32 %[t0], %[r0], %[k]\n\t"
         "v_pk_mul_f32 %[t1], %[r1], %[k]\n\t"
         "v_pk_mul_f32 %[t2], %[r2], %[k]"
-        : [d0] "=&v"(d0), [d1] "=&v"(d1), [d2] "=&v"(d2), [t0] "=&v"(P0), [t1] "=&v"(P1), [t2] "=&v"(P2), [k] "=&v"(K)
-        : [r0] "v"(r0), [r1] "v"(r1), [r2] "v"(r2), [m01] "v"(m01), [m2x] "v"(m2x), [kq] "v"(kq));
+        : RSLF_CHIP_PAIR_OUTS(n)
+        : [r0] "v"(r0), [r1] "v"(r1), [r2] "v"(r2), [m01] "v"(m01), [m2x] "v"(m2x), [kq] "v"(kq), RSLF_CHIP_PAIR_PREV(prev));
+    return n;
 }
 
-// the sums take sample s, then sample s + 1 (core.hpp:602-603), one IEEE add each
-__device__ __forceinline__ void chip_accumulate(const f2& P0, const f2& P1, const f2& P2, const f2& K, float (&A)[3], float& B)
+// samples in AGPRs: the six reads open the block (VALU operands cannot name an AGPR); they land in a fixed register
+// window, v[250:255], whose halves the asm can name -- an operand the compiler allocates is a whole pair to the asm.
+__device__ __forceinline__ ChipPK chip_pair_agpr(float a0x, float a0y, float a1x, float a1y, float a2x, float a2y, f2 m01, f2 m2x, f2 kq,
+                                                 const ChipPK& prev, float (&A)[3], float& B)
 {
-    A[0] = A[0] + P0.x;
-    A[1] = A[1] + P1.x;
-    A[2] = A[2] + P2.x;
-    B = B + K.x;
-    A[0] = A[0] + P0.y;
-    A[1] = A[1] + P1.y;
-    A[2] = A[2] + P2.y;
-    B = B + K.y;
+    ChipPK n;
+    f2 d0, d1, d2;
+    asm("v_accvgpr_read_b32 v250, %[a0x]\n\t"
+        "v_accvgpr_read_b32 v251, %[a0y]\n\t"
+        "v_accvgpr_read_b32 v252, %[a1x]\n\t"
+        "v_accvgpr_read_b32 v253, %[a1y]\n\t"
+        "v_accvgpr_read_b32 v254, %[a2x]\n\t"
+        "v_accvgpr_read_b32 v255, %[a2y]\n\t"
+        "v_pk_add_f32 %[d0], v[250:251], %[m01] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 %[d1], v[252:253], %[m01] op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 %[d2], v[254:255], %[m2x] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        RSLF_CHIP_PAIR_MID
+        "v_pk_mul_f32 %[t0], v[250:251], %[k]\n\t"
+        "v_pk_mul_f32 %[t1], v[252:253], %[k]\n\t"
+        "v_pk_mul_f32 %[t2], v[254:255], %[k]"
+        : RSLF_CHIP_PAIR_OUTS(n)
+        : [a0x] "a"(a0x), [a0y] "a"(a0y), [a1x] "a"(a1x), [a1y] "a"(a1y), [a2x] "a"(a2x), [a2y] "a"(a2y), [m01] "v"(m01), [m2x] "v"(m2x),
+          [kq] "v"(kq), RSLF_CHIP_PAIR_PREV(prev)
+        : "v250", "v251", "v252", "v253", "v254", "v255");
+    return n;
+}
+
+// one sample in AGPRs and a sentinel (1e30) for its partner
+__device__ __forceinline__ ChipPK chip_pair_agpr_single(float a0x, float a1x, float a2x, f2 m01, f2 m2x, f2 kq, const ChipPK& prev,
+                                                        float (&A)[3], float& B)
+{
+    ChipPK n;
+    f2 d0, d1, d2;
+    asm("v_accvgpr_read_b32 v250, %[a0x]\n\t"
+        "v_mov_b32 v251, 0x7149f2ca\n\t"
+        "v_accvgpr_read_b32 v252, %[a1x]\n\t"
+        "v_mov_b32 v253, 0x7149f2ca\n\t"
+        "v_accvgpr_read_b32 v254, %[a2x]\n\t"
+        "v_mov_b32 v255, 0x7149f2ca\n\t"
+        "v_pk_add_f32 %[d0], v[250:251], %[m01] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 %[d1], v[252:253], %[m01] op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 %[d2], v[254:255], %[m2x] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        RSLF_CHIP_PAIR_MID
+        "v_pk_mul_f32 %[t0], v[250:251], %[k]\n\t"
+        "v_pk_mul_f32 %[t1], v[252:253], %[k]\n\t"
+        "v_pk_mul_f32 %[t2], v[254:255], %[k]"
+        : RSLF_CHIP_PAIR_OUTS(n)
+        : [a0x] "a"(a0x), [a1x] "a"(a1x), [a2x] "a"(a2x), [m01] "v"(m01), [m2x] "v"(m2x), [kq] "v"(kq), RSLF_CHIP_PAIR_PREV(prev)
+        : "v250", "v251", "v252", "v253", "v254", "v255");
+    return n;
+}
+
+// the last pair's P and K, once no pair follows
+__device__ __forceinline__ void chip_flush(const ChipPK& p, float (&A)[3], float& B)
+{
+    A[0] = A[0] + p.P0.x;
+    A[1] = A[1] + p.P1.x;
+    A[2] = A[2] + p.P2.x;
+    B = B + p.K.x;
+    A[0] = A[0] + p.P0.y;
+    A[1] = A[1] + p.P1.y;
+    A[2] = A[2] + p.P2.y;
+    B = B + p.K.y;
 }
 
 // BORDER: some sample line of this wave may leave [0, U-1] for some hypothesis of the run: test validity per sample.
@@ -120,9 +219,9 @@ __device__ __forceinline__ void scan_chip_body(const ScanArgs& a, int v, int u, 
     f2* park = reinterpret_cast<f2*>(otab + ((S + 3) & ~3)) + lane;
 
     // one sample's two taps and its blend (interp.hpp:179-190); `rowb` = byte offset of view s's row in the EPI
-    auto taps = [&](int s, unsigned rowb, float (&e0)[C], float (&e1)[C], float& tt, bool& ok) {
-        float x = otab[s];                       // fl(fl(float(s_hat - s) * D[d]) * slope), one broadcast read for the wave
-        x = x + uf;                              // core.hpp:552
+    // `xoff` = fl(fl(float(s_hat - s) * D[d]) * slope), from the wave's offset table (one broadcast read serves four samples)
+    auto taps = [&](float xoff, unsigned rowb, float (&e0)[C], float (&e1)[C], float& tt, bool& ok) {
+        float x = xoff + uf;                     // core.hpp:552
         tt = lerp_weight(x);                     // interp.hpp:181
         int i0 = floor_to_int(x);                // interp.hpp:179
         ok = true;
@@ -161,23 +260,45 @@ __device__ __forceinline__ void scan_chip_body(const ScanArgs& a, int v, int u, 
 
         f2 Rv[C][NV / 2];
         float Ra[C][NA];
+        float Rx[C];   // the sample behind the tiers (s = NV + NA + NL; c5's 201st), in the three AGPRs the AGPR tier leaves over
         unsigned rowb = 0;
         asm volatile("" : "+s"(rowb));
-        // ---- gather, once per hypothesis: batches of four samples, all eight loads in flight before the first blend
+        // ---- gather, once per hypothesis: batches of four samples, software-pipelined -- the eight loads of batch g + 1
+        // are issued before batch g is blended, because a wave alone on its SIMD has nobody to hide an L2 round trip
+        // behind (PMC on the first version: a quarter of the wave's cycles spent in s_waitcnt).  Fully unrolled: the
+        // two buffers alternate by the parity of a compile-time index, so nothing is copied.
+        constexpr int NB = (NV + NA + NL) / GB, NO = NV + NA + NL;
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        float e0[2][GB][C], e1[2][GB][C], tt[2][GB];
+        bool ok[2][GB];
+        f4v xo[2];   // the offsets of a batch, read a batch before its loads are issued (the table is padded to a multiple of 4)
+        xo[0] = *(const f4v*)otab;
+        xo[1] = *(const f4v*)(otab + GB);
 #pragma unroll
-        for (int g = 0; g < (NV + NA) / GB; g++) {
-            float e0[GB][C], e1[GB][C], tt[GB], r[GB][C];
-            bool ok[GB];
+        for (int j = 0; j < GB; j++) {
+            taps(xo[0][j], rowb, e0[0][j], e1[0][j], tt[0][j], ok[0][j]);
+            rowb += stride_b;
+        }
+        auto batch = [&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            constexpr int cur = g & 1, nxt = cur ^ 1;
+            if (g + 1 < NB) {
 #pragma unroll
-            for (int j = 0; j < GB; j++) {
-                taps(g * GB + j, rowb, e0[j], e1[j], tt[j], ok[j]);
-                rowb += stride_b;
+                for (int j = 0; j < GB; j++) {
+                    taps(xo[nxt][j], rowb, e0[nxt][j], e1[nxt][j], tt[nxt][j], ok[nxt][j]);
+                    rowb += stride_b;
+                }
+                xo[cur] = *(const f4v*)(otab + (g + 2) * GB);   // batch g + 2's (or, at the end, the sample's behind the tiers)
+            } else {
+                // the sample behind the tiers rides in the last batch's shadow (S == NO: its slot holds the sentinel)
+                taps(S > NO ? xo[nxt][0] : 0.0f, S > NO ? rowb : 0u, e0[nxt][0], e1[nxt][0], tt[nxt][0], ok[nxt][0]);
             }
+            float r[GB][C];
 #pragma unroll
             for (int j = 0; j < GB; j++) {
-                blend(e0[j], e1[j], tt[j], ok[j], r[j]);
+                blend(e0[cur][j], e1[cur][j], tt[cur][j], ok[cur][j], r[j]);
                 if (BORDER)
-                    card += ok[j] ? 1 : 0;
+                    card += ok[cur][j] ? 1 : 0;
             }
 #pragma unroll
             for (int j = 0; j < GB; j++) {
@@ -189,42 +310,32 @@ __device__ __forceinline__ void scan_chip_body(const ScanArgs& a, int v, int u, 
                             Rv[c][s >> 1].y = r[j][c];
                         else
                             Rv[c][s >> 1].x = r[j][c];
-                    } else {
+                    } else if (s < NV + NA) {
                         Ra[c][s - NV] = agpr_put(r[j][c]);
+                    } else if ((j & 1) == 0) {
+                        park[(((s - NV - NA) >> 1) * C + c) * 64] = f2{r[j][c], r[j + 1][c]};   // pairs go out as 8-byte stores
                     }
                 }
             }
-            // pin the batch: its values exist here, and the next batch's address state is opaque -- else hipcc turns the
-            // unrolled gather into "all loads, then all blends" and parks the texels in scratch (k2_reg.hpp)
+            // pin the batch: its values exist here, and the address state of the batches to come is opaque -- else hipcc
+            // turns the unrolled gather into "all loads, then all blends" and parks the texels in scratch (k2_reg.hpp)
             if (g * GB < NV) {
 #pragma unroll
                 for (int c = 0; c < C; c++)
                     asm volatile("" : "+v"(Rv[c][g * GB / 2]), "+v"(Rv[c][g * GB / 2 + 1]));
             }
             asm volatile("" : "+s"(rowb), "+v"(card));
-        }
-        // the LDS tier, a rolled loop: pairs go out as 8-byte stores
-#pragma unroll 1
-        for (int s0 = NV + NA; s0 < NV + NA + NL; s0 += GB) {
-            float e0[GB][C], e1[GB][C], tt[GB], r[GB][C];
-            bool ok[GB];
+        };
+        ChipUnroll<0, NB>::run(batch);
+        {
+            float r[C];
+            blend(e0[NB & 1][0], e1[NB & 1][0], tt[NB & 1][0], ok[NB & 1][0], r);
+            const bool have = S > NO;   // wave-uniform
+            if (BORDER)
+                card += (have && ok[NB & 1][0]) ? 1 : 0;
 #pragma unroll
-            for (int j = 0; j < GB; j++) {
-                taps(s0 + j, rowb, e0[j], e1[j], tt[j], ok[j]);
-                rowb += stride_b;
-            }
-#pragma unroll
-            for (int j = 0; j < GB; j++) {
-                blend(e0[j], e1[j], tt[j], ok[j], r[j]);
-                if (BORDER)
-                    card += ok[j] ? 1 : 0;
-            }
-            const int p0 = (s0 - NV - NA) >> 1;
-#pragma unroll
-            for (int j = 0; j < GB; j += 2)
-#pragma unroll
-                for (int c = 0; c < C; c++)
-                    park[((p0 + (j >> 1)) * C + c) * 64] = f2{r[j][c], r[j + 1][c]};
+            for (int c = 0; c < C; c++)
+                Rx[c] = agpr_put(have ? r[c] : kSentinel);
         }
 
         float rbar[C];
@@ -238,36 +349,46 @@ __device__ __forceinline__ void scan_chip_body(const ScanArgs& a, int v, int u, 
             float A[C] = {0.0f, 0.0f, 0.0f};
             B = 0.0f;
             const f2 m01 = {rbar[0], rbar[1]}, m2x = {rbar[2], rbar[2]};
-            f2 P0, P1, P2, K;
+            ChipPK pk;
+            pk.P0 = pk.P1 = pk.P2 = pk.K = f2{0.0f, 0.0f};
             // VGPR tier
 #pragma unroll
-            for (int p = 0; p < NV / 2; p++) {
-                chip_pair(Rv[0][p], Rv[1][p], Rv[2][p], m01, m2x, kq2, P0, P1, P2, K);
-                chip_accumulate(P0, P1, P2, K, A, B);
-            }
+            for (int p = 0; p < NV / 2; p++)
+                pk = chip_pair(Rv[0][p], Rv[1][p], Rv[2][p], m01, m2x, kq2, pk, A, B);
             // AGPR tier
 #pragma unroll
-            for (int p = 0; p < NA / 2; p++) {
-                const f2 r0 = {agpr_get(Ra[0][2 * p]), agpr_get(Ra[0][2 * p + 1])};
-                const f2 r1 = {agpr_get(Ra[1][2 * p]), agpr_get(Ra[1][2 * p + 1])};
-                const f2 r2 = {agpr_get(Ra[2][2 * p]), agpr_get(Ra[2][2 * p + 1])};
-                chip_pair(r0, r1, r2, m01, m2x, kq2, P0, P1, P2, K);
-                chip_accumulate(P0, P1, P2, K, A, B);
-            }
-            // LDS tier
-#pragma unroll 2
+            for (int p = 0; p < NA / 2; p++)
+                pk = chip_pair_agpr(Ra[0][2 * p], Ra[0][2 * p + 1], Ra[1][2 * p], Ra[1][2 * p + 1], Ra[2][2 * p], Ra[2][2 * p + 1], m01, m2x,
+                                    kq2, pk, A, B);
+            // LDS tier, fully unrolled (immediate offsets): the three ds_read_b64 of pair p + 1 are issued before pair p's
+            // block, which then covers their latency
+            f2 q[2][C];
+#pragma unroll
+            for (int c = 0; c < C; c++)
+                q[0][c] = park[c * 64];
+#pragma unroll
             for (int p = 0; p < NL / 2; p++) {
-                const f2 r0 = park[(p * C + 0) * 64], r1 = park[(p * C + 1) * 64], r2 = park[(p * C + 2) * 64];
-                chip_pair(r0, r1, r2, m01, m2x, kq2, P0, P1, P2, K);
-                chip_accumulate(P0, P1, P2, K, A, B);
+                const int cur = p & 1, nxt = cur ^ 1;
+                if (p + 1 < NL / 2) {
+#pragma unroll
+                    for (int c = 0; c < C; c++)
+                        q[nxt][c] = park[((p + 1) * C + c) * 64];
+                }
+                // (left to itself hipcc sinks the reads to just before their use and waits for them there)
+                __builtin_amdgcn_sched_barrier(0);
+                pk = chip_pair(q[cur][0], q[cur][1], q[cur][2], m01, m2x, kq2, pk, A, B);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            // what no tier holds: re-gathered on every pass, one sample at a time (1 of 201 at c5)
+            // the sample behind the tiers, paired with a sentinel (K = 0, P = 0 exactly)
+            pk = chip_pair_agpr_single(Rx[0], Rx[1], Rx[2], m01, m2x, kq2, pk, A, B);
+            chip_flush(pk, A, B);
+            // what nothing holds: re-gathered on every pass, one sample at a time (none at c5)
             ncard = card;
 #pragma unroll 1
-            for (int s = NV + NA + NL; s < S; s++) {
+            for (int s = NO + 1; s < S; s++) {
                 float e0[C], e1[C], tt, r[C], q[C];
                 bool ok;
-                taps(s, (unsigned)s * stride_b, e0, e1, tt, ok);
+                taps(otab[s], (unsigned)s * stride_b, e0, e1, tt, ok);
                 blend(e0, e1, tt, ok, r);
 #pragma unroll
                 for (int c = 0; c < C; c++) {

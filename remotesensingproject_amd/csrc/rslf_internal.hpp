@@ -185,6 +185,7 @@ struct rslf_ctx {
     bool stream_share = true;  // streaming kernel: 63-pixel row tiles whose tail shares taps between neighbouring lanes
     size_t stream_lds_bytes = rslf::plan::kStreamLdsBytes;   // dynamic LDS of one streaming workgroup
     bool stream_attr_set = false;
+    bool chip_attr_set = false;
     int bitmask_mode = -1;     // 2-D sweep: bit-packed shadow of the running masks for the claims (-1 automatic by volume size)
     rslf::Partial* scan_partial = nullptr;   // [tile][group][64] records of grouped scan launches
     size_t partial_rec_cap = 0;

@@ -9,6 +9,7 @@
 #include "k2_scan.hpp"
 #include "k2_reg.hpp"
 #include "k2_stream.hpp"
+#include "k2_chip.hpp"
 #include "k3_median.hpp"
 
 using namespace rslf;
@@ -167,9 +168,11 @@ struct ScanChoice {
     int spad;          // register kernel's slot count, 0 = not the register kernel
     bool stream_ok;    // an LDS kernel could take this volume
     bool use_stream;
+    bool use_chip;     // the on-chip kernel (k2_chip.hpp) -- only ever set by choose_scan's caller-visible conditions
 };
 
-static ScanChoice choose_scan(const rslf_ctx* ctx, int S, int C, bool in_range, int interpolation)
+// `dense_uniform`: a row-tile launch with one hypothesis grid for all pixels (what the on-chip kernel is written for)
+static ScanChoice choose_scan(const rslf_ctx* ctx, int S, int C, bool in_range, int interpolation, bool dense_uniform = false)
 {
     ScanChoice c;
     c.spad = in_range ? plan::pick_spad(S, C) : 0;
@@ -184,6 +187,10 @@ static ScanChoice choose_scan(const rslf_ctx* ctx, int S, int C, bool in_range, 
         c.spad = 0;
     }
     c.use_stream = !c.spad && c.stream_ok;
+    // more views than two waves per SIMD hold on chip (RGB, 196 views and up): one wave per SIMD with every sample at hand
+    c.use_chip = c.use_stream && dense_uniform && chip_takes(S, C) && ctx->force_scan != 2;
+    if (c.use_chip)
+        c.use_stream = false;
     return c;
 }
 
@@ -193,6 +200,8 @@ static plan::ScanRequest scan_request(const rslf_ctx* ctx, int V, int U, int S, 
     rq.V = V, rq.U = U, rq.S = S, rq.C = C, rq.dim_d = dim_d;
     rq.spad = ch.spad;
     rq.use_stream = ch.use_stream;
+    rq.use_chip = ch.use_chip;
+    rq.chip_wave_floats = ch.use_chip ? chip_wave_floats(S) : 0;
     rq.reg_waves = ch.spad ? scan_reg_waves(ch.spad, C) : 0;
     rq.num_cus = ctx->num_cus;
     rq.ctx_groups = ctx->scan_groups;
@@ -211,7 +220,8 @@ static plan::ScanRequest scan_request(const rslf_ctx* ctx, int V, int U, int S, 
 // launches take no records.
 int rslf::scan_presize(rslf_ctx* ctx, int S, int U, int C, int dim_d, const rslf_params* p, const int* rows, int n_rows)
 {
-    const ScanChoice ch = choose_scan(ctx, S, C, true, p ? p->interpolation : RSLF_INTERP_LINEAR);
+    const ScanChoice ch = choose_scan(ctx, S, C, true, p ? p->interpolation : RSLF_INTERP_LINEAR,
+                                      !ctx->scan_packed && ctx->force_packed != 1);
     const bool fused = p && p->edge_confidence_opening_size <= 1 && ctx->force_packed != 1 && !ctx->scan_packed;
     int max_rows = 0;
     size_t recs = 0, tickets = 0;
@@ -277,9 +287,11 @@ extern "C" int rslf_depth_epi_scan(rslf_ctx* ctx, const rslf_volume* vol, const 
     if (!ctx->keep_total && !precompacted)
         HIP_TRY(hipMemsetAsync(ctx->total, 0, sizeof(unsigned long long), st));
 
-    const ScanChoice ch = choose_scan(ctx, vol->S, vol->C, vol->min_value >= 0.0f && vol->max_value <= 1.0e6f, p->interpolation);
+    const bool dense_uniform = !d_dmin_vu && !ctx->scan_packed && ctx->force_packed != 1 && precompacted != 2;
+    const ScanChoice ch = choose_scan(ctx, vol->S, vol->C, vol->min_value >= 0.0f && vol->max_value <= 1.0e6f, p->interpolation,
+                                      dense_uniform);
     const int spad = ch.spad;
-    const bool stream_ok = ch.stream_ok, use_stream = ch.use_stream;
+    const bool stream_ok = ch.stream_ok, use_stream = ch.use_stream, use_chip = ch.use_chip;
     // Launch shape (rslf_plan.hpp, plan_scan): hypothesis groups per tile, packed or row tiles, 63- or 64-entry tiles, row
     // blocks and records of grouped launches, the streaming kernel's LDS split -- pure host logic, unit-tested on the CPU.
     const plan::ScanRequest rq = scan_request(ctx, vol->V, vol->U, vol->S, vol->C, dim_d, ch, precompacted);
@@ -341,6 +353,11 @@ extern "C" int rslf_depth_epi_scan(rslf_ctx* ctx, const rslf_volume* vol, const 
         a.ticket = ctx->scan_ticket;
     }
     const size_t lds = sp.lds_bytes;
+    if (use_chip && !ctx->chip_attr_set) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k2_scan_chip), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)kChipLdsBytes));
+        ctx->chip_attr_set = true;
+    }
     if (use_stream && !ctx->stream_attr_set) {   // more than the 64 KiB a kernel gets without asking
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k2_scan_stream<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)ctx->stream_lds_bytes));
@@ -351,7 +368,7 @@ extern "C" int rslf_depth_epi_scan(rslf_ctx* ctx, const rslf_volume* vol, const 
 
     HIP_TRY(hipGetLastError());   // anything an earlier enqueue left behind is not this launch's fault
     ctx->last_spad = spad;
-    ctx->last_kernel = spad ? RSLF_SCAN_REG : (stream_ok ? RSLF_SCAN_STREAM : RSLF_SCAN_GENERIC);
+    ctx->last_kernel = spad ? RSLF_SCAN_REG : use_chip ? RSLF_SCAN_CHIP : (stream_ok ? RSLF_SCAN_STREAM : RSLF_SCAN_GENERIC);
     // The events that time K2 are marker packets of their own: ~5.6 us each before the next kernel starts (measured,
     // tools/probe_gaps.py) -- nothing beside a 66 ms scan, a tenth of a sweep's sparse visit.  A sweep times its first
     // (dense) visit only.
@@ -373,6 +390,8 @@ extern "C" int rslf_depth_epi_scan(rslf_ctx* ctx, const rslf_volume* vol, const 
             rc = launch_scan_reg(spad, vol->C, a, grid, st);
             if (rc)
                 return rc;
+        } else if (use_chip) {
+            hipLaunchKernelGGL(k2_scan_chip, grid, dim3(64 * kScanWaves), lds, st, a);
         } else if (use_stream) {
             if (vol->C == 1)
                 hipLaunchKernelGGL(k2_scan_stream<1>, grid, dim3(64 * kScanWaves), lds, st, a);

@@ -351,6 +351,8 @@ struct ScanRequest {
     int V, U, S, C, dim_d;
     int spad;              // register kernel's slot count, 0 = none
     bool use_stream;       // streaming kernel
+    bool use_chip;         // on-chip kernel (k2_chip.hpp): one workgroup per CU, 64-entry row tiles, never packed
+    int chip_wave_floats;  // its dynamic LDS per wave, in floats
     int reg_waves;         // waves per SIMD of the register kernel (scan_reg_waves), 0 if unknown
     int num_cus;           // compute units of the device, 0 if unknown
     int ctx_groups;        // groups the caller asked for (the sweep's sparse visits), >= 1
@@ -388,7 +390,7 @@ inline ScanPlan plan_scan(const ScanRequest& r, int nres)
     int groups = std::max(1, r.ctx_groups);
     bool packed = r.ctx_packed;
     // the streaming kernel's dense launches share tiles so that what an XCD's workgroups gather from fits its L2
-    if (r.use_stream && groups == 1 && !packed)
+    if ((r.use_stream || r.use_chip) && groups == 1 && !packed)
         groups = r.stream_groups > 0 ? r.stream_groups : kStreamGroups;
     // A dense launch of a register kernel whose grid is only a few rounds of workgroups pays for its last, partly empty
     // round: sharing each tile's hypotheses among 2-8 workgroups makes the rounds shorter and more numerous -- as long
@@ -417,13 +419,13 @@ inline ScanPlan plan_scan(const ScanRequest& r, int nres)
     p.tile_w = (r.use_stream && !packed && r.stream_share) ? 63 : 64;
     // 63-entry tiles: a row's last tile takes up to 64 entries (scan_tile)
     p.tiles_per_row = p.tile_w == 63 ? std::max(1, (r.U + 61) / 63) : (r.U + p.tile_w - 1) / p.tile_w;
-    p.packed_adapt = packed && !r.use_stream;
+    p.packed_adapt = packed && !r.use_stream && !r.use_chip;
     p.rows_per_launch = r.V;
     if (groups > 1 && !packed) {
         const size_t per_row = (size_t)p.tiles_per_row * groups * 64 * kPartialRecordBytes;
         p.rows_per_launch = (int)std::min<size_t>((size_t)r.V, std::max<size_t>(1, kPartialBudget / per_row));
     }
-    if (packed && r.use_stream)
+    if (packed && (r.use_stream || r.use_chip))
         while (groups > 1 && ((n + 63) / 64) * groups * 64 * kPartialRecordBytes > kPartialBudget)
             groups /= 2;
     p.groups = groups;
@@ -458,6 +460,10 @@ inline ScanPlan plan_scan(const ScanRequest& r, int nres)
         p.stream_wave_floats = (int)(s4 + (size_t)park * r.C * 64);
         p.stream_wave_floats = std::max(p.stream_wave_floats, 2 * (64 + (3 + r.C) * 32));   // room for the wave's EpilogueBlock
         p.lds_bytes = (size_t)kScanWavesPerTile * p.stream_wave_floats * sizeof(float);
+    }
+    if (r.use_chip) {
+        p.stream_wave_floats = r.chip_wave_floats;
+        p.lds_bytes = (size_t)kScanWavesPerTile * r.chip_wave_floats * sizeof(float);
     }
     return p;
 }

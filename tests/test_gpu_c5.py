@@ -18,7 +18,7 @@ def test_c5_shape_known_answer_and_oracle(oracle_mod):
     comp = rs.Depth1DComputer_pile(vol, c["dmin"], c["dmax"], c["D"], epi_scale_factor=1.0)
     comp.run()
     a = comp.results()
-    assert comp.stats.scan_kernel == 2, "201-view RGB is beyond the register file: streaming variant expected"
+    assert comp.stats.scan_kernel == 3, "201-view RGB, dense launch: the on-chip variant expected"
     c6 = dict(c, V=V)
     _check_known_answer(a, delta, c6)
     assert comp.stats.units == int((a["edge_mask"] > 0).sum()) * c["D"]
@@ -74,7 +74,7 @@ def test_c5_full_size_known_answer_and_8_way_shards(oracle_mod):
     assert vol.V == V and vol.S == S and vol.U == U and vol.C == C
     comp = rs.Depth1DComputer_pile(vol, c["dmin"], c["dmax"], D)
     comp.run()
-    assert comp.stats.scan_kernel == 2
+    assert comp.stats.scan_kernel == 3
     a = comp.results()
     m = _check_known_answer(a, delta, c)
     assert m.sum() >= 0.9999 * m.size

@@ -1,0 +1,86 @@
+"""The on-chip scan kernel (k2_scan_chip, remotesensingproject_amd/csrc/k2_chip.hpp): RGB light fields of 196 views and
+up -- BASELINE.json configs[4]'s 201 -- with every sample of a unit held in VGPRs + AGPRs + LDS at one wave per SIMD and
+the mean-shift passes in packed fp32.  Bit-exact against the CPU oracle (core.hpp:480-661 restated) on small fields with
+border and interior hypotheses, ragged rows, hypothesis groups and views beyond the tiers; bit-exact against the
+streaming kernel at c5's real row length and hypothesis count."""
+import numpy as np
+import pytest
+
+from tests.util import assert_pile_parity
+
+pytestmark = pytest.mark.gpu
+
+PLANES = ("edge_mask", "depth_idx", "edge_confidence", "score", "rbar", "depth_raw", "depth", "disp_confidence")
+
+
+@pytest.fixture(scope="module")
+def rs():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from remotesensingproject_amd import depth
+    return depth
+
+
+def _run(rs, vol, dmin, dmax, D, **debug):
+    ctx = rs.default_context(0)
+    ctx.set_debug(force_scan=0, force_groups=0, force_packed=-1)
+    if debug:
+        ctx.set_debug(**debug)
+    try:
+        comp = rs.Depth1DComputer_pile(vol, dmin, dmax, D, epi_scale_factor=1.0)
+        comp.run()
+        return comp.results(), comp.stats
+    finally:
+        ctx.set_debug(force_scan=0, force_groups=0, force_packed=-1)
+
+
+@pytest.mark.parametrize("U,V,S,D,dmin,dmax,groups", [
+    (200, 3, 201, 12, -0.3, 0.3, 0),     # tile 0 and the last tile are border, the middle one interior for every hypothesis
+    (70, 2, 196, 9, -1.0, 1.0, 0),       # exactly the on-chip capacity, no re-gathered sample; all border
+    (131, 3, 230, 16, -0.25, 0.5, 0),    # 30 views beyond the tiers (re-gathered per pass), a ragged last tile
+    (260, 2, 201, 24, -0.2, 0.2, 4),     # hypothesis groups: four workgroups share a tile, the last one merges
+    (65, 1, 203, 8, 0.0, 0.0, 0),        # dmin == dmax
+])
+def test_chip_kernel_against_the_oracle(rs, oracle_mod, U, V, S, D, dmin, dmax, groups):
+    rng = np.random.default_rng(1000 + U + S)
+    vol = rng.uniform(0.0, 1.0, size=(V, S, U, 3)).astype(np.float32)
+    vol[:, :, U // 3: U // 3 + 5] *= np.float32(0.05)          # a dark band: the shadow cut leaves gaps in the pixel lists
+    got, st = _run(rs, vol, dmin, dmax, D, **({"force_groups": groups} if groups else {}))
+    assert st.scan_kernel == 3, "the on-chip kernel did not run (kernel %d)" % st.scan_kernel
+    ref = oracle_mod.depth1d_pile_run(vol, dmin, dmax, D)
+    assert_pile_parity(got, ref, label="chip %dx%dx%d" % (U, V, S))
+    # ... and the streaming kernel, which the same shapes took until round 3, agrees with both
+    other, st2 = _run(rs, vol, dmin, dmax, D, force_scan=2)
+    assert st2.scan_kernel == 2
+    for k in PLANES:
+        assert np.array_equal(got[k], other[k]), k
+
+
+def test_chip_kernel_on_the_synthetic_scene_matches_the_streaming_kernel(rs):
+    """BASELINE.json configs[4]'s row length, view count and hypothesis grid on four scanlines: the known answer, and every
+    plane bit-identical to the streaming kernel's (the oracle needs ~10 s per scanline at 512 hypotheses)."""
+    from remotesensingproject_amd.synth import CONFIGS, make_lightfield
+    from tests.test_gpu_fullsize import _check_known_answer
+    c = dict(CONFIGS["c5"])
+    V = 4
+    vol, delta = make_lightfield(c["U"], V, c["S"], c["C"], seed=c["seed"], dmin=c["dmin"], dmax=c["dmax"], band=2)
+    got, st = _run(rs, vol, c["dmin"], c["dmax"], c["D"])
+    assert st.scan_kernel == 3
+    _check_known_answer(got, delta, dict(c, V=V))
+    other, st2 = _run(rs, vol, c["dmin"], c["dmax"], c["D"], force_scan=2)
+    assert st2.scan_kernel == 2 and st2.units == st.units
+    for k in PLANES:
+        assert np.array_equal(got[k], other[k]), k
+
+
+def test_chip_kernel_leaves_other_launch_shapes_to_the_streaming_kernel(rs):
+    """Per-pixel hypothesis ranges and packed pixel lists are not what the on-chip kernel is written for."""
+    import torch
+    rng = np.random.default_rng(4)
+    U, V, S, D = 80, 2, 201, 8
+    vol = rng.uniform(0.0, 1.0, size=(V, S, U, 3)).astype(np.float32)
+    _, st = _run(rs, vol, -0.3, 0.3, D, force_packed=1)
+    assert st.scan_kernel == 2
+    _, st = _run(rs, vol[:, :190], -0.3, 0.3, D)          # fewer views than the tiers hold: the streaming kernel
+    assert st.scan_kernel == 2
