@@ -198,11 +198,18 @@ __device__ __forceinline__ void chip_flush(const ChipPK& p, float (&A)[3], float
     B = B + p.K.y;
 }
 
-// BORDER: some sample line of this wave may leave [0, U-1] for some hypothesis of the run: test validity per sample.
-template <bool BORDER>
+// SHARED = false: the general form -- every lane loads both taps of a sample (16 + 8 bytes) and tests the sample's validity
+// (interp.hpp:182).  SHARED = true: lanes 0..62 hold 63 consecutive pixels, lane 63 stands on the pixel after them, every
+// sample line of every lane stays inside the row and all lanes floor alike (scan_chip_rows): a lane's right tap is its
+// neighbour's left tap, so a sample costs ONE 12-byte load, the right tap comes from lane + 1 (v_mul_f32_dpp wave_shl:1),
+// and with 4 registers per sample in flight instead of 7 the gather runs TWO batches ahead of its blends -- a wave alone on
+// its SIMD has nobody to hide an L2 round trip behind (the general form, one batch ahead, waits a third of its gather).
+template <bool SHARED>
 __device__ __forceinline__ void scan_chip_body(const ScanArgs& a, int v, int u, int d0, int d1, Best<3>& best, float* __restrict__ otab)
 {
     constexpr int C = 3, NV = kChipNV, NA = kChipNA, NL = kChipNL, GB = 4;
+    constexpr bool BORDER = !SHARED;
+    constexpr int PD = SHARED ? 3 : 2;   // batches of loads in flight + 1
     const VolView& vol = a.vol;
     const float* epi = vol.row(v, 0);
     const float uf = (float)u;
@@ -230,10 +237,16 @@ __device__ __forceinline__ void scan_chip_body(const ScanArgs& a, int v, int u, 
             i0 = ok ? i0 : 0;
         }
         const float* p = (const float*)((const char*)epi + (__umul24((unsigned)i0, 4u * C) + rowb));
+        if constexpr (SHARED) {
+            typedef float f3u __attribute__((ext_vector_type(3), aligned(4)));
+            const f3u t3 = *(const f3u*)p;
+            e0[0] = t3.x, e0[1] = t3.y, e0[2] = t3.z;
+        } else {
 #pragma unroll
-        for (int c = 0; c < C; c++) {
-            e0[c] = p[c];
-            e1[c] = p[C + c];
+            for (int c = 0; c < C; c++) {
+                e0[c] = p[c];
+                e1[c] = p[C + c];
+            }
         }
     };
     auto blend = [&](const float (&e0)[C], const float (&e1)[C], float tt, bool ok, float (&r)[C]) {
@@ -241,7 +254,9 @@ __device__ __forceinline__ void scan_chip_body(const ScanArgs& a, int v, int u, 
 #pragma unroll
         for (int c = 0; c < C; c++) {
             const float m0 = omt * e0[c];        // interp.hpp:184
-            const float m1 = tt * e1[c];
+            // 0x130 = wave_shl:1: lane i reads lane i + 1, the owner of this lane's right tap
+            const float right = SHARED ? __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(e0[c]), 0x130, 0xf, 0xf, false)) : e1[c];
+            const float m1 = tt * right;
             const float rr = m0 + m1;
             r[c] = (BORDER && !ok) ? kSentinel : rr;   // interp.hpp:189 stand-in: K = 0 and r * K = 0 exactly
         }
@@ -269,30 +284,34 @@ __device__ __forceinline__ void scan_chip_body(const ScanArgs& a, int v, int u, 
         // two buffers alternate by the parity of a compile-time index, so nothing is copied.
         constexpr int NB = (NV + NA + NL) / GB, NO = NV + NA + NL;
         typedef float f4v __attribute__((ext_vector_type(4)));
-        float e0[2][GB][C], e1[2][GB][C], tt[2][GB];
-        bool ok[2][GB];
-        f4v xo[2];   // the offsets of a batch, read a batch before its loads are issued (the table is padded to a multiple of 4)
-        xo[0] = *(const f4v*)otab;
-        xo[1] = *(const f4v*)(otab + GB);
+        float e0[PD][GB][C], e1[PD][GB][C], tt[PD][GB];
+        bool ok[PD][GB];
+        f4v xo[PD];   // the offsets of a batch, read a batch before its loads are issued (the table is padded to a multiple of 4)
 #pragma unroll
-        for (int j = 0; j < GB; j++) {
-            taps(xo[0][j], rowb, e0[0][j], e1[0][j], tt[0][j], ok[0][j]);
-            rowb += stride_b;
-        }
+        for (int b = 0; b < PD; b++)
+            xo[b] = *(const f4v*)(otab + b * GB);
+#pragma unroll
+        for (int b = 0; b < PD - 1; b++)
+#pragma unroll
+            for (int j = 0; j < GB; j++) {
+                taps(xo[b][j], rowb, e0[b][j], e1[b][j], tt[b][j], ok[b][j]);
+                rowb += stride_b;
+            }
         auto batch = [&](auto gc) {
             constexpr int g = decltype(gc)::value;
-            constexpr int cur = g & 1, nxt = cur ^ 1;
-            if (g + 1 < NB) {
+            constexpr int cur = g % PD, nxt = (g + PD - 1) % PD;   // batch g is blended; batch g + PD - 1's loads are issued
+            if (g + PD - 1 < NB) {
 #pragma unroll
                 for (int j = 0; j < GB; j++) {
                     taps(xo[nxt][j], rowb, e0[nxt][j], e1[nxt][j], tt[nxt][j], ok[nxt][j]);
                     rowb += stride_b;
                 }
-                xo[cur] = *(const f4v*)(otab + (g + 2) * GB);   // batch g + 2's (or, at the end, the sample's behind the tiers)
-            } else {
-                // the sample behind the tiers rides in the last batch's shadow (S == NO: its slot holds the sentinel)
+            } else if (g + PD - 1 == NB) {
+                // the sample behind the tiers rides in the last batches' shadow (S == NO: its slot will hold the sentinel)
                 taps(S > NO ? xo[nxt][0] : 0.0f, S > NO ? rowb : 0u, e0[nxt][0], e1[nxt][0], tt[nxt][0], ok[nxt][0]);
             }
+            if (g + PD <= NB)
+                xo[cur] = *(const f4v*)(otab + (g + PD) * GB);     // batch g + PD's offsets take the place of batch g's
             float r[GB][C];
 #pragma unroll
             for (int j = 0; j < GB; j++) {
@@ -329,10 +348,10 @@ __device__ __forceinline__ void scan_chip_body(const ScanArgs& a, int v, int u, 
         ChipUnroll<0, NB>::run(batch);
         {
             float r[C];
-            blend(e0[NB & 1][0], e1[NB & 1][0], tt[NB & 1][0], ok[NB & 1][0], r);
+            blend(e0[NB % PD][0], e1[NB % PD][0], tt[NB % PD][0], ok[NB % PD][0], r);
             const bool have = S > NO;   // wave-uniform
             if (BORDER)
-                card += (have && ok[NB & 1][0]) ? 1 : 0;
+                card += (have && ok[NB % PD][0]) ? 1 : 0;
 #pragma unroll
             for (int c = 0; c < C; c++)
                 Rx[c] = agpr_put(have ? r[c] : kSentinel);
@@ -421,27 +440,50 @@ __device__ __forceinline__ void scan_chip_body(const ScanArgs& a, int v, int u, 
     }
 }
 
-// Runs of hypotheses whose sample lines stay inside the row for every lane take the form without the validity test
-// (as scan_stream_rows / scan_reg_rows), in ascending order: first maximum wins (core.hpp:636-645).
-__device__ __forceinline__ void scan_chip_rows(const ScanArgs& a, int v, int u, int d0, int d1, Best<3>& best, float* otab)
+// Which form a hypothesis takes is decided per HYPOTHESIS (as scan_stream_rows does): the shared-tap form needs a dense
+// tile -- 63 consecutive pixels in lanes 0..62, lane 63 free to stand on the pixel after them -- sample lines that stay
+// inside the row for every lane (two pixels of margin, which covers lane 63's extra pixel), and view offsets none of whose
+// fractions is within an ulp of 1 (positions are offset + integer u: the lanes then all floor alike).  Runs of
+// hypotheses of one kind go to one body call, in ascending order: first maximum wins (core.hpp:636-645).
+__device__ __forceinline__ void scan_chip_rows(const ScanArgs& a, int v, int u, bool active, int d0, int d1, Best<3>& best, float* otab)
 {
-    const float max_ds = (float)max(a.s_hat, a.vol.S - 1 - a.s_hat);
+    const int S = a.vol.S;
+    const int ln = threadIdx.x & 63;
+    const int u0 = __builtin_amdgcn_readfirstlane(u), u62 = __builtin_amdgcn_readlane(u, 62);
+    // (every lane is compared, not just the ends: a short or gappy list can span 62 pixels too -- idle lanes shadow the last entry)
+    const bool consecutive = __all(ln > 62 || u == u0 + ln);
+    // (a row's last tile may hold a 64th entry, scan_tile: lane 63 is then a pixel of its own and cannot lend itself out)
+    const bool lane63_free = !__any(ln == 63 && active);
+    const bool dense = a.tile_w == 63 && consecutive && lane63_free;
+    const int ud = (ln == 63) ? u62 + 1 : u;
+    const float max_ds = (float)max(a.s_hat, S - 1 - a.s_hat);
     const float range = a.dmax - a.dmin, denom = (float)(a.dim_d - 1);
     const float uf = (float)u, Um1 = (float)(a.vol.U - 1);
-    auto interior = [&](int d) -> bool {
-        const float reach = max_ds * fabsf(hypothesis(a.dmin, range, denom, d)) * fabsf(a.k.slope) + 2.0f;
-        return __all((uf - reach >= 0.0f) && (uf + reach <= Um1));
+    auto shared_form = [&](int d) -> bool {
+        if (!dense)
+            return false;
+        const float Dd = hypothesis(a.dmin, range, denom, d);
+        const float reach = max_ds * fabsf(Dd) * fabsf(a.k.slope) + 2.0f;
+        if (!__all((uf - reach >= 0.0f) && (uf + reach <= Um1)))
+            return false;
+        bool odd = false;
+        for (int s = ln; s < S; s += 64) {
+            float off = (float)(a.s_hat - s) * Dd;   // core.hpp:542,550 -- the very operations the body's table holds
+            off = off * a.k.slope;                   // core.hpp:551
+            odd |= __builtin_amdgcn_fractf(off) > a.stream_frac_max;
+        }
+        return !__any(odd);
     };
     int d = d0;
     while (d < d1) {
-        const bool in = interior(d);
+        const bool sh = shared_form(d);
         int e = d + 1;
-        while (e < d1 && interior(e) == in)
+        while (e < d1 && shared_form(e) == sh)
             e++;
-        if (in)
-            scan_chip_body<false>(a, v, u, d, e, best, otab);
+        if (sh)
+            scan_chip_body<true>(a, v, ud, d, e, best, otab);
         else
-            scan_chip_body<true>(a, v, u, d, e, best, otab);
+            scan_chip_body<false>(a, v, u, d, e, best, otab);
         d = e;
     }
 }
@@ -454,7 +496,7 @@ __global__ __launch_bounds__(64 * kScanWaves) __attribute__((amdgpu_waves_per_eu
     constexpr bool kEpiDyn = true;   // the waves' results for the epilogue go to the head of their own regions
     float* const epi_lds = otab;
     const int epi_stride = a.stream_wave_floats;
-    RSLF_SCAN_ROW_TILE((scan_chip_rows(a, v, u, d0, d1, best, otab)))
+    RSLF_SCAN_ROW_TILE((scan_chip_rows(a, v, u, active, d0, d1, best, otab)))
 }
 
 }  // namespace rslf

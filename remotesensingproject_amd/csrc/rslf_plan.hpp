@@ -351,7 +351,7 @@ struct ScanRequest {
     int V, U, S, C, dim_d;
     int spad;              // register kernel's slot count, 0 = none
     bool use_stream;       // streaming kernel
-    bool use_chip;         // on-chip kernel (k2_chip.hpp): one workgroup per CU, 64-entry row tiles, never packed
+    bool use_chip;         // on-chip kernel (k2_chip.hpp): one workgroup per CU, row tiles as the streaming kernel's, never packed
     int chip_wave_floats;  // its dynamic LDS per wave, in floats
     int reg_waves;         // waves per SIMD of the register kernel (scan_reg_waves), 0 if unknown
     int num_cus;           // compute units of the device, 0 if unknown
@@ -416,7 +416,7 @@ inline ScanPlan plan_scan(const ScanRequest& r, int nres)
     while (groups > 1 && r.dim_d < 2 * kScanWavesPerTile * groups)
         groups /= 2;
 
-    p.tile_w = (r.use_stream && !packed && r.stream_share) ? 63 : 64;
+    p.tile_w = ((r.use_stream || r.use_chip) && !packed && r.stream_share) ? 63 : 64;
     // 63-entry tiles: a row's last tile takes up to 64 entries (scan_tile)
     p.tiles_per_row = p.tile_w == 63 ? std::max(1, (r.U + 61) / 63) : (r.U + p.tile_w - 1) / p.tile_w;
     p.packed_adapt = packed && !r.use_stream && !r.use_chip;

@@ -11,7 +11,12 @@ dmin = float(sys.argv[6]) if len(sys.argv) > 6 else -2.0
 dmax = float(sys.argv[7]) if len(sys.argv) > 7 else 5.96875
 vol, _ = make_lightfield(U, V, S, C, seed=1, dmin=dmin, dmax=dmax)
 v = rs.Volume.from_dense(torch.from_numpy(vol).cuda())
-comp = rs.Depth1DComputer_pile(v, dmin, dmax, D)
+params = rs.Depth1DParameters()
+if os.environ.get("ITER"):      # passes of the mean shift: splits a kernel's time into its gather and its passes
+    params.par_mean_shift_max_iter = float(os.environ["ITER"])
+if os.environ.get("FORCE_SCAN"):
+    v.ctx.set_debug(force_scan=int(os.environ["FORCE_SCAN"]))
+comp = rs.Depth1DComputer_pile(v, dmin, dmax, D, parameters=params)
 comp.run(want_stats=True)
 torch.cuda.synchronize()
 units = comp.stats.units; st = comp.stats
