@@ -39,6 +39,28 @@ def algorithmic_bytes_per_pixel(S: int, C: int) -> int:
     return 4 * S * C + 8 + 13 + 4 * C
 
 
+def measured_traffic(key):
+    """roofline.traffic = HBM bytes per launch from the PMC counters of THIS code (profiles/k2_traffic.json, written by
+    tools/summarize_profiles.py from a rocprofv3 --pmc run of this very command).  Every entry carries the hash of the
+    sources it was measured on; an entry measured on other code is not quoted (traffic: null, and the source says why)."""
+    tpath = os.path.join(ROOT, "profiles", "k2_traffic.json")
+    if key is None:
+        return None, "none: a developer run with --rows has no committed counter run"
+    try:
+        from remotesensingproject_amd import build as hb
+        have = hb.source_hash()
+        e = json.load(open(tpath)).get(key)
+    except Exception as ex:  # noqa: BLE001
+        return None, "none: %s" % ex
+    if not e:
+        return None, "none: profiles/k2_traffic.json has no entry %s" % key
+    if e.get("source_hash") != have:
+        return None, "stale: profiles/k2_traffic.json[%s] was measured on sources %s, this tree is %s (%.4g bytes then)" % (
+            key, e.get("source_hash"), have, e.get("hbm_bytes_per_launch", float("nan")))
+    return e["hbm_bytes_per_launch"], "profiles/k2_traffic.json[%s]: rocprofv3 --pmc FETCH_SIZE (calibrated on k0_pack) + WRITE_SIZE, %s, sources %s" % (
+        key, e.get("collected", "undated"), have)
+
+
 def cpu_baseline(cfg: dict, budget_s: float = 12.0) -> dict:
     """The CPU oracle (a port of the reference's arithmetic, OpenMP over scanlines like
     core.hpp:799) timed on this host on a bounded sample: whole scanlines of the same workload."""
@@ -82,17 +104,25 @@ def end_to_end(rs, host: np.ndarray, cfg: dict, units: int, device: int) -> dict
     epis = list(host[..., 0]) if cfg["C"] == 1 else list(host)
     m = rs.MultiDevice([device])
     ts = []
-    for _ in range(5):     # the first call sizes the device buffers
+    calls = 5 if host.nbytes <= (4 << 30) else 3     # the first call sizes the device buffers; c5 (21 GB in) takes seconds per call
+    for _ in range(calls):
         t0 = time.perf_counter()
         m.depth1d_pile(epis, cfg["dmin"], cfg["dmax"], cfg["D"], epi_scale_factor=1.0)
         ts.append(time.perf_counter() - t0)
     m.close()
     print("e2e calls (ms): " + " ".join("%.1f" % (x * 1e3) for x in ts), file=sys.stderr)
-    t = sorted(ts)[2]
+    t = sorted(ts[1:])[(calls - 1) // 2]              # median of the calls after the first
+    # the upload alone (Depth1DComputer_pile's constructor on the same host EPIs: copy + normalise + pack, dc.hpp:425-477):
+    # what the PCIe link delivers from pageable memory, for the reader who wants e2e minus kernels explained
+    t0 = time.perf_counter()
+    v = rs.Volume.from_epis(epis, 1.0, rs.default_context(device))
+    up = time.perf_counter() - t0
+    v.close()
     return {"ms": t * 1e3, "value": units / t / 1e6, "unit": "Mpixel*hyp/s",
             "what": "host EPIs (Vec<Mat>-style, pageable) in -> host planes out, one call; upload, kernels and download "
-                    "overlap in scanline chunks with a recomputed halo (rslf_multi_depth1d_pile_f32); median of 5",
-            "input_gb": host.nbytes / 1e9}
+                    "overlap in scanline chunks with a recomputed halo (rslf_multi_depth1d_pile_f32); median of the %d calls "
+                    "after the first" % (calls - 1),
+            "input_gb": host.nbytes / 1e9, "upload_alone_ms": up * 1e3, "upload_alone_gbs": host.nbytes / 1e9 / up}
 
 
 def pick_config(args, default_for_c3: str | None = None) -> tuple[dict, str]:
@@ -271,7 +301,7 @@ def main() -> None:
         names = {"share": "stream_share", "groups": "stream_groups", "lds": "stream_lds_kib"}
         ctx.set_debug(**{names.get(k, k): int(v) for k, v in (kv.split("=") for kv in os.environ["RSLF_BENCH_HOOKS"].split(",")) if not k.startswith("_")})
     vol = rs.Volume.from_dense(torch.from_numpy(host).to(dev), 1.0, ctx)
-    want_e2e = world == 1 and not args.no_e2e and host.nbytes <= (4 << 30)
+    want_e2e = world == 1 and not args.no_e2e
     if not want_e2e:
         del host
     comp = rs.Depth1DComputer_pile(vol, cfg["dmin"], cfg["dmax"], D, parameters=params)
@@ -281,14 +311,22 @@ def main() -> None:
                     depth=comp.m_best_depth_v_u, depth_raw=comp.m_depth_raw_v_u, score=comp.m_score_v_u,
                     depth_idx=comp.m_depth_idx_v_u, rbar=comp.m_rbar_v_u, edge_mask=comp.m_edge_confidence_mask_v_u)
 
-    k2_ms = []
+    k2_ms, gather_ms = [], []
     gatherer = sharding.PlaneGatherer(shard, U, C, dev)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)] if world > 1 else None
 
     def step(record: bool):
         comp.run(want_stats=False)
+        if ev:
+            ev[0].record()
         out = gatherer(planes())   # N > 1: RCCL gather of the owned rows onto rank 0
+        if ev:
+            ev[1].record()
         if record:
             k2_ms.append(ctx.last_scan_kernel_ms())   # HIP events on the launching stream
+            if ev:
+                ev[1].synchronize()
+                gather_ms.append(ev[0].elapsed_time(ev[1]))   # enqueue-to-done of the gather on this rank
         return out
 
     def fence():
@@ -320,6 +358,15 @@ def main() -> None:
     if world > 1:
         dist.all_reduce(n)
     pixels = int(n.item())
+    # per-rank figures for the N > 1 line: a slow gather and a short grid look the same in ms_per_step alone
+    per_rank = None
+    if world > 1:
+        mine = torch.tensor([float(np.mean(k2_ms)), float(np.mean(gather_ms)) if gather_ms else 0.0, float(shard.hi - shard.lo),
+                             float(shard.v1 - shard.v0)],
+                            dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [[float(x) for x in t.tolist()] for t in allr]
     units_per_step = pixels * D
     ms_per_step = elapsed / args.steps * 1e3
     value = units_per_step / (elapsed / args.steps) / 1e6
@@ -329,16 +376,7 @@ def main() -> None:
         units_launch = int(comp.stats.units)          # what rank 0's K2 launch processed (incl. halo rows)
         flops = algorithmic_flops_per_unit(S, C)
         achieved_tflops = units_launch * flops / (k2_avg_ms * 1e-3) / 1e12
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "k2_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                key = "%s_n%d" % (args.config, world)
-                if key in tj and not args.rows:
-                    traffic = tj[key]["hbm_bytes_per_launch"]
-            except Exception:  # noqa: BLE001
-                traffic = None
+        traffic, traffic_source = measured_traffic("%s_n%d" % (args.config, world) if not args.rows else None)
         px_launch = units_launch // D
         hbm_bytes = px_launch * algorithmic_bytes_per_pixel(S, C)
         line = {
@@ -373,6 +411,7 @@ def main() -> None:
                 "unit": "TFLOP/s",
                 "frac": achieved_tflops / PEAK_FP32_VECTOR_TFLOPS,
                 "traffic": traffic,
+                "traffic_source": traffic_source,
                 "flops_per_unit": flops,
                 "units_per_launch": units_launch,
                 "kernel_ms": k2_avg_ms,
@@ -389,6 +428,10 @@ def main() -> None:
                 "note": "compulsory-byte model; this path is VALU-bound, not HBM-bound (SURVEY 8d)",
             },
         }
+        if per_rank:
+            line["per_rank"] = {"k2_ms": [r[0] for r in per_rank], "gather_ms": [r[1] for r in per_rank],
+                                "rows_held": [int(r[2]) for r in per_rank], "rows_owned": [int(r[3]) for r in per_rank],
+                                "note": "K2 HIP-event time and enqueue-to-done time of the plane gather on every rank, means over the steps"}
         if want_e2e:
             line["e2e"] = end_to_end(rs, host, cfg, units_per_step, local_rank)
         if world == 1 and not args.no_cpu_baseline:

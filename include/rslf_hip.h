@@ -132,6 +132,7 @@ int rslf_ctx_synchronize(rslf_ctx* ctx);
  *   "force_scan"     0 automatic | 1 generic scan kernel | 2 streaming scan kernel (never the on-chip one)
  *   "force_groups"   0 automatic | 1..64 hypothesis groups per tile
  *   "force_packed"   -1 automatic | 0 row tiles | 1 one packed pixel list
+ *   "claim_skip"     1 (default) the 2-D sweep's claims skip views with nothing left to paint within reach | 0 off
  *   "stream_share"   1 (default) 63-pixel tiles sharing taps between lanes in the streaming kernel | 0 off
  *   "stream_groups"  0 automatic | hypothesis groups per tile of the streaming kernel's dense launches
  *   "stream_lds_kib" dynamic LDS of one streaming workgroup, KiB (default 72)

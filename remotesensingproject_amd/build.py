@@ -84,6 +84,25 @@ def source_hash() -> str:
     return h.hexdigest()[:16]
 
 
+def build_variant(name: str, defines: list[str]) -> str:
+    """A/B builds (developer tool): the library with extra -D flags, as ab/librslf_<name>.so (git-ignored; it travels to
+    the GPU box).  Only the scan unit takes the defines; the other objects are the in-tree ones."""
+    build()
+    out_dir = os.path.join(os.path.dirname(HERE), "ab")
+    os.makedirs(out_dir, exist_ok=True)
+    obj = os.path.join(OBJ, "rslf_pile_%s.o" % name)
+    r = subprocess.run([_hipcc()] + HIPCC_FLAGS + ["-D" + d for d in defines] + ["-I", INCLUDE, "-c", "rslf_pile.hip", "-o", obj],
+                       cwd=CSRC, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + r.stderr[-4000:])
+    so = os.path.join(out_dir, "librslf_%s.so" % name)
+    objs = [obj if u == "rslf_pile.hip" else _obj(u) for u in SOURCES]
+    r = subprocess.run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so] + objs, cwd=CSRC, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("link failed:\n" + r.stderr[-4000:])
+    return so
+
+
 def build(force: bool = False, report: bool = False) -> str:
     """Build the shared library in-tree (one object per translation unit, compiled in parallel); returns its path."""
     if not force and not report and not needs_build():
@@ -138,5 +157,9 @@ def resource_table(stderr: str) -> str:
 
 
 if __name__ == "__main__":
+    if "--variant" in sys.argv:   # python -m remotesensingproject_amd.build --variant NAME -DFOO=1 ...
+        i = sys.argv.index("--variant")
+        print(build_variant(sys.argv[i + 1], [a[2:] for a in sys.argv[i + 2:] if a.startswith("-D")]))
+        sys.exit(0)
     p = build(force="--force" in sys.argv, report="--report" in sys.argv)
     print(p)

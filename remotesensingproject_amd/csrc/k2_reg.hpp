@@ -38,8 +38,8 @@ constexpr int kPadSlack = 16;     // compiled slot counts step by at most this: 
 // GB:        samples whose loads are in flight together, 0 = the default (gather_batch).  The packed kernel of long
 //            one-channel units asks for a quarter of the unit at once: on a sparse launch a wave has its SIMD nearly to
 //            itself, and a hypothesis costs it one memory round trip per batch.
-template <int SPAD, int C, bool BORDER, bool UNIFORM_D, bool PK, int GB = 0>
-__device__ __forceinline__ void scan_reg_body(const ScanArgs& a, int v, int u, int d0, int d1, Best<C>& best,
+template <int SPAD, int C, bool BORDER, bool UNIFORM_D, bool PK, int GB = 0, class BestT = Best<C>>
+__device__ __forceinline__ void scan_reg_body(const ScanArgs& a, int v, int u, int d0, int d1, BestT& best,
                                               float* __restrict__ otab)
 {
     // 104 slots (the c3 shape) have 15 registers to spare at three waves per SIMD: 13 loads in flight instead of 8
@@ -334,17 +334,31 @@ constexpr int scan_reg_waves(int spad, int c)
     return w > 8 ? 8 : (w < 1 ? 1 : w);
 }
 
+// The variants above that run a wave more than their registers allow keep the per-pixel running result in LDS, not in
+// registers (BestLds, k2_scan.hpp): nothing is left for hipcc to spill.
+#ifndef RSLF_REG_BEST_LDS
+#define RSLF_REG_BEST_LDS 1
+#endif
+constexpr bool scan_reg_best_in_lds(int spad, int c)
+{
+    if (!RSLF_REG_BEST_LDS)
+        return false;
+    if (c == 1)
+        return spad == 16 || spad == 40 || spad == 48 || (spad >= 80 && spad <= 88) || (spad >= 104 && spad <= 144);
+    return spad == 24 || spad == 40;
+}
+
 // One wave per SIMD: a wave issues a VALU instruction every ~5 clocks whatever it is (tools/ubench_valu.hip),
 // so packed fp32 halves the issue slots of the mean-shift pass.  With two or more waves the SIMD is already
 // saturated by scalar instructions and packed ones run at half rate.
 constexpr bool scan_reg_packed_math(int spad, int c) { return scan_reg_waves(spad, c) == 1; }
 
-template <int SPAD, int C>
-__device__ __forceinline__ void scan_reg_rows(const ScanArgs& a, int v, int u, int d0, int d1, Best<C>& best, float* otab)
+template <int SPAD, int C, class BestT>
+__device__ __forceinline__ void scan_reg_rows(const ScanArgs& a, int v, int u, int d0, int d1, BestT& best, float* otab)
 {
     constexpr bool PK = scan_reg_packed_math(SPAD, C);
     if (a.dmin_vu) {
-        scan_reg_body<SPAD, C, true, false, PK>(a, v, u, d0, d1, best, otab);
+        scan_reg_body<SPAD, C, true, false, PK, 0, BestT>(a, v, u, d0, d1, best, otab);
         return;
     }
     // the validity test is decided per hypothesis, as in the streaming kernel (scan_stream_rows): runs of hypotheses whose
@@ -363,9 +377,9 @@ __device__ __forceinline__ void scan_reg_rows(const ScanArgs& a, int v, int u, i
         while (e < d1 && interior(e) == in)
             e++;
         if (in)
-            scan_reg_body<SPAD, C, false, true, PK>(a, v, u, d, e, best, otab);
+            scan_reg_body<SPAD, C, false, true, PK, 0, BestT>(a, v, u, d, e, best, otab);
         else
-            scan_reg_body<SPAD, C, true, true, PK>(a, v, u, d, e, best, otab);
+            scan_reg_body<SPAD, C, true, true, PK, 0, BestT>(a, v, u, d, e, best, otab);
         d = e;
     }
 }
@@ -379,7 +393,13 @@ void k2_scan_reg(ScanArgs a)
     constexpr bool kEpiDyn = false;
     float* const epi_lds = nullptr;
     const int epi_stride = 0;
-    RSLF_SCAN_ROW_TILE((scan_reg_rows<SPAD, C>(a, v, u, d0, d1, best, otab)))
+    if constexpr (scan_reg_best_in_lds(SPAD, C)) {
+        __shared__ float s_best[kScanWaves][BestLds<C>::kFloats];
+        BestLds<C> running(s_best[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)]);
+        RSLF_SCAN_ROW_TILE((running.init(), scan_reg_rows<SPAD, C>(a, v, u, d0, d1, running, otab), running.load(best)))
+    } else {
+        RSLF_SCAN_ROW_TILE((scan_reg_rows<SPAD, C>(a, v, u, d0, d1, best, otab)))
+    }
 }
 
 // Packed tiles: its own kernel, because per-lane EPI bases cost address registers the row kernel's

@@ -121,6 +121,54 @@ struct Best {
     }
 };
 
+// The same running result kept in LDS, [field][lane] in the wave's own block: for the register kernels that run one wave
+// per SIMD more than their registers allow -- the six (C = 1) or eight values of Best are touched once per hypothesis
+// (a few thousand instructions apart) and were what hipcc spilled to scratch there: 330 MB of HBM writes per c2 launch
+// against 41 MB of algorithmic traffic (profiles/r02_c2_n1_pmc.json).  Same operations, same order, same bits.
+template <int C>
+struct BestLds {
+    float* blk;   // this wave's block: score[64], d[64], D[64], rbar[C][64], sum (double)[64]
+    static constexpr int kFloats = (3 + C + 2) * 64;
+    __device__ __forceinline__ explicit BestLds(float* wave_block) : blk(wave_block + (threadIdx.x & 63)) {}
+    __device__ __forceinline__ double* sum_ptr() const
+    {
+        return reinterpret_cast<double*>(blk - (threadIdx.x & 63) + (3 + C) * 64) + (threadIdx.x & 63);
+    }
+    __device__ __forceinline__ void init()
+    {
+        blk[0] = -1.0f;
+        reinterpret_cast<int*>(blk)[64] = 0;
+        blk[128] = 0.0f;
+#pragma unroll
+        for (int c = 0; c < C; c++)
+            blk[(3 + c) * 64] = 0.0f;
+        *sum_ptr() = 0.0;
+    }
+    __device__ __forceinline__ void offer(float sc, int dd, float Dd, const float (&rb)[C])
+    {
+        double* sp = sum_ptr();
+        *sp = *sp + (double)sc;
+        if (sc > blk[0]) {   // strict: first maximum wins (cv::minMaxLoc, core.hpp:634)
+            blk[0] = sc;
+            reinterpret_cast<int*>(blk)[64] = dd;
+            blk[128] = Dd;
+#pragma unroll
+            for (int c = 0; c < C; c++)
+                blk[(3 + c) * 64] = rb[c];
+        }
+    }
+    __device__ __forceinline__ void load(Best<C>& b) const
+    {
+        b.score = blk[0];
+        b.d = reinterpret_cast<const int*>(blk)[64];
+        b.D = blk[128];
+#pragma unroll
+        for (int c = 0; c < C; c++)
+            b.rbar[c] = blk[(3 + c) * 64];
+        b.sum = *sum_ptr();
+    }
+};
+
 // Which tile does this workgroup own, which pixel this lane?  Block-uniform result
 // (every wave of the block takes the same branch, so the later barrier is safe).
 // `lb` = tile * groups + group.

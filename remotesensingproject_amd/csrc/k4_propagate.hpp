@@ -23,21 +23,26 @@
 
 namespace rslf {
 
+constexpr int kClaimMaxViews = 1024;    // views whose "anything left to paint?" bits a claim workgroup keeps in LDS
 constexpr int kNoWinner = 0x7F7F7F7F;   // what hipMemset(0x7F) leaves; >= any column index
 
 // One source pixel's claims (core.hpp:1105-1125): `cur` is its filtered disparity.
+// `live_views` (nullable; LDS, one bit per view, claim_live_views): a view none of whose segments this workgroup's sources
+// can land in has a pixel left in its running mask is skipped for the whole workgroup -- after the first visits that is
+// most views for most workgroups, where every source used to read one running-mask byte per view (the whole [S][V][U]
+// volume, 209 MB at c3, on each of the 101 visits).
 template <int C>
-__device__ __forceinline__ void propagate_claim_pixel(const VolView& vol, int s_hat, int v, int u, float cur,
+__device__ __forceinline__ void propagate_claim_pixel(const VolView& vol, int s_hat, int v, int u, float cur, bool source,
                                                       const float* __restrict__ rbar_vu, const uint8_t* __restrict__ mask_svu,
                                                       int* __restrict__ winner_svu, uint8_t* __restrict__ dirty, float slope,
-                                                      float prop_eps)
+                                                      float prop_eps, const unsigned long long* live_views)
 {
     const int nseg = (vol.U + 255) >> 8;
     const long long o = (long long)v * vol.U + u;
     float rb[C];
 #pragma unroll
     for (int c = 0; c < C; c++)
-        rb[c] = rbar_vu[o * C + c];
+        rb[c] = source ? rbar_vu[o * C + c] : 0.0f;
     const long long plane = (long long)vol.V * vol.U;
     const long long row = (long long)v * vol.U;
     // eight views at a time: their running-mask bytes, then the radiances of those still unpainted, are loaded together
@@ -46,6 +51,9 @@ __device__ __forceinline__ void propagate_claim_pixel(const VolView& vol, int s_
     for (int s0 = 0; s0 < vol.S; s0 += B) {
         int ri[B];
         bool live[B];
+        static_assert(64 % B == 0, "a batch of views sits in one word of the live-view bits");
+        if (live_views && ((live_views[s0 >> 6] >> (s0 & 63)) & ((1ull << B) - 1ull)) == 0)
+            continue;   // workgroup-uniform: nothing left to paint in these views within the workgroup's reach
 #pragma unroll
         for (int j = 0; j < B; j++) {
             const int s = s0 + j;
@@ -53,7 +61,7 @@ __device__ __forceinline__ void propagate_claim_pixel(const VolView& vol, int s_
             float off = cur * (float)(s_hat - s);
             off = off * slope;
             ri[j] = u + (int)roundf(off);
-            live[j] = s < vol.S && ri[j] >= 0 && ri[j] < vol.U;
+            live[j] = source && s < vol.S && ri[j] >= 0 && ri[j] < vol.U;
             if (live[j])
                 live[j] = mask_svu[(long long)s * plane + row + ri[j]] != 0;
         }
@@ -93,7 +101,8 @@ __global__ __launch_bounds__(256) void k34_median_claim(VolView vol, int s_hat, 
                                                        int size, float eps, const float* __restrict__ rbar_vu,
                                                        const uint8_t* __restrict__ mask_svu, int* __restrict__ winner_svu,
                                                        uint8_t* __restrict__ dirty, float slope, float prop_eps,
-                                                       const float* __restrict__ gate_Cd_vu, float disp_thr, int* __restrict__ reset)
+                                                       const float* __restrict__ gate_Cd_vu, float disp_thr, int* __restrict__ reset,
+                                                       const int* __restrict__ remain)
 {
     // `reset`: the packed list's length, which the scan before this launch was the last to read and the apply pass after
     // it counts up again from 0
@@ -102,16 +111,59 @@ __global__ __launch_bounds__(256) void k34_median_claim(VolView vol, int s_hat, 
     extern __shared__ __attribute__((aligned(16))) float s_median_cand[];   // [size*size][256]
     float (*cand)[256] = reinterpret_cast<float (*)[256]>(s_median_cand);
     const int v = blockIdx.y;
-    const int u = blockIdx.x * blockDim.x + threadIdx.x;
-    if (u >= vol.U)
-        return;
-    const long long o = (long long)v * vol.U + u;
+    const int u_first = blockIdx.x * blockDim.x;
+    const int u = u_first + threadIdx.x;
+    const bool inside = u < vol.U;
+    const long long o = (long long)v * vol.U + (inside ? u : vol.U - 1);
     // core.hpp:678-679, :881-892: the median over the edge mask, 0 elsewhere
-    const float cur = edge_mask_vu[o] ? selective_median_any<C>(vol, raw_vu, edge_mask_vu, s_hat, size, eps, v, u, cand) : 0.0f;
-    filtered_vu[o] = cur;
-    if (gate_Cd_vu ? !(gate_Cd_vu[o] > disp_thr) : !edge_mask_vu[o])   // core.hpp:1097-1103
+    float cur = 0.0f;
+    if (inside) {
+        cur = edge_mask_vu[o] ? selective_median_any<C>(vol, raw_vu, edge_mask_vu, s_hat, size, eps, v, u, cand) : 0.0f;
+        filtered_vu[o] = cur;
+    }
+    const bool source = inside && (gate_Cd_vu ? gate_Cd_vu[o] > disp_thr : edge_mask_vu[o] != 0);   // core.hpp:1097-1103
+    // the range of the disparities the workgroup's sources hold (a non-finite one: everywhere)
+    __shared__ float s_lo[4], s_hi[4];
+    const bool finite = fabsf(cur) < 1.0e9f;   // false for NaN too
+    float lo = source ? (finite ? cur : -1.0e9f) : INFINITY, hi = source ? (finite ? cur : 1.0e9f) : -INFINITY;
+    for (int off = 32; off > 0; off >>= 1) {
+        lo = fminf(lo, __shfl_xor(lo, off));
+        hi = fmaxf(hi, __shfl_xor(hi, off));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        s_lo[threadIdx.x >> 6] = lo;
+        s_hi[threadIdx.x >> 6] = hi;
+    }
+    const bool any_source = __syncthreads_or(source);
+    if (!any_source)
         return;
-    propagate_claim_pixel<C>(vol, s_hat, v, u, cur, rbar_vu, mask_svu, winner_svu, dirty, slope, prop_eps);
+    const float cur_lo = fminf(fminf(s_lo[0], s_lo[1]), fminf(s_lo[2], s_lo[3]));
+    const float cur_hi = fmaxf(fmaxf(s_hi[0], s_hi[1]), fmaxf(s_hi[2], s_hi[3]));
+    // one thread per view decides whether the view is worth visiting at all (kClaimMaxViews views: more, and every view is visited)
+    __shared__ unsigned long long s_live[kClaimMaxViews / 64];
+    const bool skipping = remain != nullptr && vol.S <= kClaimMaxViews;
+    if (skipping) {
+        const int nseg = (vol.U + 255) >> 8;
+        for (int s0 = 0; s0 < vol.S; s0 += 256) {
+            const int s = s0 + threadIdx.x;
+            bool any = false;
+            if (s < vol.S) {
+                // targets: u + round(fl(fl(cur * float(s_hat - s)) * slope)), monotone in cur; 1.5 covers the roundings
+                const float k = (float)(s_hat - s) * slope;
+                const float a0 = cur_lo * k, a1 = cur_hi * k;
+                const int lo = max(0, (int)floorf((float)u_first + fminf(a0, a1) - 1.5f)) >> 8;
+                const int hi = min(vol.U - 1, max(0, (int)ceilf((float)(u_first + 255) + fmaxf(a0, a1) + 1.5f))) >> 8;
+                const int* rr = remain + ((long long)s * vol.V + v) * nseg;
+                for (int g = lo; g <= hi; g++)
+                    any |= rr[g] != 0;
+            }
+            const unsigned long long b = __ballot(any);
+            if ((threadIdx.x & 63) == 0)
+                s_live[(s0 + threadIdx.x) >> 6] = b;
+        }
+        __syncthreads();
+    }
+    propagate_claim_pixel<C>(vol, s_hat, v, u, cur, source, rbar_vu, mask_svu, winner_svu, dirty, slope, prop_eps, skipping ? s_live : nullptr);
 }
 
 // The apply pass of a visit (core.hpp:1119-1127) and, in the same launch, the pixel list of the NEXT visit's scan: one
@@ -125,13 +177,16 @@ __global__ __launch_bounds__(256) void k34_median_claim(VolView vol, int s_hat, 
 // One 256-column segment of row r = s*V + v of the planes.
 __device__ __forceinline__ void apply_segment(long long r, int seg, int V, int U, const float* __restrict__ filtered_vu,
                                               const float* __restrict__ Cd_hat_vu, float* __restrict__ depth_svu,
-                                              float* __restrict__ Cd_svu, uint8_t* mask_svu, int* __restrict__ winner_svu)
+                                              float* __restrict__ Cd_svu, uint8_t* mask_svu, int* __restrict__ winner_svu,
+                                              int* __restrict__ remain)
 {
     const int u = (seg << 8) + threadIdx.x;
-    if (u >= U)
-        return;
-    const long long t = r * U + u;
-    const int w = winner_svu[t];
+    const long long t = r * U + (u < U ? u : U - 1);
+    const int w = u < U ? winner_svu[t] : U;
+    // every claimed target was in the running mask when it was claimed and leaves it now: the segment's count follows
+    const unsigned long long leaving = __ballot(w < U);
+    if (remain && leaving && (threadIdx.x & 63) == 0)
+        atomicSub(&remain[r * ((U + 255) >> 8) + seg], __popcll(leaving));
     if (w >= U)
         return;
     const long long src = (r % V) * U + w;     // (v, w)
@@ -142,6 +197,28 @@ __device__ __forceinline__ void apply_segment(long long r, int seg, int V, int U
     winner_svu[t] = kNoWinner;
 }
 
+// remain[row][segment] = pixels of the running mask in that 256-column segment, once per sweep (rslf_sweep_begin); the
+// apply passes keep it in step.  (A compaction only ever clears pixels outside the edge mask, which the running masks --
+// clones of the edge masks, core.hpp:958-965 -- do not hold: should a scan drop a pixel from its edge mask, core.hpp:653-657,
+// the count stays one too high, which costs a skipped skip, never a missed claim.)
+__global__ __launch_bounds__(256) void k4_count_segments(const uint8_t* __restrict__ mask_svu, long long rows, int U, int* __restrict__ remain)
+{
+    const int nseg = (U + 255) >> 8;
+    const long long item = blockIdx.x;   // one workgroup per (row, segment)
+    if (item >= rows * nseg)
+        return;
+    const long long r = item / nseg;
+    const int seg = (int)(item - r * nseg);
+    const int u = (seg << 8) + threadIdx.x;
+    const unsigned long long b = __ballot(u < U && mask_svu[r * U + (u < U ? u : 0)] != 0);
+    __shared__ int s_n[4];
+    if ((threadIdx.x & 63) == 0)
+        s_n[threadIdx.x >> 6] = __popcll(b);
+    __syncthreads();
+    if (threadIdx.x == 0)
+        remain[item] = s_n[0] + s_n[1] + s_n[2] + s_n[3];
+}
+
 constexpr int kApplyRowsPerBlock = 4;     // rows a workgroup of the general part takes (their flags: one load)
 constexpr int kApplyFlagSlots = 1024;     // >= kApplyRowsPerBlock * ceil(U / 256) for U <= 65536
 
@@ -150,7 +227,8 @@ __global__ __launch_bounds__(256) void k4_propagate_apply(int S, int V, int U, i
                                                          float* __restrict__ Cd_svu, uint8_t* mask_svu, int* __restrict__ winner_svu,
                                                          uint8_t* __restrict__ dirty, int s_next, const uint8_t* __restrict__ edge_mask_next_vu,
                                                          int* __restrict__ list, int* __restrict__ count,
-                                                         unsigned long long* __restrict__ total, int* __restrict__ packed_n)
+                                                         unsigned long long* __restrict__ total, int* __restrict__ packed_n,
+                                                         int* __restrict__ remain)
 {
     __shared__ uint8_t s_flags[kApplyFlagSlots];
     const int nseg = (U + 255) >> 8;
@@ -161,7 +239,7 @@ __global__ __launch_bounds__(256) void k4_propagate_apply(int S, int V, int U, i
         uint8_t* flags = dirty + r * nseg;
         for (int seg = 0; seg < nseg; seg++)
             if (flags[seg])   // the same byte for the whole workgroup
-                apply_segment(r, seg, V, U, filtered_vu, Cd_hat_vu, depth_svu, Cd_svu, mask_svu, winner_svu);
+                apply_segment(r, seg, V, U, filtered_vu, Cd_hat_vu, depth_svu, Cd_svu, mask_svu, winner_svu, remain);
         __syncthreads();      // every thread has read the flags, and this row's mask writes are the workgroup's own
         if ((int)threadIdx.x < nseg)
             flags[threadIdx.x] = 0;
@@ -187,7 +265,7 @@ __global__ __launch_bounds__(256) void k4_propagate_apply(int S, int V, int U, i
     __syncthreads();
     for (int i = 0; i < nfl; i++)
         if (s_flags[i])
-            apply_segment(r0 + i / nseg, i % nseg, V, U, filtered_vu, Cd_hat_vu, depth_svu, Cd_svu, mask_svu, winner_svu);
+            apply_segment(r0 + i / nseg, i % nseg, V, U, filtered_vu, Cd_hat_vu, depth_svu, Cd_svu, mask_svu, winner_svu, remain);
 }
 
 }  // namespace rslf

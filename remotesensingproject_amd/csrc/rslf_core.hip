@@ -244,6 +244,7 @@ extern "C" int rslf_ctx_destroy(rslf_ctx* ctx) RSLF_API_TRY
         (void)hipFree(ctx->helper[i]);
     (void)hipFree(ctx->winner);
     (void)hipFree(ctx->dirty);
+    (void)hipFree(ctx->remain);
     (void)hipFree(ctx->sweep_mask);
     (void)hipFree(ctx->filtered);
     if (ctx->ev0)
@@ -276,6 +277,8 @@ extern "C" int rslf_ctx_set_debug(rslf_ctx* ctx, const char* key, int value) RSL
         ctx->force_packed = value;
     else if (strcmp(key, "stream_share") == 0 && (value == 0 || value == 1))
         ctx->stream_share = value != 0;
+    else if (strcmp(key, "claim_skip") == 0 && (value == 0 || value == 1))
+        ctx->claim_skip = value;
     else if (strcmp(key, "stream_groups") == 0 && value >= 0 && value <= 64)
         ctx->stream_groups = value;
     else if (strcmp(key, "stream_lds_kib") == 0 && value >= 16 && value <= 152) {

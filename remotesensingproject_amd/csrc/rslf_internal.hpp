@@ -186,7 +186,7 @@ struct rslf_ctx {
     size_t stream_lds_bytes = rslf::plan::kStreamLdsBytes;   // dynamic LDS of one streaming workgroup
     bool stream_attr_set = false;
     bool chip_attr_set = false;
-    int bitmask_mode = -1;     // 2-D sweep: bit-packed shadow of the running masks for the claims (-1 automatic by volume size)
+    int claim_skip = 1;        // 2-D sweep: the claims skip views with nothing left to paint within reach (0: off, A/B and tests)
     rslf::Partial* scan_partial = nullptr;   // [tile][group][64] records of grouped scan launches
     size_t partial_rec_cap = 0;
     int* scan_ticket = nullptr;        // [tile] of the same launches: which group merges the tile (zero between launches)
@@ -201,6 +201,7 @@ struct rslf_ctx {
     // 2-D sweep scratch
     int* winner = nullptr;        // [S][V][U]
     uint8_t* dirty = nullptr;     // [S][V][ceil(U/256)]: segments of the winner rows that hold a claim (all 0 between visits)
+    int* remain = nullptr;        // [S][V][ceil(U/256)]: pixels left in the running mask per segment (lets the claims skip views)
     size_t dirty_cap = 0;
     uint8_t* sweep_mask = nullptr;
     float* filtered = nullptr;    // [V][U] median of the visited view, the propagation's source

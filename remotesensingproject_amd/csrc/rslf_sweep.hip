@@ -33,8 +33,11 @@ static int ensure_sweep_scratch(rslf_ctx* ctx, const rslf_volume* vol)
     const size_t flags = (size_t)vol->S * vol->V * ((vol->U + 255) / 256);
     if (flags > ctx->dirty_cap) {
         (void)hipFree(ctx->dirty);
+        (void)hipFree(ctx->remain);
         ctx->dirty = nullptr;
+        ctx->remain = nullptr;
         ctx->dirty_cap = 0;
+        HIP_TRY(hipMalloc(&ctx->remain, flags * sizeof(int)));
         HIP_TRY(hipMalloc(&ctx->dirty, flags));
         ctx->dirty_cap = flags;
         HIP_TRY(hipMemsetAsync(ctx->dirty, 0, flags, ctx->stream));   // every apply pass leaves them at 0 again
@@ -94,6 +97,14 @@ extern "C" int rslf_sweep_begin(rslf_ctx* ctx, const rslf_volume* vol, const uin
     if (v_hi < V)
         HIP_TRY(hipMemset2DAsync(mask_svu + (size_t)v_hi * U, n, 0, (size_t)(V - v_hi) * U, S, st));
     HIP_TRY(hipMemsetAsync(ctx->total, 0, sizeof(unsigned long long), st));
+    {   // pixels of the running masks per 256-column segment: what lets the claims of the later visits skip most views
+        const long long rows = (long long)S * V;
+        const long long items = rows * ((U + 255) / 256);
+        if (items > (1ll << 31) - 1)
+            return fail(RSLF_ERR_UNSUPPORTED, "%d views x %d scanlines x %d columns: too large for one counting launch", S, V, U);
+        hipLaunchKernelGGL(k4_count_segments, dim3((unsigned)items), dim3(256), 0, st, mask_svu, rows, U, ctx->remain);
+        HIP_TRY(hipGetLastError());
+    }
     {   // the sparse visits' records, sized before the first visit (no allocation in the middle of the sequence).
         // (The same choice of kernel as rslf_depth_epi_scan makes for linear interpolation without debug hooks; should it
         // differ, that call sizes the records itself.)
@@ -183,16 +194,18 @@ extern "C" int rslf_sweep_visit_finish(rslf_ctx* ctx, const rslf_volume* vol, in
     if (C == 1)
         hipLaunchKernelGGL(k34_median_claim<1>, grid_vu, dim3(256), median_lds, st, view_of(vol), s_hat, depth, ctx->filtered, cem,
                            p->median_filter_size, p->median_filter_epsilon, rbar, mask_svu, ctx->winner, ctx->dirty, p->slope_factor,
-                           p->propagation_epsilon, p->use_disp_confidence_score ? Cd : nullptr, p->disp_score_threshold, packed_n);
+                           p->propagation_epsilon, p->use_disp_confidence_score ? Cd : nullptr, p->disp_score_threshold, packed_n,
+                           ctx->claim_skip ? ctx->remain : nullptr);
     else
         hipLaunchKernelGGL(k34_median_claim<3>, grid_vu, dim3(256), median_lds, st, view_of(vol), s_hat, depth, ctx->filtered, cem,
                            p->median_filter_size, p->median_filter_epsilon, rbar, mask_svu, ctx->winner, ctx->dirty, p->slope_factor,
-                           p->propagation_epsilon, p->use_disp_confidence_score ? Cd : nullptr, p->disp_score_threshold, packed_n);
+                           p->propagation_epsilon, p->use_disp_confidence_score ? Cd : nullptr, p->disp_score_threshold, packed_n,
+                           ctx->claim_skip ? ctx->remain : nullptr);
     HIP_TRY(hipGetLastError());
     const unsigned apply_blocks = (unsigned)((s_next >= 0 ? V : 0) + ((long long)S * V + kApplyRowsPerBlock - 1) / kApplyRowsPerBlock);
     hipLaunchKernelGGL(k4_propagate_apply, dim3(apply_blocks), dim3(256), 0, st, S, V, U, s_hat, ctx->filtered, Cd, d_depth_svu,
                        d_Cd_svu, mask_svu, ctx->winner, ctx->dirty, s_next, s_next >= 0 ? d_Ce_mask_svu + (size_t)s_next * n : nullptr, ctx->list,
-                       ctx->count, ctx->total, packed_n);
+                       ctx->count, ctx->total, packed_n, ctx->remain);
     HIP_TRY(hipGetLastError());
     ctx->packed_n_clean = s_next < 0;       // k34_median_claim zeroed the packed list's length; a listing apply pass set it again
     ctx->precompacted = s_next >= 0 ? 2 : 0;

@@ -20,6 +20,7 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 PROF = os.path.join(ROOT, "gpurun_out", os.environ.get("PROF_DIR", "prof"))
 
 
@@ -78,7 +79,10 @@ def main():
                 factor = known / (summary[k0]["FETCH_SIZE"] * 1024.0)
         rd = summary[k2]["FETCH_SIZE"] * 1024.0 * factor
         wr = summary[k2].get("WRITE_SIZE", 0.0) * 1024.0
-        traffic = dict(hbm_bytes_per_launch=rd + wr, read_bytes=rd, write_bytes=wr,
+        from remotesensingproject_amd import build as hb
+        import datetime
+        traffic = dict(source_hash=hb.source_hash(), collected=datetime.date.today().isoformat(),
+                       hbm_bytes_per_launch=rd + wr, read_bytes=rd, write_bytes=wr,
                        fetch_size_kib=summary[k2]["FETCH_SIZE"], write_size_kib=summary[k2].get("WRITE_SIZE"),
                        read_calibration_factor=factor, calibrated_on="k0_pack known read bytes %s" % known,
                        kernel=k2, workload=wl)
@@ -86,7 +90,32 @@ def main():
         tj = json.load(open(tpath)) if os.path.exists(tpath) else {}
         tj[tag] = traffic
         json.dump(tj, open(tpath, "w"), indent=1)
-    json.dump(dict(bench_line_under_rocprof=bench, per_launch_counter_means=summary, k2_traffic=traffic),
+    # effective shader clock of the scan under profiling: GRBM_GUI_ACTIVE is summed over the 8 XCDs (MI355X_MICROARCH.md)
+    clock = None
+    stats_avg_ns = None
+    if st:
+        for r in rows[1:]:
+            if k2 and r[0].split("(")[0].replace("void ", "") == k2:
+                stats_avg_ns = float(r[3]) if len(r) > 3 else None
+    if k2 and "GRBM_GUI_ACTIVE" in summary.get(k2, {}) and stats_avg_ns:
+        clock = summary[k2]["GRBM_GUI_ACTIVE"] / 8.0 / stats_avg_ns   # cycles per ns = GHz
+    # several launches make one step of a grouped streaming / on-chip sweep: what bench.py's events bracket is their SUM
+    launches_per_step = None
+    if k2 and st:
+        for r in rows[1:]:
+            if r[0].split("(")[0].replace("void ", "") == k2 and bench.get("steps"):
+                launches_per_step = float(r[1]) / (bench["steps"] + bench.get("warmup", 0) + 1)   # + the stats run
+    if traffic and launches_per_step and launches_per_step > 1.5:
+        n = round(launches_per_step)
+        traffic.update(launches_per_step=n, per_launch_mean=dict(read_bytes=traffic["read_bytes"], write_bytes=traffic["write_bytes"]),
+                       hbm_bytes_per_launch=(rd + wr) * n, read_bytes=rd * n, write_bytes=wr * n,
+                       note="a step of this workload is %d launches of the kernel (row blocks); the figures are their SUM, what bench.py's HIP events bracket" % n)
+        tj = json.load(open(tpath))
+        tj[tag] = traffic
+        json.dump(tj, open(tpath, "w"), indent=1)
+    json.dump(dict(bench_line_under_rocprof=bench, per_launch_counter_means=summary, k2_traffic=traffic,
+                   effective_clock_ghz_under_profiling=clock, kernel_avg_ns_rocprof_stats=stats_avg_ns,
+                   source_hash=traffic.get("source_hash") if traffic else None),
               open(os.path.join(out, "%s_%s_pmc.json" % (rnd, tag)), "w"), indent=1)
     print(json.dumps(dict(k2=summary.get(k2), traffic=traffic), indent=1))
 
