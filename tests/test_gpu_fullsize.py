@@ -103,3 +103,40 @@ def test_c3_full_known_answer(rs, oracle_mod):
     for k in ("depth_idx", "score", "rbar", "depth_raw", "edge_confidence", "edge_mask"):
         assert np.array_equal(a[k][rows], getattr(ref, k)), k
     assert np.array_equal(a["depth"][:3], ref.depth[:3])   # rows 0..2 see only rows 0..4
+
+
+def test_c3_full_size_8_way_partition_stitches(rs):
+    """BASELINE.json configs[3] (c4): the c3 sweep cut into eight blocks of 135 scanlines with their recomputed 2-row
+    halos (what eight ranks compute), run one after the other on the one GPU and stitched through the same packed-plane
+    path the RCCL gather uses -- bit-identical to the unsharded planes, scanned-pixel counts adding up.  RCCL itself has
+    not run on hardware (one-GPU boxes); tools/multi_gpu_selftest.py is the one command for the first multi-GPU lease."""
+    import torch
+    from remotesensingproject_amd import sharding
+    from remotesensingproject_amd.synth import make_config
+    vol, _, c = make_config("c3")
+    V, U, D = c["V"], c["U"], c["D"]
+    dev = torch.from_numpy(vol).cuda()
+    comp = rs.Depth1DComputer_pile(rs.Volume.from_dense(dev, 1.0), c["dmin"], c["dmax"], D)
+    comp.run()
+    full = dict(edge_confidence=comp.m_edge_confidence_v_u, disp_confidence=comp.m_disp_confidence_v_u, depth=comp.m_best_depth_v_u,
+                depth_raw=comp.m_depth_raw_v_u, score=comp.m_score_v_u, depth_idx=comp.m_depth_idx_v_u, rbar=comp.m_rbar_v_u,
+                edge_mask=comp.m_edge_confidence_mask_v_u)
+    parts = sharding.row_partition(V, 8)
+    assert all(b - a == 135 for a, b in parts)
+    bufs, scanned = [], 0
+    for r in range(8):
+        sh = sharding.make_shard(V, r, 8, 5)
+        assert (sh.v1 - sh.v0, sh.hi - sh.lo) == (135, 137 if r in (0, 7) else 139)
+        cs = rs.Depth1DComputer_pile(rs.Volume.from_dense(dev[sh.rows], 1.0), c["dmin"], c["dmax"], D)
+        cs.run(want_stats=False)
+        pl = dict(edge_confidence=cs.m_edge_confidence_v_u, disp_confidence=cs.m_disp_confidence_v_u, depth=cs.m_best_depth_v_u,
+                  depth_raw=cs.m_depth_raw_v_u, score=cs.m_score_v_u, depth_idx=cs.m_depth_idx_v_u, rbar=cs.m_rbar_v_u,
+                  edge_mask=cs.m_edge_confidence_mask_v_u)
+        scanned += int((pl["edge_mask"][sh.interior] > 0).sum().item())
+        bufs.append(sharding.pack_planes(pl, sh.interior, 135, U, 1))
+        del cs, pl
+    st = sharding.unpack_planes(bufs, parts, 135, U, 1)
+    torch.cuda.synchronize()
+    for k in full:
+        assert torch.equal(st[k], full[k]), k
+    assert scanned == comp.stats.pixels_scanned
