@@ -389,6 +389,8 @@ def usable_cpus() -> int:
 
 
 ASSUME_RGB_SUM_IN_ORDER, ASSUME_MUL_SCALE_LAST, ASSUME_DIV0_IEEE, ASSUME_MAX_NAN_TAIL = 1, 2, 4, 8
+# the fine-to-coarse pyramid's readings (rslf_fine_to_coarse_core.cpp:22-41, :69-135)
+ASSUME_GAUSS_ROW_SYMM, ASSUME_GAUSS_COL_ORDER, ASSUME_AREA_SCALAR, ASSUME_SIZE_FLOOR, ASSUME_RESIZE_FLOAT = 16, 32, 64, 128, 256
 
 
 def set_assumptions(flags: int) -> None:

@@ -971,6 +971,11 @@ static int cv_round_half_even(double x)
 void oracle_f2c_out_dims(int V, int U, int* V2, int* U2)
 {
     /* cv::resize with dsize empty: Size(saturate_cast<int>(cols*fx), saturate_cast<int>(rows*fy)) */
+    if (g_assume & ORACLE_ASSUME_SIZE_FLOOR) {
+        *V2 = (int)floor(V * 0.5);
+        *U2 = (int)floor(U * 0.5);
+        return;
+    }
     *V2 = cv_round_half_even(V * 0.5);
     *U2 = cv_round_half_even(U * 0.5);
 }
@@ -994,23 +999,44 @@ static void gaussian7_reflect(const float* src, float* dst, float* tmp, int R, i
     for (int y = 0; y < R; y++)
         for (int x = 0; x < W; x++)
             for (int c = 0; c < C; c++) {
-                float s = k[0] * src[((size_t)y * W + reflect_border(x - 3, W)) * C + c];
-                for (int j = 1; j < 7; j++) {
-                    const float pr = k[j] * src[((size_t)y * W + reflect_border(x + j - 3, W)) * C + c];
-                    s = s + pr;
+                float s;
+                if (g_assume & ORACLE_ASSUME_GAUSS_ROW_SYMM) {
+                    s = k[3] * src[((size_t)y * W + x) * C + c];
+                    for (int j = 1; j <= 3; j++) {
+                        const float a = src[((size_t)y * W + reflect_border(x + j, W)) * C + c];
+                        const float b = src[((size_t)y * W + reflect_border(x - j, W)) * C + c];
+                        const float ab = a + b;
+                        const float pr = k[3 + j] * ab;
+                        s = s + pr;
+                    }
+                } else {
+                    s = k[0] * src[((size_t)y * W + reflect_border(x - 3, W)) * C + c];
+                    for (int j = 1; j < 7; j++) {
+                        const float pr = k[j] * src[((size_t)y * W + reflect_border(x + j - 3, W)) * C + c];
+                        s = s + pr;
+                    }
                 }
                 tmp[((size_t)y * W + x) * C + c] = s;
             }
     for (int y = 0; y < R; y++)
         for (int x = 0; x < W; x++)
             for (int c = 0; c < C; c++) {
-                float s = k[3] * tmp[((size_t)y * W + x) * C + c];
-                for (int j = 1; j <= 3; j++) {
-                    const float a = tmp[((size_t)reflect_border(y + j, R) * W + x) * C + c];
-                    const float b = tmp[((size_t)reflect_border(y - j, R) * W + x) * C + c];
-                    const float ab = a + b;
-                    const float pr = k[3 + j] * ab;
-                    s = s + pr;
+                float s;
+                if (g_assume & ORACLE_ASSUME_GAUSS_COL_ORDER) {
+                    s = k[0] * tmp[((size_t)reflect_border(y - 3, R) * W + x) * C + c];
+                    for (int j = 1; j < 7; j++) {
+                        const float pr = k[j] * tmp[((size_t)reflect_border(y + j - 3, R) * W + x) * C + c];
+                        s = s + pr;
+                    }
+                } else {
+                    s = k[3] * tmp[((size_t)y * W + x) * C + c];
+                    for (int j = 1; j <= 3; j++) {
+                        const float a = tmp[((size_t)reflect_border(y + j, R) * W + x) * C + c];
+                        const float b = tmp[((size_t)reflect_border(y - j, R) * W + x) * C + c];
+                        const float ab = a + b;
+                        const float pr = k[3 + j] * ab;
+                        s = s + pr;
+                    }
                 }
                 dst[((size_t)y * W + x) * C + c] = s;
             }
@@ -1027,7 +1053,12 @@ static void halve_area(const float* src, int R, int W, int C, float* dst, int R2
             for (int c = 0; c < C; c++) {
                 const int y0 = 2 * y, x0 = 2 * x;
                 float out;
-                if (y0 + 1 < R && x0 + 1 < W) {
+                if (y0 + 1 < R && x0 + 1 < W && (g_assume & ORACLE_ASSUME_AREA_SCALAR)) {
+                    float sum = src[((size_t)y0 * W + x0) * C + c] + src[((size_t)y0 * W + x0 + 1) * C + c];
+                    sum = sum + src[((size_t)(y0 + 1) * W + x0) * C + c];
+                    sum = sum + src[((size_t)(y0 + 1) * W + x0 + 1) * C + c];
+                    out = sum * 0.25f;
+                } else if (y0 + 1 < R && x0 + 1 < W) {
                     const float a = src[((size_t)y0 * W + x0) * C + c] + src[((size_t)(y0 + 1) * W + x0) * C + c];
                     const float b = src[((size_t)y0 * W + x0 + 1) * C + c] + src[((size_t)(y0 + 1) * W + x0 + 1) * C + c];
                     const float ab = a + b;
@@ -1214,8 +1245,9 @@ static void resize_linear_f32(const float* src, int R, int W, float* dst, int R2
     int* xofs = (int*)malloc(sizeof(int) * (size_t)W2);
     float* xa = (float*)malloc(sizeof(float) * 2 * (size_t)W2);
     int xmax = W2;
+    const int coord_float = (g_assume & ORACLE_ASSUME_RESIZE_FLOAT) != 0;
     for (int dx = 0; dx < W2; dx++) {
-        float fx = (float)((dx + 0.5) * scale_x - 0.5);
+        float fx = coord_float ? ((float)dx + 0.5f) * (float)scale_x - 0.5f : (float)((dx + 0.5) * scale_x - 0.5);
         int sx = (int)floor(fx);
         fx -= sx;
         if (sx < 0) {
@@ -1237,7 +1269,7 @@ static void resize_linear_f32(const float* src, int R, int W, float* dst, int R2
     float* row0 = (float*)malloc(sizeof(float) * (size_t)W2);
     float* row1 = (float*)malloc(sizeof(float) * (size_t)W2);
     for (int dy = 0; dy < R2; dy++) {
-        float fy = (float)((dy + 0.5) * scale_y - 0.5);
+        float fy = coord_float ? ((float)dy + 0.5f) * (float)scale_y - 0.5f : (float)((dy + 0.5) * scale_y - 0.5);
         int sy = (int)floor(fy);
         fy -= sy;
         const float b0 = 1.f - fy, b1 = fy;

@@ -206,6 +206,14 @@ void oracle_f2c_fuse(const float* const* disp, const uint8_t* const* valid, cons
 #define ORACLE_ASSUME_MUL_SCALE_LAST   2   /* cv::multiply(a, b, scale) as scale * (a * b), not (scale * a) * b */
 #define ORACLE_ASSUME_DIV0_IEEE        4   /* cv::divide by 0 as IEEE inf / NaN (OpenCV 4.x), not 0 (3.x) */
 #define ORACLE_ASSUME_MAX_NAN_TAIL     8   /* cv::max(x, 0) keeps a NaN in the scalar tail (last n % 8 elements) */
+/* ... and of the fine-to-coarse pyramid (rslf_fine_to_coarse_core.cpp:22-41, :69-135): */
+#define ORACLE_ASSUME_GAUSS_ROW_SYMM   16  /* GaussianBlur's ROW filter in the symmetric form k[c]*x[c] + k[c+j]*(x[c+j] + x[c-j]) (as its
+                                              column filter), not taps accumulated left to right */
+#define ORACLE_ASSUME_GAUSS_COL_ORDER  32  /* ... and its COLUMN filter with the taps accumulated top to bottom, not the symmetric form */
+#define ORACLE_ASSUME_AREA_SCALAR      64  /* the 2x2 area mean as ((S00 + S01) + S10) + S11 (resizeAreaFast's scalar tail, which the last
+                                              W2 % 4 columns of a SIMD build take) for every pixel, not (S00 + S10) + (S01 + S11) */
+#define ORACLE_ASSUME_SIZE_FLOOR       128 /* level sizes floor(n * 0.5) (saturate_cast of a truncating build), not cvRound */
+#define ORACLE_ASSUME_RESIZE_FLOAT     256 /* the upscaling's source coordinates computed in float, not in double and then cast */
 void oracle_set_assumptions(int flags);
 int oracle_assumptions(void);
 int oracle_num_threads(void);

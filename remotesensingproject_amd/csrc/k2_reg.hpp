@@ -20,7 +20,7 @@ namespace rslf {
 // and P = 1e30 * 0 = 0 exactly, so they add +0 to every sum -- bit-identical to the
 // reference's "NaN -> K = 0, R0 = 0" without a second register per sample.
 // Needs R == max(R, 0), hence the non-negative-volume precondition checked by
-// the host (rslf_abi.hip: rslf_depth_epi_pile).
+// the host (rslf_pile.hip: choose_scan).
 // ---------------------------------------------------------------------------
 // samples whose loads are in flight together (2 registers per sample and channel while they are)
 constexpr int gather_batch(int c) { return c == 1 ? 8 : 4; }

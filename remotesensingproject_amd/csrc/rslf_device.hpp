@@ -29,7 +29,7 @@ struct VolView {
     }
 };
 
-// Scalars derived once on the host from rslf_params (rslf_abi.hip: make_consts).
+// Scalars derived once on the host from rslf_params (rslf_core.hip: make_scan_consts).
 struct ScanConsts {
     float slope;          // par_slope_factor
     float inv_h2;         // float(1.0 / double(h*h))       kernels.hpp:43

@@ -268,6 +268,13 @@ static void test_scan_plans()
     p = plan_scan(c5, 68);
     CHECK(p.groups == 16 && p.tile_w == 63 && p.tiles_per_row == 65 && p.rows_per_launch == 126 && p.stream_park == 24);
     CHECK(p.lds_bytes == 4 * 4 * (204 + 24 * 3 * 64) && p.lds_bytes <= kStreamLdsBytes);
+    ScanRequest chip = c5;                                  // the on-chip kernel: the streaming kernel's groups and tiles, all of the CU's LDS
+    chip.use_stream = false;
+    chip.use_chip = true;
+    chip.chip_wave_floats = 204 + 52 * 3 * 64;
+    p = plan_scan(chip, 0);
+    CHECK(p.groups == 16 && !p.packed && p.tile_w == 63 && p.tiles_per_row == 65 && p.rows_per_launch == 126 && p.stream_park == 0);
+    CHECK(p.lds_bytes == (size_t)4 * 4 * (204 + 52 * 3 * 64) && p.lds_bytes <= (size_t)160 << 10);
     // the sweep's sparse visits: a packed list, 32 groups asked for
     ScanRequest sparse = request(512, 512, 33, 1, 128);
     sparse.ctx_groups = kSweepGroups;

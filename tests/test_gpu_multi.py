@@ -193,3 +193,46 @@ def test_multi_fine_to_coarse_equals_single_device(rs, devices, C_, dtype, V):
     assert np.array_equal(got_valid, want_valid.cpu().numpy())
     assert m.stats.pixels_scanned == sum(int(c.stats.pixels_scanned) for c in f.m_computers)
     m.close()
+
+
+def _need_devices(n):
+    from remotesensingproject_amd import _lib
+    have = int(_lib.lib().rslf_device_count())
+    if have < n:
+        pytest.skip("needs %d GPUs, this box has %d: the copies between DIFFERENT devices (hipMemcpyPeerAsync of the device-out "
+                    "pile path, the sweep's boundary-row fetch, the fine-to-coarse row transfers) have never run" % (n, have))
+
+
+@pytest.mark.parametrize("devices", [[0, 1], [0, 1, 2, 3]])
+def test_on_distinct_devices_everything_equals_one_device(rs, devices):
+    """the cross-device branches.  Skipped on the one-GPU development boxes; on a multi-GPU node this and
+    tools/multi_gpu_selftest.py are their first execution.  Pile path (host-out and device-out), sharded sweep,
+    fine-to-coarse -- each bit-identical to the one-device run -- and the peer-access matrix is printed."""
+    _need_devices(len(devices))
+    V, S, U, D = 64, 7, 140, 12
+    vol = _field(V, S, U, 1, 77)
+    epis = [vol[v, :, :, 0] for v in range(V)]
+    m = rs.MultiDevice(devices)
+    print("peer access:", m.peer_access())
+    comp = rs.Depth1DComputer_pile(epis, -1.0, 2.0, D, epi_scale_factor=1.0)
+    comp.run()
+    ref = comp.results()
+    got = m.depth1d_pile(epis, -1.0, 2.0, D, epi_scale_factor=1.0)
+    for k in PLANES:
+        assert np.array_equal(got[k], ref[k]), k
+    dev_out = m.depth1d_pile_device_out(epis, -1.0, 2.0, D, out_device=devices[-1], epi_scale_factor=1.0)
+    for k in PLANES:
+        assert dev_out[k].device.index == devices[-1]
+        assert np.array_equal(dev_out[k].cpu().numpy(), ref[k]), k
+    c2 = rs.Depth2DComputer(epis, -1.0, 2.0, D, epi_scale_factor=1.0)
+    c2.run()
+    r2 = c2.results()
+    g2 = m.depth2d(epis, -1.0, 2.0, D, epi_scale_factor=1.0)
+    for k in r2:
+        assert np.array_equal(g2[k], r2[k]), k
+    f = rs.FineToCoarse(vol[..., 0], -1.0, 1.0, 9, epi_scale_factor=1.0)
+    f.run()
+    wm, wv = f.get_results()
+    gm, gv, _ = m.fine_to_coarse(epis, -1.0, 1.0, 9, epi_scale_factor=1.0)
+    assert np.array_equal(gm, wm.cpu().numpy()) and np.array_equal(gv, wv.cpu().numpy())
+    m.close()

@@ -7,7 +7,12 @@ its plausible alternative (oracle.set_assumptions) on the golden cases, a slice 
 whose hypothesis count leaves a SIMD tail, and counts what changes: arg-max indices, best scores, edge-mask pixels,
 filtered depths.  CPU only (the oracle); the product is not involved.
 
-    python tools/blast_radius.py [--out profiles/r02_blast_radius.md]
+    python tools/blast_radius.py [--out profiles/r03_blast_radius.md] [--rows scan|f2c|all]
+
+Round 3: the same for the fine-to-coarse row (rslf_fine_to_coarse_core.cpp:22-41, :69-135) -- Gaussian row / column tap
+order, the area mean's pairing, cvRound level sizes, the upscaling's coordinate precision: the whole oracle pipeline
+(pyramid, per-level sweeps with tightened bounds, fusion) is re-run with one reading replaced, on the shapes
+tests/test_gpu_f2c.py drives, and the fused map's pixels that change are counted.
 """
 from __future__ import annotations
 
@@ -50,12 +55,83 @@ def cases():
     yield "structured RGB (160 px x 6 rows, 25 views, 33 hyp)", v3, dict(dmin=-1.0, dmax=1.0, D=33, s_hat=-1)
 
 
+F2C_ALTS = [
+    ("(v) Gaussian ROW filter in the symmetric form", oracle.ASSUME_GAUSS_ROW_SYMM,
+     "cv::GaussianBlur's row pass as k[c]*x[c] + sum_j k[c+j]*(x[c+j] + x[c-j]) (what its column pass does) instead of the seven taps accumulated left to right (fine_to_coarse_core.cpp:33)"),
+    ("(vi) Gaussian COLUMN filter tap by tap", oracle.ASSUME_GAUSS_COL_ORDER,
+     "the column pass accumulating its seven taps top to bottom instead of the symmetric form (fine_to_coarse_core.cpp:33)"),
+    ("(vii) area mean as ((S00+S01)+S10)+S11", oracle.ASSUME_AREA_SCALAR,
+     "cv::resize(0.5, 0.5)'s 2x2 mean in resizeAreaFast's scalar order -- what the last W2 % 4 columns of a SIMD build take -- applied to EVERY pixel (an upper bound) instead of the SIMD form (S00+S10)+(S01+S11) (fine_to_coarse_core.cpp:37)"),
+    ("(viii) level sizes floor(n/2)", oracle.ASSUME_SIZE_FLOOR,
+     "Size(cols*0.5, rows*0.5) truncated instead of cvRound (ties to even): differs only where a side is odd (fine_to_coarse_core.cpp:37)"),
+    ("(ix) upscaling coordinates in float", oracle.ASSUME_RESIZE_FLOAT,
+     "cv::resize(INTER_LINEAR)'s source coordinates (dx+0.5)*scale-0.5 evaluated in float instead of double-then-cast (fine_to_coarse_core.cpp:104)"),
+]
+
+
+def f2c_cases():
+    """The shapes of tests/test_gpu_f2c.py (44 x 64 px, 5 views) and a larger, odd-sized field whose levels have odd sides."""
+    for C_, u8 in ((1, False), (3, False), (3, True), (1, True)):
+        vol, _ = make_lightfield(64, 44, 5, C_, seed=2, dmin=-1, dmax=1, band=8)
+        raw = np.round(vol * 255.0).astype(np.float32) if u8 else (vol * 200 + 3).astype(np.float32)
+        yield "test_gpu_f2c case: 64 x 44 px, 5 views, %d ch, %s, 9 hyp" % (C_, "uchar" if u8 else "float"), raw, dict(dmin=-1.0, dmax=1.0, D=9, u8=u8)
+    vol, _ = make_lightfield(203, 91, 7, 1, seed=11, dmin=-1, dmax=2, band=8)
+    yield "203 x 91 px (odd sides at every level), 7 views, float, 16 hyp", (vol * 180 + 5).astype(np.float32), dict(dmin=-1.0, dmax=2.0, D=16, u8=False)
+    rng = np.random.default_rng(5)
+    yield "noise 150 x 70 px, 5 views, float, 12 hyp", rng.uniform(0, 255, (70, 5, 150, 1)).astype(np.float32), dict(dmin=-1.0, dmax=1.0, D=12, u8=False)
+
+
+def f2c_section(lines):
+    lines += ["", "# Blast radius of the fine-to-coarse row's readings (round 3)", "",
+              "`python tools/blast_radius.py --rows f2c` — CPU oracle only: `FineToCoarse` constructor + `run()` + `get_results()`",
+              "(pyramid, per-level sweeps with tightened bounds, fusion) with ONE reading replaced.  `pyramid` = values of the first halved",
+              "volume that differ (bitwise: the reading's direct effect, one ulp each); `levels` = pyramid levels whose size",
+              "changes; `lvl px` = pixels of the per-level disparity planes that differ (bitwise, summed over the levels of equal size);",
+              "`fused` = pixels of the fused map that differ (bitwise), `valid` = pixels of the fused validity mask that differ,",
+              "`max |d|` = largest change of a fused disparity.  uchar fields blur and halve in integer arithmetic (exact: tap order",
+              "and pairing cannot matter there), so (v)-(vii) can only move float fields.", ""]
+    for label, flag, what in F2C_ALTS:
+        lines += ["## %s" % label, "", what + ".", "", "| case | fused px | pyramid | levels | lvl px | fused | valid | max \\|d\\| |", "|---|---|---|---|---|---|---|---|"]
+        tot = moved = 0
+        for name, raw, m in f2c_cases():
+            down = oracle.downsample_epis_u8 if m["u8"] else oracle.downsample_epis
+            oracle.set_assumptions(0)
+            a = oracle.fine_to_coarse_run(raw, m["dmin"], m["dmax"], m["D"], is_u8=m["u8"])
+            pa = down(raw)
+            oracle.set_assumptions(flag)
+            b = oracle.fine_to_coarse_run(raw, m["dmin"], m["dmax"], m["D"], is_u8=m["u8"])
+            pb = down(raw)
+            oracle.set_assumptions(0)
+            pyr = "%.1f %%" % (100.0 * float((pa.view(np.uint32) != pb.view(np.uint32)).mean())) if pa.shape == pb.shape else "resized"
+            n = a["fused_map"].size
+            dl = sum(1 for x, y in zip(a["dims"], b["dims"]) if x != y) + abs(len(a["dims"]) - len(b["dims"]))
+            lvl = sum(int((la.depth.view(np.uint32) != lb.depth.view(np.uint32)).sum())
+                      for la, lb, x, y in zip(a["levels"], b["levels"], a["dims"], b["dims"]) if x == y)
+            same_shape = a["fused_map"].shape == b["fused_map"].shape
+            df = int((a["fused_map"].view(np.uint32) != b["fused_map"].view(np.uint32)).sum()) if same_shape else n
+            dv = int((a["fused_valid"] != b["fused_valid"]).sum()) if same_shape else n
+            with np.errstate(invalid="ignore"):
+                mx = float(np.nanmax(np.abs(a["fused_map"].astype(np.float64) - b["fused_map"].astype(np.float64)))) if same_shape else float("nan")
+            lines.append("| %s | %d | %s | %d | %d | %d | %d | %.3g |" % (name, n, pyr, dl, lvl, df, dv, mx))
+            tot += n
+            moved += df
+        lines += ["", "Total: %d of %d fused disparities change (%.3f %%)." % (moved, tot, 100.0 * moved / max(tot, 1)), ""]
+        print(label, "->", moved, "of", tot, "fused pixels", flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r02_blast_radius.md"))
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r03_blast_radius.md"))
+    ap.add_argument("--rows", default="all", choices=["scan", "f2c", "all"])
     args = ap.parse_args()
     oracle.build()
-    lines = ["# Blast radius of the unverifiable OpenCV 3.x readings (round 2)", "",
+    if args.rows == "f2c":
+        lines = []
+        f2c_section(lines)
+        open(args.out, "w").write("\n".join(lines).lstrip("\n") + "\n")
+        print("wrote", args.out)
+        return
+    lines = ["# Blast radius of the unverifiable OpenCV 3.x readings: the scan (round 2 table, re-run)", "",
              "`python tools/blast_radius.py` — CPU oracle only.  Each row re-runs `Depth1DComputer_pile::run` with ONE reading of",
              "SURVEY.md App. B replaced by its alternative and counts what differs from the reading of record (the one the HIP",
              "path is bit-identical to).  `idx` = arg-max indices among scanned pixels, `score` = best scores (bitwise),",
@@ -82,6 +158,8 @@ def main():
             tot_idx += d_idx
         lines += ["", "Total: %d of %d arg-max indices move (%.4f %%)." % (tot_idx, tot_px, 100.0 * tot_idx / max(tot_px, 1)), ""]
         print(label, "->", tot_idx, "of", tot_px, "indices", flush=True)
+    if args.rows == "all":
+        f2c_section(lines)
     open(args.out, "w").write("\n".join(lines) + "\n")
     print("wrote", args.out)
 

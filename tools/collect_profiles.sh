@@ -4,11 +4,14 @@
 # share a pass; MI355X_MICROARCH.md "rocprofv3 PMC slots"); TA / TD / TCP counters two per pass (larger groups aborted or
 # hung the profiler on this pool).  Every pass has its own timeout and the chain stops at the first failure.
 #   BENCH_ARGS="--config c5 --rows 16" PROF_DIR=prof_c5 bash tools/collect_profiles.sh
+# Round 3: the SAME lease also records (a) an un-profiled bench line of the same command (bench_plain.json: what the
+# roofline of record is checked against), (b) the source hash the numbers belong to, (c) the library's resource table.
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/${PROF_DIR:-prof}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-e2e ${BENCH_ARGS:-}"
+ARGS="--steps ${PROF_STEPS:-3} --warmup 1 --no-cpu-baseline --no-e2e ${BENCH_ARGS:-}"
+python3 -c "import sys; sys.path.insert(0, '$R'); from remotesensingproject_amd import build as b; print(b.source_hash())" > $OUT/source_hash.txt 2>/dev/null
 pass() {  # name, rocprofv3 options...
   name=$1; shift
   echo "pass $name" >> $OUT/progress.txt
@@ -17,6 +20,7 @@ pass() {  # name, rocprofv3 options...
   echo "pass $name rc=$rc" >> $OUT/progress.txt
   return $rc
 }
+timeout -k 5 ${PASS_TIMEOUT:-200} python3 $R/bench.py --steps ${PLAIN_STEPS:-10} --warmup 2 --no-cpu-baseline --no-e2e ${BENCH_ARGS:-} > $OUT/bench_plain.json 2> $OUT/bench_plain.err &&
 pass stats --stats && cp $OUT/bench_stats.json $OUT/bench_stats.json.keep &&
 pass pmc_fetch --pmc FETCH_SIZE &&
 pass pmc_write --pmc WRITE_SIZE &&

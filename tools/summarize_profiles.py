@@ -113,7 +113,26 @@ def main():
         tj = json.load(open(tpath))
         tj[tag] = traffic
         json.dump(tj, open(tpath, "w"), indent=1)
-    json.dump(dict(bench_line_under_rocprof=bench, per_launch_counter_means=summary, k2_traffic=traffic,
+    # the un-profiled line of the same command on the same lease (tools/collect_profiles.sh): the roofline of record
+    plain = {}
+    pj = os.path.join(PROF, "bench_plain.json")
+    if os.path.exists(pj):
+        try:
+            plain = json.loads([l for l in open(pj).read().strip().splitlines() if l.startswith("{")][-1])
+            json.dump(plain, open(os.path.join(out, "%s_bench_%s.json" % (rnd, tag)), "w"), indent=1)
+        except Exception:  # noqa: BLE001
+            plain = {}
+    check = None
+    if plain and stats_avg_ns and k2:
+        rl = plain["roofline"]
+        n = traffic.get("launches_per_step", 1) if traffic else 1
+        frac_csv = rl["units_per_launch"] * rl["flops_per_unit"] / (stats_avg_ns * n * 1e-9) / 1e12 / rl["peak"]
+        check = dict(frac_of_the_unprofiled_line=rl["frac"], frac_from_the_rocprof_average=frac_csv, ratio=frac_csv / rl["frac"],
+                     kernel_ms_hip_events=rl["kernel_ms"], kernel_ms_rocprof_average=stats_avg_ns * n / 1e6,
+                     ms_per_step_unprofiled=plain["ms_per_step"],
+                     note="units x flops / rocprof average / peak against the un-profiled line's frac: same lease, same library")
+    json.dump(dict(bench_line_under_rocprof=bench, bench_line_unprofiled_same_lease=plain, roofline_check=check,
+                   per_launch_counter_means=summary, k2_traffic=traffic,
                    effective_clock_ghz_under_profiling=clock, kernel_avg_ns_rocprof_stats=stats_avg_ns,
                    source_hash=traffic.get("source_hash") if traffic else None),
               open(os.path.join(out, "%s_%s_pmc.json" % (rnd, tag)), "w"), indent=1)
