@@ -9,7 +9,8 @@
 //     [0, NV)              in VGPRs, as register pairs (s, s+1) per channel
 //     [NV, NV + NA)        in AGPRs: one v_accvgpr_read_b32 per value and pass (VALU operands cannot name an AGPR)
 //     [NV + NA, .. + NL)   in LDS, [pair][channel][lane] as 8-byte pairs: one conflict-free ds_read_b64 per pair and channel
-//     the rest (S - NV - NA - NL samples, 1 at c5) re-gathered per pass, as the streaming kernel's tail is
+//     sample NV + NA + NL   in the three AGPRs the AGPR tier leaves over (c5: 64 + 84 + 52 = 200, and the 201st)
+//     the rest (none at c5) re-gathered per pass, as the streaming kernel's tail is
 // -- gathered ONCE per hypothesis.  A wave alone on its SIMD issues one instruction every ~5 clocks whatever it is
 // (tools/ubench_valu.hip), so the pass runs in packed fp32 on sample pairs: v_pk_add / v_pk_mul do two samples' work per
 // issue slot, each half the scalar instruction's IEEE operation (tools/ubench_pk.hip).  The two running sums still take
@@ -23,10 +24,12 @@
 
 namespace rslf {
 
-// samples per tier (all even: the pass works on pairs).  NV: 3 * NV VGPRs beside ~60 of working state; NA: 3 * NA <= 256
-// AGPRs; NL: what a quarter of the CU's LDS holds behind the wave's offset table.
+// samples per tier (all even: the pass works on pairs).  NV: 3 * NV VGPRs beside ~60 of working state (64: hipcc keeps a few
+// per-tile values in scratch, touched outside the pass loops; 60 left four samples of c5 to the per-pass tail and ran 7.6 %
+// slower, profiles/r03_k2_variants.md); NA: 3 * NA <= 256 AGPRs; NL: what a quarter of the CU's LDS holds behind the
+// wave's offset table.
 #ifndef RSLF_CHIP_NV
-#define RSLF_CHIP_NV 60
+#define RSLF_CHIP_NV 64
 #endif
 #ifndef RSLF_CHIP_NA
 #define RSLF_CHIP_NA 84

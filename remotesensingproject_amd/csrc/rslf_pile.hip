@@ -187,7 +187,7 @@ static ScanChoice choose_scan(const rslf_ctx* ctx, int S, int C, bool in_range, 
         c.spad = 0;
     }
     c.use_stream = !c.spad && c.stream_ok;
-    // more views than two waves per SIMD hold on chip (RGB, 196 views and up): one wave per SIMD with every sample at hand
+    // more views than two waves per SIMD hold on chip (RGB, 200 views and up): one wave per SIMD with every sample at hand
     c.use_chip = c.use_stream && dense_uniform && chip_takes(S, C) && ctx->force_scan != 2;
     if (c.use_chip)
         c.use_stream = false;
