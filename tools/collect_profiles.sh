@@ -20,14 +20,19 @@ pass() {  # name, rocprofv3 options...
   echo "pass $name rc=$rc" >> $OUT/progress.txt
   return $rc
 }
-timeout -k 5 ${PASS_TIMEOUT:-200} python3 $R/bench.py --steps ${PLAIN_STEPS:-10} --warmup 2 --no-cpu-baseline --no-e2e ${BENCH_ARGS:-} > $OUT/bench_plain.json 2> $OUT/bench_plain.err &&
-pass stats --stats && cp $OUT/bench_stats.json $OUT/bench_stats.json.keep &&
-pass pmc_fetch --pmc FETCH_SIZE &&
-pass pmc_write --pmc WRITE_SIZE &&
-pass pmc_sq --pmc SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_WAIT_INST_ANY &&
-pass pmc_sq2 --pmc SQ_INSTS_LDS SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM_RD SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE &&
-pass pmc_l2 --pmc TCC_HIT_sum TCC_MISS_sum &&
-pass pmc_ta --pmc TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum &&
-pass pmc_td --pmc TD_TD_BUSY_sum TD_TC_STALL_sum &&
-pass pmc_tcp --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum
+# PASSES: which of the passes to run (default: all).  The full-size c5 run takes minutes per pass: PASSES="stats pmc_fetch pmc_write pmc_sq"
+PASSES=${PASSES:-"stats pmc_fetch pmc_write pmc_sq pmc_sq2 pmc_l2 pmc_ta pmc_td pmc_tcp"}
+want() { case " $PASSES " in *" $1 "*) return 0;; esac; return 1; }
+timeout -k 5 ${PASS_TIMEOUT:-200} python3 $R/bench.py --steps ${PLAIN_STEPS:-10} --warmup 2 --no-cpu-baseline --no-e2e ${BENCH_ARGS:-} > $OUT/bench_plain.json 2> $OUT/bench_plain.err || { echo "plain bench failed"; tail -3 $OUT/bench_plain.err; exit 1; }
+run() { want $1 || return 0; pass "$@" || { echo "pass $1 failed"; tail -3 $OUT/bench_$1.err; exit 1; }; }
+run stats --stats
+[ -f $OUT/bench_stats.json ] && cp $OUT/bench_stats.json $OUT/bench_stats.json.keep
+run pmc_fetch --pmc FETCH_SIZE
+run pmc_write --pmc WRITE_SIZE
+run pmc_sq --pmc SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_WAIT_INST_ANY
+run pmc_sq2 --pmc SQ_INSTS_LDS SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM_RD SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE
+run pmc_l2 --pmc TCC_HIT_sum TCC_MISS_sum
+run pmc_ta --pmc TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum
+run pmc_td --pmc TD_TD_BUSY_sum TD_TC_STALL_sum
+run pmc_tcp --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum
 echo "profiles in $OUT: $(tail -1 $OUT/progress.txt)"
