@@ -23,6 +23,12 @@ namespace rslf {
 // the host (rslf_pile.hip: choose_scan).
 // ---------------------------------------------------------------------------
 // samples whose loads are in flight together (2 registers per sample and channel while they are)
+#ifndef RSLF_REG_GB104
+#define RSLF_REG_GB104 13   // loads in flight per gather round of the 104-slot (c3) kernel.  13 = eight rounds per hypothesis instead
+                            // of thirteen: 67.24 vs 67.85 ms on one box (profiles/r03_k2_variants.md) at the price of 20 B/lane of
+                            // scratch -- per-tile values (the pixel index, the centre texel's address) stored once per workgroup,
+                            // outside every loop: 0.27 GB of HBM writes per launch, 1.3x the algorithmic bytes.  8: no scratch.
+#endif
 constexpr int gather_batch(int c) { return c == 1 ? 8 : 4; }
 constexpr int kPadSlack = 16;     // compiled slot counts step by at most this: only the last kPadSlack slots can be padding
 
@@ -44,7 +50,7 @@ __device__ __forceinline__ void scan_reg_body(const ScanArgs& a, int v, int u, i
 {
     // 104 slots (the c3 shape) have 15 registers to spare at three waves per SIMD: 13 loads in flight instead of 8
     // (8 batches instead of 13 per hypothesis) measured 0.5 % faster
-    constexpr int kGatherBatch = GB > 0 ? GB : (C == 1 && !PK && SPAD == 104) ? 13 : gather_batch(C);
+    constexpr int kGatherBatch = GB > 0 ? GB : (C == 1 && !PK && SPAD == 104 && RSLF_REG_GB104 == 13) ? 13 : gather_batch(C);
     static_assert(SPAD % kGatherBatch == 0 && (!PK || kGatherBatch % 2 == 0), "whole batches, whole pairs");
     static_assert(SPAD % 8 == 0, "slot counts are multiples of 8");
     const VolView& vol = a.vol;
