@@ -37,6 +37,9 @@ namespace rslf {
 #ifndef RSLF_CHIP_NL
 #define RSLF_CHIP_NL 52
 #endif
+#ifndef RSLF_CHIP_PD
+#define RSLF_CHIP_PD 3
+#endif
 constexpr int kChipNV = RSLF_CHIP_NV, kChipNA = RSLF_CHIP_NA, kChipNL = RSLF_CHIP_NL;
 constexpr int kChipOnChip = kChipNV + kChipNA + kChipNL;
 constexpr size_t kChipLdsBytes = (size_t)160 << 10;   // one workgroup per CU takes all of it
@@ -120,7 +123,7 @@ struct ChipPK {
         [kx] "v"(p.K.x), [ky] "v"(p.K.y)
 
 // samples in VGPR pairs (the VGPR tier, and the LDS tier once its ds_read_b64 have landed)
-__device__ __forceinline__ ChipPK chip_pair(f2 r0, f2 r1, f2 r2, f2 m01, f2 m2x, f2 kq, const ChipPK& prev, float (&A)[3], float& B)
+__device__ __forceinline__ ChipPK chip_pair(f2 r0, f2 r1, f2 r2, f2 m01, f2 m2x, unsigned long long kq, const ChipPK& prev, float (&A)[3], float& B)
 {
     ChipPK n;
     f2 d0, d1, d2;
@@ -132,13 +135,13 @@ __device__ __forceinline__ ChipPK chip_pair(f2 r0, f2 r1, f2 r2, f2 m01, f2 m2x,
         "v_pk_mul_f32 %[t1], %[r1], %[k]\n\t"
         "v_pk_mul_f32 %[t2], %[r2], %[k]"
         : RSLF_CHIP_PAIR_OUTS(n)
-        : [r0] "v"(r0), [r1] "v"(r1), [r2] "v"(r2), [m01] "v"(m01), [m2x] "v"(m2x), [kq] "v"(kq), RSLF_CHIP_PAIR_PREV(prev));
+        : [r0] "v"(r0), [r1] "v"(r1), [r2] "v"(r2), [m01] "v"(m01), [m2x] "v"(m2x), [kq] "s"(kq), RSLF_CHIP_PAIR_PREV(prev));
     return n;
 }
 
 // samples in AGPRs: the six reads open the block (VALU operands cannot name an AGPR); they land in a fixed register
 // window, v[250:255], whose halves the asm can name -- an operand the compiler allocates is a whole pair to the asm.
-__device__ __forceinline__ ChipPK chip_pair_agpr(float a0x, float a0y, float a1x, float a1y, float a2x, float a2y, f2 m01, f2 m2x, f2 kq,
+__device__ __forceinline__ ChipPK chip_pair_agpr(float a0x, float a0y, float a1x, float a1y, float a2x, float a2y, f2 m01, f2 m2x, unsigned long long kq,
                                                  const ChipPK& prev, float (&A)[3], float& B)
 {
     ChipPK n;
@@ -158,13 +161,13 @@ __device__ __forceinline__ ChipPK chip_pair_agpr(float a0x, float a0y, float a1x
         "v_pk_mul_f32 %[t2], v[254:255], %[k]"
         : RSLF_CHIP_PAIR_OUTS(n)
         : [a0x] "a"(a0x), [a0y] "a"(a0y), [a1x] "a"(a1x), [a1y] "a"(a1y), [a2x] "a"(a2x), [a2y] "a"(a2y), [m01] "v"(m01), [m2x] "v"(m2x),
-          [kq] "v"(kq), RSLF_CHIP_PAIR_PREV(prev)
+          [kq] "s"(kq), RSLF_CHIP_PAIR_PREV(prev)
         : "v250", "v251", "v252", "v253", "v254", "v255");
     return n;
 }
 
 // one sample in AGPRs and a sentinel (1e30) for its partner
-__device__ __forceinline__ ChipPK chip_pair_agpr_single(float a0x, float a1x, float a2x, f2 m01, f2 m2x, f2 kq, const ChipPK& prev,
+__device__ __forceinline__ ChipPK chip_pair_agpr_single(float a0x, float a1x, float a2x, f2 m01, f2 m2x, unsigned long long kq, const ChipPK& prev,
                                                         float (&A)[3], float& B)
 {
     ChipPK n;
@@ -183,7 +186,7 @@ __device__ __forceinline__ ChipPK chip_pair_agpr_single(float a0x, float a1x, fl
         "v_pk_mul_f32 %[t1], v[252:253], %[k]\n\t"
         "v_pk_mul_f32 %[t2], v[254:255], %[k]"
         : RSLF_CHIP_PAIR_OUTS(n)
-        : [a0x] "a"(a0x), [a1x] "a"(a1x), [a2x] "a"(a2x), [m01] "v"(m01), [m2x] "v"(m2x), [kq] "v"(kq), RSLF_CHIP_PAIR_PREV(prev)
+        : [a0x] "a"(a0x), [a1x] "a"(a1x), [a2x] "a"(a2x), [m01] "v"(m01), [m2x] "v"(m2x), [kq] "s"(kq), RSLF_CHIP_PAIR_PREV(prev)
         : "v250", "v251", "v252", "v253", "v254", "v255");
     return n;
 }
@@ -212,19 +215,20 @@ __device__ __forceinline__ void scan_chip_body(const ScanArgs& a, int v, int u, 
 {
     constexpr int C = 3, NV = kChipNV, NA = kChipNA, NL = kChipNL, GB = 4;
     constexpr bool BORDER = !SHARED;
-    constexpr int PD = SHARED ? 3 : 2;   // batches of loads in flight + 1
+    constexpr int PD = SHARED ? RSLF_CHIP_PD : 2;   // batches of loads in flight + 1
     const VolView& vol = a.vol;
     const float* epi = vol.row(v, 0);
+    // Values every hypothesis needs but that cost one instruction to make are made per hypothesis: hipcc otherwise hoists
+    // them out of the loop into vector registers -- and, with 192 of the 256 holding samples, spills them, and every
+    // scratch store is a write that leaves the L2 (the wave's stores are written through).
     const float uf = (float)u;
     const unsigned Um1_bits = __float_as_uint((float)(vol.U - 1));
     const int S = vol.S;
     const int lane = threadIdx.x & 63;
-    const float range = a.dmax - a.dmin;
-    const float denom = (float)(a.dim_d - 1);
-    const float slope = a.k.slope;
-    const f2 kq2 = {a.k.inv_h2, a.k.inv_h2};
+    // kq for the packed multiplies: a scalar-register PAIR whose low half op_sel broadcasts (no vector registers held for it)
+    const unsigned long long kq2 = (unsigned long long)__float_as_uint(a.k.inv_h2);
     const unsigned stride_b = (unsigned)vol.stride_s << 2;
-    const float* centre_p = epi + (long long)a.s_hat * vol.stride_s + u * C;
+    const unsigned centre_off = ((unsigned)(a.s_hat * (int)vol.stride_s) + (unsigned)(u * C)) << 2;   // 32-bit: one EPI is < 2 GiB
     // LDS tier: [pair][channel][lane] as f2 behind the offset table
     f2* park = reinterpret_cast<f2*>(otab + ((S + 3) & ~3)) + lane;
 
@@ -267,7 +271,12 @@ __device__ __forceinline__ void scan_chip_body(const ScanArgs& a, int v, int u, 
 
 #pragma unroll 1
     for (int d = d0; d < d1; d++) {
-        const float Dd = hypothesis(a.dmin, range, denom, d);
+        float dmin_s = a.dmin, dmax_s = a.dmax, slope = a.k.slope;
+        int dim_s = a.dim_d;
+        asm volatile("" : "+s"(dmin_s), "+s"(dmax_s), "+s"(slope), "+s"(dim_s));   // opaque: re-derived here, not hoisted
+        const float range = dmax_s - dmin_s;
+        const float denom = (float)(dim_s - 1);
+        const float Dd = hypothesis(dmin_s, range, denom, d);
         for (int s = lane; s < S; s += 64) {
             float off = (float)(a.s_hat - s) * Dd;   // core.hpp:542,550
             off = off * slope;                       // core.hpp:551
@@ -363,7 +372,7 @@ __device__ __forceinline__ void scan_chip_body(const ScanArgs& a, int v, int u, 
         float rbar[C];
 #pragma unroll
         for (int c = 0; c < C; c++)
-            rbar[c] = centre_p[c];                   // core.hpp:577: R[s_hat] = E[s_hat][u] exactly (re-read: L1 / L2)
+            rbar[c] = ((const float*)((const char*)epi + centre_off))[c];   // core.hpp:577: R[s_hat] = E[s_hat][u] exactly (re-read: L1 / L2)
         float B = 0.0f;
         int ncard = card;
 #pragma unroll 1

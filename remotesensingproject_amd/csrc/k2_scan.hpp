@@ -62,7 +62,7 @@ struct ScanArgs {
     // wave's walk over its hypotheses): each workgroup leaves a partial record and the last one to finish merges
     // them in hypothesis order (scan_epilogue / combine_tile).
     int groups;
-    struct Partial* partial;   // [tile][group][64]
+    struct Partial* partial;   // records of grouped launches: [tile * groups + group][word 0..7][lane 0..63] (word-major)
     int* ticket;               // [tile], zero between launches: the group that draws the last ticket merges the tile
     int v0;                    // row tiles: first scanline of this launch (grouped dense launches go by row blocks)
     // Packed tiles (sparse launches): `list` is ONE list of pixel indices v*U + u over all scanlines,
@@ -82,6 +82,9 @@ struct ScanArgs {
     float stream_frac_max;
 };
 
+// Laid out WORD-major in memory ([item][word][lane], record_word): a wave's store of one word is then 256 contiguous bytes.
+// Lane-major 32-byte structs made every dword store touch sixteen 128-byte lines in part, and the write-through (sc1) stores
+// left the L2 as sector writes: 274 MB of HBM writes per c2 launch for 33.5 MB of records (profiles/r03_c2_n1_pmc.json).
 struct Partial {   // one lane's merged result over one group's hypotheses
     float score, D;
     int d;
@@ -271,6 +274,8 @@ __device__ __forceinline__ unsigned load_coherent(const unsigned* p)
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+constexpr int kRecordWords = 8;
+
 template <int C>
 __device__ __forceinline__ void combine_tile(const ScanArgs& a, int tile, int v, int u);
 
@@ -348,17 +353,17 @@ __device__ __forceinline__ void scan_epilogue(const ScanArgs& a, int lb, int v, 
         // written with agent-scope atomic stores (sc1: through to the memory side), the wave waits for them to complete
         // (s_waitcnt vmcnt(0)) before lane 0 draws the ticket, and the group that draws the last one reads the records
         // with agent-scope atomic loads (sc1: past the caches), which its branch on the ticket orders after the draw.
-        unsigned* w = reinterpret_cast<unsigned*>(a.partial + ((long long)lb * 64 + lane));
-        static_assert(sizeof(Partial) == 32, "eight words per record");
+        unsigned* w = reinterpret_cast<unsigned*>(a.partial) + ((long long)lb * kRecordWords * 64 + lane);   // word k at w[k * 64]
+        static_assert(sizeof(Partial) == 4 * kRecordWords, "eight words per record");
         const unsigned long long sb = (unsigned long long)__double_as_longlong(sum);
-        store_coherent(w + 0, __float_as_uint(best));
-        store_coherent(w + 1, __float_as_uint(best_D));
-        store_coherent(w + 2, (unsigned)best_d);
+        store_coherent(w + 0 * 64, __float_as_uint(best));
+        store_coherent(w + 1 * 64, __float_as_uint(best_D));
+        store_coherent(w + 2 * 64, (unsigned)best_d);
 #pragma unroll
-        for (int c = 0; c < 3; c++)
-            store_coherent(w + 3 + c, c < C ? __float_as_uint(best_rbar[c < C ? c : 0]) : 0u);
-        store_coherent(w + 6, (unsigned)sb);
-        store_coherent(w + 7, (unsigned)(sb >> 32));
+        for (int c = 0; c < C; c++)   // (one-channel records leave words 4 and 5 unwritten: nobody reads them)
+            store_coherent(w + (3 + c) * 64, __float_as_uint(best_rbar[c]));
+        store_coherent(w + 6 * 64, (unsigned)sb);
+        store_coherent(w + 7 * 64, (unsigned)(sb >> 32));
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (a workgroup-scope release fence emits nothing here)
         const int tile = lb / a.groups;
         int drawn = 0;
@@ -382,7 +387,7 @@ __device__ __forceinline__ void scan_epilogue(const ScanArgs& a, int lb, int v, 
 template <int C>
 __device__ __forceinline__ void combine_tile(const ScanArgs& a, int tile, int v, int u)
 {
-    const unsigned* pr = reinterpret_cast<const unsigned*>(a.partial + (long long)tile * a.groups * 64 + (threadIdx.x & 63));
+    const unsigned* pr = reinterpret_cast<const unsigned*>(a.partial) + ((long long)tile * a.groups * kRecordWords * 64 + (threadIdx.x & 63));
     float best = -1.0f, best_D = 0.0f;
     int best_d = -1;
     float best_rbar[C];
@@ -392,7 +397,7 @@ __device__ __forceinline__ void combine_tile(const ScanArgs& a, int tile, int v,
     double sum = 0.0;
     // eight groups' records at a time, every word's load issued before the first is used: the loads go past the caches
     // (a round trip to memory each), and this wave is the last thing its tile waits for
-    constexpr int GB = 8, W = sizeof(Partial) / sizeof(unsigned);
+    constexpr int GB = 8, W = kRecordWords;
     for (int g0 = 0; g0 < a.groups; g0 += GB) {
         unsigned w[GB][W];
 #pragma unroll
@@ -401,7 +406,7 @@ __device__ __forceinline__ void combine_tile(const ScanArgs& a, int tile, int v,
 #pragma unroll
             for (int k = 0; k < W; k++)
                 if (k < 3 + C || k >= 6)
-                    w[j][k] = load_coherent(q + k);
+                    w[j][k] = load_coherent(q + k * 64);
         }
 #pragma unroll
         for (int j = 0; j < GB; j++) {
