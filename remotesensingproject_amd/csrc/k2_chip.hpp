@@ -71,16 +71,22 @@ struct ChipUnroll<N, N> {
     static __device__ __forceinline__ void run(F&) {}
 };
 
+// Three AGPRs hold a lane's running score sum (a double) and best score (ChipBest, below) behind the register allocator's
+// back: they are named outright there, and listed as clobbered by every statement that takes or returns an "a" operand,
+// so no operand of this file is ever placed in them (hipcc itself touches AGPRs here only to hold such operands: with
+// every AGPR live it spilled an allocator-managed value of this kind once per hypothesis).
+#define RSLF_CHIP_KEEP_REGS "a253", "a254", "a255"
+
 __device__ __forceinline__ float agpr_put(float v)
 {
     float a;
-    asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(a) : "v"(v));
+    asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(a) : "v"(v) : RSLF_CHIP_KEEP_REGS);
     return a;
 }
 __device__ __forceinline__ float agpr_get(float a)
 {
     float v;
-    asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(a));
+    asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(a) : RSLF_CHIP_KEEP_REGS);
     return v;
 }
 
@@ -162,32 +168,7 @@ __device__ __forceinline__ ChipPK chip_pair_agpr(float a0x, float a0y, float a1x
         : RSLF_CHIP_PAIR_OUTS(n)
         : [a0x] "a"(a0x), [a0y] "a"(a0y), [a1x] "a"(a1x), [a1y] "a"(a1y), [a2x] "a"(a2x), [a2y] "a"(a2y), [m01] "v"(m01), [m2x] "v"(m2x),
           [kq] "s"(kq), RSLF_CHIP_PAIR_PREV(prev)
-        : "v250", "v251", "v252", "v253", "v254", "v255");
-    return n;
-}
-
-// one sample in AGPRs and a sentinel (1e30) for its partner
-__device__ __forceinline__ ChipPK chip_pair_agpr_single(float a0x, float a1x, float a2x, f2 m01, f2 m2x, unsigned long long kq, const ChipPK& prev,
-                                                        float (&A)[3], float& B)
-{
-    ChipPK n;
-    f2 d0, d1, d2;
-    asm("v_accvgpr_read_b32 v250, %[a0x]\n\t"
-        "v_mov_b32 v251, 0x7149f2ca\n\t"
-        "v_accvgpr_read_b32 v252, %[a1x]\n\t"
-        "v_mov_b32 v253, 0x7149f2ca\n\t"
-        "v_accvgpr_read_b32 v254, %[a2x]\n\t"
-        "v_mov_b32 v255, 0x7149f2ca\n\t"
-        "v_pk_add_f32 %[d0], v[250:251], %[m01] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
-        "v_pk_add_f32 %[d1], v[252:253], %[m01] op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
-        "v_pk_add_f32 %[d2], v[254:255], %[m2x] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
-        RSLF_CHIP_PAIR_MID
-        "v_pk_mul_f32 %[t0], v[250:251], %[k]\n\t"
-        "v_pk_mul_f32 %[t1], v[252:253], %[k]\n\t"
-        "v_pk_mul_f32 %[t2], v[254:255], %[k]"
-        : RSLF_CHIP_PAIR_OUTS(n)
-        : [a0x] "a"(a0x), [a1x] "a"(a1x), [a2x] "a"(a2x), [m01] "v"(m01), [m2x] "v"(m2x), [kq] "s"(kq), RSLF_CHIP_PAIR_PREV(prev)
-        : "v250", "v251", "v252", "v253", "v254", "v255");
+        : "v250", "v251", "v252", "v253", "v254", "v255", RSLF_CHIP_KEEP_REGS);
     return n;
 }
 
@@ -204,6 +185,70 @@ __device__ __forceinline__ void chip_flush(const ChipPK& p, float (&A)[3], float
     B = B + p.K.y;
 }
 
+// A wave's running result over its hypotheses, kept OUT of the allocator's vector registers.  With 192 of the 256
+// holding samples hipcc spilled Best (eight values per lane) to scratch and wrote it back after every hypothesis: 32 bytes
+// per lane and hypothesis, 4.3 GB of HBM writes per 64 scanlines of c5 against 0.64 GB of algorithmic traffic -- every
+// store leaves the L2.  What every hypothesis touches -- the double sum of the scores (cv::mean, core.hpp:641) and the best
+// score -- sits in RSLF_CHIP_KEEP_REGS; the index and rbar live in scratch ON PURPOSE (four words behind a pointer the
+// optimiser cannot see through, or it would promote them back into registers) and are WRITTEN only where a lane's best
+// improves (core.hpp:636-645: strictly greater, the first maximum wins).  Same operations in the same order as Best<3>.
+struct ChipBest {
+    float* slot;   // index (bits), rbar[3]
+    __device__ __forceinline__ void init(float* four)
+    {
+        four[0] = __int_as_float(0);
+        four[1] = four[2] = four[3] = 0.0f;
+        asm volatile("" : "+s"(four) : : "memory");
+        slot = four;
+        asm volatile("v_accvgpr_write_b32 a253, 0\n\t"
+                     "v_accvgpr_write_b32 a254, 0\n\t"
+                     "v_accvgpr_write_b32 a255, -1.0"
+                     :
+                     :
+                     : RSLF_CHIP_KEEP_REGS);
+    }
+    __device__ __forceinline__ void offer(float sc, int d, const float (&rb)[3])
+    {
+        unsigned lo, hi;
+        float cur;
+        asm volatile("v_accvgpr_read_b32 %0, a253\n\t"
+                     "v_accvgpr_read_b32 %1, a254\n\t"
+                     "v_accvgpr_read_b32 %2, a255"
+                     : "=&v"(lo), "=&v"(hi), "=&v"(cur)
+                     :
+                     : RSLF_CHIP_KEEP_REGS);
+        const double sum = __hiloint2double((int)hi, (int)lo) + (double)sc;
+        asm volatile("v_accvgpr_write_b32 a253, %0\n\t"
+                     "v_accvgpr_write_b32 a254, %1"
+                     :
+                     : "v"(__double2loint(sum)), "v"(__double2hiint(sum))
+                     : RSLF_CHIP_KEEP_REGS);
+        if (sc > cur) {
+            asm volatile("v_accvgpr_write_b32 a255, %0" : : "v"(sc) : RSLF_CHIP_KEEP_REGS);
+            slot[0] = __int_as_float(d);
+            slot[1] = rb[0];
+            slot[2] = rb[1];
+            slot[3] = rb[2];
+        }
+    }
+    __device__ __forceinline__ void finish(const ScanArgs& a, Best<3>& b) const
+    {
+        unsigned lo, hi;
+        asm volatile("v_accvgpr_read_b32 %0, a253\n\t"
+                     "v_accvgpr_read_b32 %1, a254\n\t"
+                     "v_accvgpr_read_b32 %2, a255"
+                     : "=&v"(lo), "=&v"(hi), "=&v"(b.score)
+                     :
+                     : RSLF_CHIP_KEEP_REGS);
+        b.sum = __hiloint2double((int)hi, (int)lo);
+        b.d = __float_as_int(slot[0]);
+        b.D = hypothesis(a.dmin, a.dmax - a.dmin, (float)(a.dim_d - 1), b.d);   // the scan's own operations (core.hpp:545-548)
+        b.rbar[0] = slot[1];
+        b.rbar[1] = slot[2];
+        b.rbar[2] = slot[3];
+    }
+};
+
 // SHARED = false: the general form -- every lane loads both taps of a sample (16 + 8 bytes) and tests the sample's validity
 // (interp.hpp:182).  SHARED = true: lanes 0..62 hold 63 consecutive pixels, lane 63 stands on the pixel after them, every
 // sample line of every lane stays inside the row and all lanes floor alike (scan_chip_rows): a lane's right tap is its
@@ -211,7 +256,7 @@ __device__ __forceinline__ void chip_flush(const ChipPK& p, float (&A)[3], float
 // and with 4 registers per sample in flight instead of 7 the gather runs TWO batches ahead of its blends -- a wave alone on
 // its SIMD has nobody to hide an L2 round trip behind (the general form, one batch ahead, waits a third of its gather).
 template <bool SHARED>
-__device__ __forceinline__ void scan_chip_body(const ScanArgs& a, int v, int u, int d0, int d1, Best<3>& best, float* __restrict__ otab)
+__device__ __forceinline__ void scan_chip_body(const ScanArgs& a, int v, int u, int d0, int d1, ChipBest& best, float* __restrict__ otab)
 {
     constexpr int C = 3, NV = kChipNV, NA = kChipNA, NL = kChipNL, GB = 4;
     constexpr bool BORDER = !SHARED;
@@ -287,7 +332,6 @@ __device__ __forceinline__ void scan_chip_body(const ScanArgs& a, int v, int u, 
 
         f2 Rv[C][NV / 2];
         float Ra[C][NA];
-        float Rx[C];   // the sample behind the tiers (s = NV + NA + NL; c5's 201st), in the three AGPRs the AGPR tier leaves over
         unsigned rowb = 0;
         asm volatile("" : "+s"(rowb));
         // ---- gather, once per hypothesis: batches of four samples, software-pipelined -- the eight loads of batch g + 1
@@ -318,9 +362,6 @@ __device__ __forceinline__ void scan_chip_body(const ScanArgs& a, int v, int u, 
                     taps(xo[nxt][j], rowb, e0[nxt][j], e1[nxt][j], tt[nxt][j], ok[nxt][j]);
                     rowb += stride_b;
                 }
-            } else if (g + PD - 1 == NB) {
-                // the sample behind the tiers rides in the last batches' shadow (S == NO: its slot will hold the sentinel)
-                taps(S > NO ? xo[nxt][0] : 0.0f, S > NO ? rowb : 0u, e0[nxt][0], e1[nxt][0], tt[nxt][0], ok[nxt][0]);
             }
             if (g + PD <= NB)
                 xo[cur] = *(const f4v*)(otab + (g + PD) * GB);     // batch g + PD's offsets take the place of batch g's
@@ -358,16 +399,12 @@ __device__ __forceinline__ void scan_chip_body(const ScanArgs& a, int v, int u, 
             asm volatile("" : "+s"(rowb), "+v"(card));
         };
         ChipUnroll<0, NB>::run(batch);
-        {
-            float r[C];
-            blend(e0[NB % PD][0], e1[NB % PD][0], tt[NB % PD][0], ok[NB % PD][0], r);
-            const bool have = S > NO;   // wave-uniform
-            if (BORDER)
-                card += (have && ok[NB % PD][0]) ? 1 : 0;
-#pragma unroll
-            for (int c = 0; c < C; c++)
-                Rx[c] = agpr_put(have ? r[c] : kSentinel);
-        }
+        // The sample behind the tiers (s = NO; c5's 201st) has no place to stay -- registers, AGPRs and LDS are full to the
+        // word -- so every pass fetches it again (an L1 / L2 hit), but AHEAD: its loads go out as the pass begins and its
+        // blend follows the last tier, a hundred blocks later (the ragged tail below waits for each of its loads instead).
+        const bool have = S > NO;   // wave-uniform
+        const float xoff_x = have ? otab[NO] : 0.0f;
+        const unsigned rowb_x = have ? (unsigned)NO * stride_b : 0u;
 
         float rbar[C];
 #pragma unroll
@@ -382,6 +419,10 @@ __device__ __forceinline__ void scan_chip_body(const ScanArgs& a, int v, int u, 
             const f2 m01 = {rbar[0], rbar[1]}, m2x = {rbar[2], rbar[2]};
             ChipPK pk;
             pk.P0 = pk.P1 = pk.P2 = pk.K = f2{0.0f, 0.0f};
+            float xe0[C], xe1[C], xtt;
+            bool xok;
+            taps(xoff_x, rowb_x, xe0, xe1, xtt, xok);
+            __builtin_amdgcn_sched_barrier(0);
             // VGPR tier
 #pragma unroll
             for (int p = 0; p < NV / 2; p++)
@@ -410,11 +451,20 @@ __device__ __forceinline__ void scan_chip_body(const ScanArgs& a, int v, int u, 
                 pk = chip_pair(q[cur][0], q[cur][1], q[cur][2], m01, m2x, kq2, pk, A, B);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            // the sample behind the tiers, paired with a sentinel (K = 0, P = 0 exactly)
-            pk = chip_pair_agpr_single(Rx[0], Rx[1], Rx[2], m01, m2x, kq2, pk, A, B);
+            // the sample behind the tiers, paired with a sentinel (K = 0, P = 0 exactly; so is a missing one: S == NO)
+            {
+                float rx[C];
+                blend(xe0, xe1, xtt, xok, rx);
+#pragma unroll
+                for (int c = 0; c < C; c++)
+                    rx[c] = have ? rx[c] : kSentinel;
+                pk = chip_pair(f2{rx[0], kSentinel}, f2{rx[1], kSentinel}, f2{rx[2], kSentinel}, m01, m2x, kq2, pk, A, B);
+            }
             chip_flush(pk, A, B);
-            // what nothing holds: re-gathered on every pass, one sample at a time (none at c5)
             ncard = card;
+            if (BORDER)
+                ncard += (have && xok) ? 1 : 0;
+            // what is left: re-gathered on every pass, one sample at a time (none at c5)
 #pragma unroll 1
             for (int s = NO + 1; s < S; s++) {
                 float e0[C], e1[C], tt, r[C], q[C];
@@ -448,7 +498,7 @@ __device__ __forceinline__ void scan_chip_body(const ScanArgs& a, int v, int u, 
         const float cardf = (float)ncard;
         float sc = (ncard != 0) ? (B / cardf) : 0.0f;   // core.hpp:616-620: the last pass's sum of K
         sc = (sc > 0.0f) ? sc : 0.0f;                   // core.hpp:622
-        best.offer(sc, d, Dd, rbar);
+        best.offer(sc, d, rbar);
     }
 }
 
@@ -457,8 +507,11 @@ __device__ __forceinline__ void scan_chip_body(const ScanArgs& a, int v, int u, 
 // inside the row for every lane (two pixels of margin, which covers lane 63's extra pixel), and view offsets none of whose
 // fractions is within an ulp of 1 (positions are offset + integer u: the lanes then all floor alike).  Runs of
 // hypotheses of one kind go to one body call, in ascending order: first maximum wins (core.hpp:636-645).
-__device__ __forceinline__ void scan_chip_rows(const ScanArgs& a, int v, int u, bool active, int d0, int d1, Best<3>& best, float* otab)
+__device__ __forceinline__ void scan_chip_rows(const ScanArgs& a, int v, int u, bool active, int d0, int d1, Best<3>& result, float* otab)
 {
+    float four[4];
+    ChipBest best;
+    best.init(four);
     const int S = a.vol.S;
     const int ln = threadIdx.x & 63;
     const int u0 = __builtin_amdgcn_readfirstlane(u), u62 = __builtin_amdgcn_readlane(u, 62);
@@ -498,6 +551,7 @@ __device__ __forceinline__ void scan_chip_rows(const ScanArgs& a, int v, int u, 
             scan_chip_body<false>(a, v, u, d, e, best, otab);
         d = e;
     }
+    best.finish(a, result);
 }
 
 __global__ __launch_bounds__(64 * kScanWaves) __attribute__((amdgpu_waves_per_eu(1, 1))) void k2_scan_chip(ScanArgs a)
