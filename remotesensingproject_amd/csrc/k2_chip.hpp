@@ -5,16 +5,19 @@
 // unit's 201 RGB samples, and the other 109 are re-gathered on each of the ten mean-shift passes -- 34 vector
 // instructions and a 12-byte L1 read per sample and pass against 19 for a sample that is at hand; three quarters of
 // its time.  Here a wave has its SIMD to itself: 512 registers (the unified file: 256 VGPRs + 256 AGPRs) and a quarter
-// of the CU's 160 KiB of LDS hold EVERY sample of a unit --
-//     [0, NV)              in VGPRs, as register pairs (s, s+1) per channel
-//     [NV, NV + NA)        in AGPRs: one v_accvgpr_read_b32 per value and pass (VALU operands cannot name an AGPR)
-//     [NV + NA, .. + NL)   in LDS, [pair][channel][lane] as 8-byte pairs: one conflict-free ds_read_b64 per pair and channel
-//     sample NV + NA + NL   in the three AGPRs the AGPR tier leaves over (c5: 64 + 84 + 52 = 200, and the 201st)
-//     the rest (none at c5) re-gathered per pass, as the streaming kernel's tail is
-// -- gathered ONCE per hypothesis.  A wave alone on its SIMD issues one instruction every ~5 clocks whatever it is
-// (tools/ubench_valu.hip), so the pass runs in packed fp32 on sample pairs: v_pk_add / v_pk_mul do two samples' work per
-// issue slot, each half the scalar instruction's IEEE operation (tools/ubench_pk.hip).  The two running sums still take
-// one sample at a time in ascending s (core.hpp:602-603).  No scratch: the kernel's HBM traffic is the slab read once.
+// of the CU's 160 KiB of LDS hold all but three samples of a unit -- in the order a pass walks them,
+//     views [0, NV)               in VGPRs, as register pairs (s, s+1) per channel
+//     [NV, NV + NA)               in AGPRs, laid out by hand: one v_accvgpr_read_b32 per value and pass (VALU operands cannot name an AGPR)
+//     the next three              fetched AGAIN on every pass (L1 / L2 hits), their loads issued a tier ahead of their use
+//     [NV + NA + 3, .. + NL)      in LDS, [pair][channel][lane] as 8-byte pairs: one conflict-free ds_read_b64 per pair and channel
+//     the rest (none at c5: 64 + 84 + 3 + 50 = 201) re-gathered per pass one by one, as the streaming kernel's tail is
+// -- the 198 gathered ONCE per hypothesis.  (The chip is full to the word: 201 x 3 samples + the wave's running result
+// -- a double sum and the best score in three AGPRs, the best index and rbar in LDS -- is what 192 + 256 registers and
+// 157 words of LDS per lane hold, less two samples.)  A wave alone on its SIMD issues one instruction every ~5 clocks
+// whatever it is (tools/ubench_valu.hip), so the pass runs in packed fp32 on sample pairs: v_pk_add / v_pk_mul do two
+// samples' work per issue slot, each half the scalar instruction's IEEE operation (tools/ubench_pk.hip).  The two running
+// sums still take one sample at a time in ascending s (core.hpp:602-603).  No scratch, and nothing written but the
+// workgroup's record: the kernel's HBM traffic is the slab read once plus 2 KB per (tile, group).
 //
 // Dense row-tile launches with one hypothesis grid for all pixels only (no per-pixel [dmin, dmax] planes, no packed
 // lists): everything else stays with the streaming kernel.
@@ -24,10 +27,9 @@
 
 namespace rslf {
 
-// samples per tier (all even: the pass works on pairs).  NV: 3 * NV VGPRs beside ~60 of working state (64: hipcc keeps a few
-// per-tile values in scratch, touched outside the pass loops; 60 left four samples of c5 to the per-pass tail and ran 7.6 %
-// slower, profiles/r03_k2_variants.md); NA: 3 * NA <= 256 AGPRs; NL: what a quarter of the CU's LDS holds behind the
-// wave's offset table.
+// samples per tier (all even: the pass works on pairs).  NV: 3 * NV VGPRs beside ~60 of working state (60 left four more
+// samples of c5 to per-pass fetches and ran 7.6 % slower, profiles/r03_k2_variants.md); NA: 3 * NA + 3 <= 256 AGPRs;
+// NL: what a quarter of the CU's LDS holds behind the wave's offset table and before its running best.
 #ifndef RSLF_CHIP_NV
 #define RSLF_CHIP_NV 64
 #endif
@@ -35,23 +37,26 @@ namespace rslf {
 #define RSLF_CHIP_NA 84
 #endif
 #ifndef RSLF_CHIP_NL
-#define RSLF_CHIP_NL 52
+#define RSLF_CHIP_NL 50
 #endif
 #ifndef RSLF_CHIP_PD
 #define RSLF_CHIP_PD 3
 #endif
 constexpr int kChipNV = RSLF_CHIP_NV, kChipNA = RSLF_CHIP_NA, kChipNL = RSLF_CHIP_NL;
-constexpr int kChipOnChip = kChipNV + kChipNA + kChipNL;
-constexpr size_t kChipLdsBytes = (size_t)160 << 10;   // one workgroup per CU takes all of it
-static_assert(kChipNV % 4 == 0 && kChipNA % 4 == 0 && kChipNL % 4 == 0, "gather batches of four samples, pairs in the pass");
-static_assert(3 * kChipNA <= 256, "AGPR tier");
+constexpr int kChipOnChip = kChipNV + kChipNA + kChipNL;   // samples that stay on the chip for a hypothesis
+constexpr int kChipAhead = 3;                              // samples fetched again on every pass, ahead of their use
+constexpr int kChipMinS = kChipOnChip + kChipAhead;
+constexpr int kChipBestFloats = 4 * 64;                    // a wave's running index and rbar (ChipBest)
+constexpr size_t kChipLdsBytes = (size_t)160 << 10;        // one workgroup per CU takes all of it
+static_assert(kChipNV % 4 == 0 && kChipNA % 4 == 0 && kChipNL % 2 == 0, "gather batches of four samples, pairs in the pass");
+static_assert(3 * kChipNA + 3 <= 256, "AGPR tier and the three named registers");
 
-// floats of dynamic LDS per wave: [view offsets, S rounded up to 4][NL samples x 3 channels x 64 lanes]
-__host__ __device__ constexpr int chip_wave_floats(int S) { return ((S + 3) & ~3) + kChipNL * 3 * 64; }
-// the kernel takes volumes whose on-chip tiers are all in use and whose per-wave LDS share fits
+// floats of dynamic LDS per wave: [view offsets, S rounded up to 4][NL samples x 3 channels x 64 lanes][running best, 4 x 64]
+__host__ __device__ constexpr int chip_wave_floats(int S) { return ((S + 3) & ~3) + kChipNL * 3 * 64 + kChipBestFloats; }
+// the kernel takes volumes whose on-chip tiers and fetched-ahead slots are all in use and whose per-wave LDS share fits
 __host__ __device__ constexpr bool chip_takes(int S, int C)
 {
-    return C == 3 && S >= kChipOnChip && (size_t)chip_wave_floats(S) * 4 * kScanWaves <= kChipLdsBytes;
+    return C == 3 && S >= kChipMinS && (size_t)chip_wave_floats(S) * 4 * kScanWaves <= kChipLdsBytes;
 }
 
 // f(integral_constant<int, G>) for G = 0 .. N-1, in order: a loop unrolled by the type system -- `#pragma unroll` leaves the
@@ -71,23 +76,34 @@ struct ChipUnroll<N, N> {
     static __device__ __forceinline__ void run(F&) {}
 };
 
-// Three AGPRs hold a lane's running score sum (a double) and best score (ChipBest, below) behind the register allocator's
-// back: they are named outright there, and listed as clobbered by every statement that takes or returns an "a" operand,
-// so no operand of this file is ever placed in them (hipcc itself touches AGPRs here only to hold such operands: with
-// every AGPR live it spilled an allocator-managed value of this kind once per hypothesis).
-#define RSLF_CHIP_KEEP_REGS "a253", "a254", "a255"
+// The 256 AGPRs are laid out BY HAND: sample i of the AGPR tier has its channels in a[3i .. 3i + 2], a253:a254 hold a
+// lane's running score sum (a double) and a255 its best score (ChipBest, below).  The register numbers are template
+// constants printed into the instruction text ("a%c[n]"), and every statement that touches one lists ALL of them as
+// clobbered, so hipcc keeps nothing of its own there.  (Left to the allocator as "a"-constrained values, 252 + 3 of 256
+// was more than it could colour: it spilled an AGPR value per hypothesis in one build and five in the next.)
+#define RSLF_CHIP_AGPRS \
+    "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", \
+    "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", \
+    "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", \
+    "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", \
+    "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", \
+    "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", \
+    "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", \
+    "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127", \
+    "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", \
+    "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159", \
+    "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175", \
+    "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191", \
+    "a192", "a193", "a194", "a195", "a196", "a197", "a198", "a199", "a200", "a201", "a202", "a203", "a204", "a205", "a206", "a207", \
+    "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219", "a220", "a221", "a222", "a223", \
+    "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239", \
+    "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255"
 
-__device__ __forceinline__ float agpr_put(float v)
+template <int R>
+__device__ __forceinline__ void agpr_put(float v)
 {
-    float a;
-    asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(a) : "v"(v) : RSLF_CHIP_KEEP_REGS);
-    return a;
-}
-__device__ __forceinline__ float agpr_get(float a)
-{
-    float v;
-    asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(a) : RSLF_CHIP_KEEP_REGS);
-    return v;
+    static_assert(R >= 0 && R < 3 * kChipNA, "an AGPR-tier register");
+    asm volatile("v_accvgpr_write_b32 a%c1, %0" : : "v"(v), "n"(R) : RSLF_CHIP_AGPRS);
 }
 
 // One pair of samples (s, s+1) of one RGB pass in packed fp32: per channel delta = R - rbar, t = kq * delta,
@@ -145,30 +161,32 @@ __device__ __forceinline__ ChipPK chip_pair(f2 r0, f2 r1, f2 r2, f2 m01, f2 m2x,
     return n;
 }
 
-// samples in AGPRs: the six reads open the block (VALU operands cannot name an AGPR); they land in a fixed register
-// window, v[250:255], whose halves the asm can name -- an operand the compiler allocates is a whole pair to the asm.
-__device__ __forceinline__ ChipPK chip_pair_agpr(float a0x, float a0y, float a1x, float a1y, float a2x, float a2y, f2 m01, f2 m2x, unsigned long long kq,
-                                                 const ChipPK& prev, float (&A)[3], float& B)
+// samples in AGPRs (pair P of the tier: a[6P .. 6P + 5]): the six reads open the block (VALU operands cannot name an AGPR);
+// they land in a fixed register window, v[250:255], whose halves the asm can name -- an operand the compiler allocates is
+// a whole pair to the asm.
+template <int P>
+__device__ __forceinline__ ChipPK chip_pair_agpr(f2 m01, f2 m2x, unsigned long long kq, const ChipPK& prev, float (&A)[3], float& B)
 {
+    static_assert(P >= 0 && 2 * P + 1 < kChipNA, "a pair of the AGPR tier");
     ChipPK n;
     f2 d0, d1, d2;
-    asm("v_accvgpr_read_b32 v250, %[a0x]\n\t"
-        "v_accvgpr_read_b32 v251, %[a0y]\n\t"
-        "v_accvgpr_read_b32 v252, %[a1x]\n\t"
-        "v_accvgpr_read_b32 v253, %[a1y]\n\t"
-        "v_accvgpr_read_b32 v254, %[a2x]\n\t"
-        "v_accvgpr_read_b32 v255, %[a2y]\n\t"
-        "v_pk_add_f32 %[d0], v[250:251], %[m01] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
-        "v_pk_add_f32 %[d1], v[252:253], %[m01] op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
-        "v_pk_add_f32 %[d2], v[254:255], %[m2x] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
-        RSLF_CHIP_PAIR_MID
-        "v_pk_mul_f32 %[t0], v[250:251], %[k]\n\t"
-        "v_pk_mul_f32 %[t1], v[252:253], %[k]\n\t"
-        "v_pk_mul_f32 %[t2], v[254:255], %[k]"
-        : RSLF_CHIP_PAIR_OUTS(n)
-        : [a0x] "a"(a0x), [a0y] "a"(a0y), [a1x] "a"(a1x), [a1y] "a"(a1y), [a2x] "a"(a2x), [a2y] "a"(a2y), [m01] "v"(m01), [m2x] "v"(m2x),
-          [kq] "s"(kq), RSLF_CHIP_PAIR_PREV(prev)
-        : "v250", "v251", "v252", "v253", "v254", "v255", RSLF_CHIP_KEEP_REGS);
+    asm volatile("v_accvgpr_read_b32 v250, a%c[a0x]\n\t"
+                 "v_accvgpr_read_b32 v251, a%c[a0y]\n\t"
+                 "v_accvgpr_read_b32 v252, a%c[a1x]\n\t"
+                 "v_accvgpr_read_b32 v253, a%c[a1y]\n\t"
+                 "v_accvgpr_read_b32 v254, a%c[a2x]\n\t"
+                 "v_accvgpr_read_b32 v255, a%c[a2y]\n\t"
+                 "v_pk_add_f32 %[d0], v[250:251], %[m01] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+                 "v_pk_add_f32 %[d1], v[252:253], %[m01] op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+                 "v_pk_add_f32 %[d2], v[254:255], %[m2x] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+                 RSLF_CHIP_PAIR_MID
+                 "v_pk_mul_f32 %[t0], v[250:251], %[k]\n\t"
+                 "v_pk_mul_f32 %[t1], v[252:253], %[k]\n\t"
+                 "v_pk_mul_f32 %[t2], v[254:255], %[k]"
+                 : RSLF_CHIP_PAIR_OUTS(n)
+                 : [a0x] "n"(6 * P), [a1x] "n"(6 * P + 1), [a2x] "n"(6 * P + 2), [a0y] "n"(6 * P + 3), [a1y] "n"(6 * P + 4), [a2y] "n"(6 * P + 5),
+                   [m01] "v"(m01), [m2x] "v"(m2x), [kq] "s"(kq), RSLF_CHIP_PAIR_PREV(prev)
+                 : "v250", "v251", "v252", "v253", "v254", "v255", RSLF_CHIP_AGPRS);
     return n;
 }
 
@@ -185,27 +203,50 @@ __device__ __forceinline__ void chip_flush(const ChipPK& p, float (&A)[3], float
     B = B + p.K.y;
 }
 
+// NOTHING a lane owns is carried through a hypothesis by the compiler's choice: with 192 of the 256 registers holding
+// samples, every per-lane value that lives across the gather and the passes -- the pixel's column, its float, its byte
+// offset, the lane's LDS addresses -- was spilled once per workgroup and re-read once per hypothesis (84 bytes of scratch
+// per lane; dirty scratch lines pushed out of the L2 by the streaming reads were a third of the kernel's HBM writes).
+// So a tile is known by wave-UNIFORM values only (scalar registers), and what a lane needs is made again where it is
+// used: its number from v_mbcnt (an asm the optimiser cannot hoist or merge), its pixel from the scanline's list
+// (K1's output, an L2 hit) -- or, on a dense tile, first pixel + lane.
+__device__ __forceinline__ int chip_lane()
+{
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\t"
+                 "v_mbcnt_hi_u32_b32 %0, -1, %0"
+                 : "=v"(l));
+    return l;
+}
+struct ChipTile {
+    const int* row;   // the scanline's pixel list
+    int e0, last;     // the tile's first entry; the last entry it may read (idle lanes shadow it, scan_tile)
+    int u0;           // the first entry's pixel
+    __device__ __forceinline__ int pixel(int lane) const { return row[min(e0 + lane, last)]; }
+};
+
 // A wave's running result over its hypotheses, kept OUT of the allocator's vector registers.  With 192 of the 256
 // holding samples hipcc spilled Best (eight values per lane) to scratch and wrote it back after every hypothesis: 32 bytes
 // per lane and hypothesis, 4.3 GB of HBM writes per 64 scanlines of c5 against 0.64 GB of algorithmic traffic -- every
-// store leaves the L2.  What every hypothesis touches -- the double sum of the scores (cv::mean, core.hpp:641) and the best
-// score -- sits in RSLF_CHIP_KEEP_REGS; the index and rbar live in scratch ON PURPOSE (four words behind a pointer the
-// optimiser cannot see through, or it would promote them back into registers) and are WRITTEN only where a lane's best
-// improves (core.hpp:636-645: strictly greater, the first maximum wins).  Same operations in the same order as Best<3>.
+// store leaves the L2.  (Index and rbar in scratch by hand, written only where a lane's best improves, still wrote
+// 1.1 GB: scores rise smoothly towards a pixel's disparity, so half the hypotheses improve on their predecessor.)
+// What every hypothesis touches -- the double sum of the scores (cv::mean, core.hpp:641) and the best score -- sits in
+// a253:a254 and a255; index and rbar sit in LDS, [4][64] behind the wave's sample tier, which gave up two samples for
+// them (kChipAhead).  Same operations in the same order as Best<3> (core.hpp:636-645: strictly greater, first maximum).
 struct ChipBest {
-    float* slot;   // index (bits), rbar[3]
-    __device__ __forceinline__ void init(float* four)
+    float* wave_blk;   // [index (bits), rbar0, rbar1, rbar2][64 lanes]
+    __device__ __forceinline__ void init(float* wave_block)
     {
-        four[0] = __int_as_float(0);
-        four[1] = four[2] = four[3] = 0.0f;
-        asm volatile("" : "+s"(four) : : "memory");
-        slot = four;
+        wave_blk = wave_block;
+        float* blk = wave_blk + chip_lane();
+        blk[0] = __int_as_float(0);
+        blk[64] = blk[128] = blk[192] = 0.0f;
         asm volatile("v_accvgpr_write_b32 a253, 0\n\t"
                      "v_accvgpr_write_b32 a254, 0\n\t"
                      "v_accvgpr_write_b32 a255, -1.0"
                      :
                      :
-                     : RSLF_CHIP_KEEP_REGS);
+                     : RSLF_CHIP_AGPRS);
     }
     __device__ __forceinline__ void offer(float sc, int d, const float (&rb)[3])
     {
@@ -216,19 +257,20 @@ struct ChipBest {
                      "v_accvgpr_read_b32 %2, a255"
                      : "=&v"(lo), "=&v"(hi), "=&v"(cur)
                      :
-                     : RSLF_CHIP_KEEP_REGS);
+                     : RSLF_CHIP_AGPRS);
         const double sum = __hiloint2double((int)hi, (int)lo) + (double)sc;
         asm volatile("v_accvgpr_write_b32 a253, %0\n\t"
                      "v_accvgpr_write_b32 a254, %1"
                      :
                      : "v"(__double2loint(sum)), "v"(__double2hiint(sum))
-                     : RSLF_CHIP_KEEP_REGS);
+                     : RSLF_CHIP_AGPRS);
         if (sc > cur) {
-            asm volatile("v_accvgpr_write_b32 a255, %0" : : "v"(sc) : RSLF_CHIP_KEEP_REGS);
-            slot[0] = __int_as_float(d);
-            slot[1] = rb[0];
-            slot[2] = rb[1];
-            slot[3] = rb[2];
+            asm volatile("v_accvgpr_write_b32 a255, %0" : : "v"(sc) : RSLF_CHIP_AGPRS);
+            float* blk = wave_blk + chip_lane();
+            blk[0] = __int_as_float(d);
+            blk[64] = rb[0];
+            blk[128] = rb[1];
+            blk[192] = rb[2];
         }
     }
     __device__ __forceinline__ void finish(const ScanArgs& a, Best<3>& b) const
@@ -239,13 +281,14 @@ struct ChipBest {
                      "v_accvgpr_read_b32 %2, a255"
                      : "=&v"(lo), "=&v"(hi), "=&v"(b.score)
                      :
-                     : RSLF_CHIP_KEEP_REGS);
+                     : RSLF_CHIP_AGPRS);
         b.sum = __hiloint2double((int)hi, (int)lo);
-        b.d = __float_as_int(slot[0]);
+        const float* blk = wave_blk + chip_lane();
+        b.d = __float_as_int(blk[0]);
         b.D = hypothesis(a.dmin, a.dmax - a.dmin, (float)(a.dim_d - 1), b.d);   // the scan's own operations (core.hpp:545-548)
-        b.rbar[0] = slot[1];
-        b.rbar[1] = slot[2];
-        b.rbar[2] = slot[3];
+        b.rbar[0] = blk[64];
+        b.rbar[1] = blk[128];
+        b.rbar[2] = blk[192];
     }
 };
 
@@ -256,23 +299,28 @@ struct ChipBest {
 // and with 4 registers per sample in flight instead of 7 the gather runs TWO batches ahead of its blends -- a wave alone on
 // its SIMD has nobody to hide an L2 round trip behind (the general form, one batch ahead, waits a third of its gather).
 template <bool SHARED>
-__device__ __forceinline__ void scan_chip_body(const ScanArgs& a, int v, int u, int d0, int d1, ChipBest& best, float* __restrict__ otab)
+__device__ __forceinline__ void scan_chip_body(const ScanArgs& a, int v, const ChipTile& t, int d0, int d1, ChipBest& best, float* __restrict__ otab)
 {
     constexpr int C = 3, NV = kChipNV, NA = kChipNA, NL = kChipNL, GB = 4;
+    constexpr int NO = NV + NA + NL, NB = (NO + GB - 1) / GB;   // on-chip samples; gather batches (the last may be half full)
     constexpr bool BORDER = !SHARED;
     constexpr int PD = SHARED ? RSLF_CHIP_PD : 2;   // batches of loads in flight + 1
     const VolView& vol = a.vol;
     const float* epi = vol.row(v, 0);
-    // Values every hypothesis needs but that cost one instruction to make are made per hypothesis: hipcc otherwise hoists
-    // them out of the loop into vector registers -- and, with 192 of the 256 holding samples, spills them, and every
-    // scratch store is a write that leaves the L2 (the wave's stores are written through).
-    const float uf = (float)u;
+    // Values every hypothesis needs but that cost an instruction or two to make are made per hypothesis: hipcc otherwise
+    // hoists them out of the loop into vector registers and spills them (ChipTile, above).
     const unsigned Um1_bits = __float_as_uint((float)(vol.U - 1));
     const int S = vol.S;
-    const int lane = threadIdx.x & 63;
     // kq for the packed multiplies: a scalar-register PAIR whose low half op_sel broadcasts (no vector registers held for it)
     const unsigned long long kq2 = (unsigned long long)__float_as_uint(a.k.inv_h2);
-    const unsigned stride_b = (unsigned)vol.stride_s << 2;
+
+#pragma unroll 1
+    for (int d = d0; d < d1; d++) {
+    unsigned stride_b = (unsigned)vol.stride_s << 2;
+    asm volatile("" : "+s"(stride_b));   // (its multiples are made where they are used, not carried in scalar registers)
+    const int lane = chip_lane();
+    const int u = SHARED ? t.u0 + lane : t.pixel(lane);   // (dense tiles: lanes 0..62 consecutive, lane 63 on the pixel after them)
+    const float uf = (float)u;
     const unsigned centre_off = ((unsigned)(a.s_hat * (int)vol.stride_s) + (unsigned)(u * C)) << 2;   // 32-bit: one EPI is < 2 GiB
     // LDS tier: [pair][channel][lane] as f2 behind the offset table
     f2* park = reinterpret_cast<f2*>(otab + ((S + 3) & ~3)) + lane;
@@ -314,8 +362,7 @@ __device__ __forceinline__ void scan_chip_body(const ScanArgs& a, int v, int u, 
         }
     };
 
-#pragma unroll 1
-    for (int d = d0; d < d1; d++) {
+    {
         float dmin_s = a.dmin, dmax_s = a.dmax, slope = a.k.slope;
         int dim_s = a.dim_d;
         asm volatile("" : "+s"(dmin_s), "+s"(dmax_s), "+s"(slope), "+s"(dim_s));   // opaque: re-derived here, not hoisted
@@ -325,24 +372,34 @@ __device__ __forceinline__ void scan_chip_body(const ScanArgs& a, int v, int u, 
         for (int s = lane; s < S; s += 64) {
             float off = (float)(a.s_hat - s) * Dd;   // core.hpp:542,550
             off = off * slope;                       // core.hpp:551
-            otab[s] = off;
+            // the table is in the order of USE: the on-chip samples as the gather walks them (LDS tier, AGPR tier, VGPR
+            // tier), then the three fetched ahead, then the ragged tail
+            const int pos = s < NV                        ? NL + NA + s
+                            : s < NV + NA                 ? NL + (s - NV)
+                            : s < NV + NA + kChipAhead    ? NO + (s - NV - NA)
+                            : s < NO + kChipAhead         ? s - NV - NA - kChipAhead
+                                                          : s;
+            otab[pos] = off;
         }
         __builtin_amdgcn_wave_barrier();
         int card = BORDER ? 0 : S;
 
         f2 Rv[C][NV / 2];
-        float Ra[C][NA];
-        unsigned rowb = 0;
-        asm volatile("" : "+s"(rowb));
-        // ---- gather, once per hypothesis: batches of four samples, software-pipelined -- the eight loads of batch g + 1
+        // ---- gather, once per hypothesis: batches of four samples, software-pipelined -- the loads of the batches to come
         // are issued before batch g is blended, because a wave alone on its SIMD has nobody to hide an L2 round trip
         // behind (PMC on the first version: a quarter of the wave's cycles spent in s_waitcnt).  Fully unrolled: the
-        // two buffers alternate by the parity of a compile-time index, so nothing is copied.
-        constexpr int NB = (NV + NA + NL) / GB, NO = NV + NA + NL;
+        // buffers rotate by a compile-time index, so nothing is copied.  The VGPR tier is gathered LAST: until then its 192
+        // registers are free, and as they fill up the loads in flight run out -- gathered first, the tier kept the file
+        // full for two thirds of the gather and hipcc spilled four of its registers once per hypothesis.
+        // (The AGPR tier stays in the middle: gathered first, hipcc spills five of ITS values.)
+        // gather index i: [0, NL) LDS tier (views NV + NA + 3 ..), [NL, NL + NA) AGPR tier (views NV ..), then the VGPR tier
+        unsigned rowb = (unsigned)(NV + NA + kChipAhead) * stride_b;
+        asm volatile("" : "+s"(rowb));
         typedef float f4v __attribute__((ext_vector_type(4)));
         float e0[PD][GB][C], e1[PD][GB][C], tt[PD][GB];
         bool ok[PD][GB];
         f4v xo[PD];   // the offsets of a batch, read a batch before its loads are issued (the table is padded to a multiple of 4)
+        static_assert((RSLF_CHIP_PD - 1) * GB <= NL && NL % 2 == 0 && (NA + NL) % 2 == 0, "prologue inside the LDS tier; pairs do not straddle tiers");
 #pragma unroll
         for (int b = 0; b < PD; b++)
             xo[b] = *(const f4v*)(otab + b * GB);
@@ -359,53 +416,70 @@ __device__ __forceinline__ void scan_chip_body(const ScanArgs& a, int v, int u, 
             if (g + PD - 1 < NB) {
 #pragma unroll
                 for (int j = 0; j < GB; j++) {
-                    taps(xo[nxt][j], rowb, e0[nxt][j], e1[nxt][j], tt[nxt][j], ok[nxt][j]);
-                    rowb += stride_b;
+                    const int i = (g + PD - 1) * GB + j;
+                    if (i < NO) {
+                        if (i == NL)
+                            rowb = (unsigned)NV * stride_b;   // (the views fetched ahead on every pass are not gathered here)
+                        if (i == NL + NA)
+                            rowb = 0;
+                        taps(xo[nxt][j], rowb, e0[nxt][j], e1[nxt][j], tt[nxt][j], ok[nxt][j]);
+                        rowb += stride_b;
+                    }
                 }
             }
-            if (g + PD <= NB)
+            if (g + PD < NB)
                 xo[cur] = *(const f4v*)(otab + (g + PD) * GB);     // batch g + PD's offsets take the place of batch g's
             float r[GB][C];
 #pragma unroll
             for (int j = 0; j < GB; j++) {
-                blend(e0[cur][j], e1[cur][j], tt[cur][j], ok[cur][j], r[j]);
-                if (BORDER)
-                    card += ok[cur][j] ? 1 : 0;
+                if (g * GB + j < NO) {
+                    blend(e0[cur][j], e1[cur][j], tt[cur][j], ok[cur][j], r[j]);
+                    if (BORDER)
+                        card += ok[cur][j] ? 1 : 0;
+                }
             }
 #pragma unroll
             for (int j = 0; j < GB; j++) {
-                const int s = g * GB + j;
+                const int i = g * GB + j;
 #pragma unroll
                 for (int c = 0; c < C; c++) {
-                    if (s < NV) {
-                        if (s & 1)
-                            Rv[c][s >> 1].y = r[j][c];
-                        else
-                            Rv[c][s >> 1].x = r[j][c];
-                    } else if (s < NV + NA) {
-                        Ra[c][s - NV] = agpr_put(r[j][c]);
-                    } else if ((j & 1) == 0) {
-                        park[(((s - NV - NA) >> 1) * C + c) * 64] = f2{r[j][c], r[j + 1][c]};   // pairs go out as 8-byte stores
+                    if (i >= NO) {
+                    } else if (i < NL) {
+                        if ((j & 1) == 0)
+                            park[((i >> 1) * C + c) * 64] = f2{r[j][c], r[j + 1][c]};   // pairs go out as 8-byte stores
+                    } else if (i < NL + NA) {
+                        // (below: the register number must be a constant expression)
+                    } else if ((i - NA - NL) & 1) {
+                        Rv[c][(i - NA - NL) >> 1].y = r[j][c];
+                    } else {
+                        Rv[c][(i - NA - NL) >> 1].x = r[j][c];
                     }
                 }
             }
+            auto to_agpr = [&](auto kc) {
+                constexpr int k = decltype(kc)::value, j = k / C, c = k % C, i = g * GB + j;
+                if constexpr (i >= NL && i < NL + NA)
+                    agpr_put<(i - NL) * C + c>(r[j][c]);
+            };
+            ChipUnroll<0, GB * C>::run(to_agpr);
             // pin the batch: its values exist here, and the address state of the batches to come is opaque -- else hipcc
             // turns the unrolled gather into "all loads, then all blends" and parks the texels in scratch (k2_reg.hpp)
-            if (g * GB < NV) {
 #pragma unroll
-                for (int c = 0; c < C; c++)
-                    asm volatile("" : "+v"(Rv[c][g * GB / 2]), "+v"(Rv[c][g * GB / 2 + 1]));
+            for (int j = 0; j < GB; j += 2) {
+                const int i = g * GB + j;
+                if (i >= NA + NL && i < NO) {
+#pragma unroll
+                    for (int c = 0; c < C; c++)
+                        asm volatile("" : "+v"(Rv[c][(i - NA - NL) >> 1]));
+                }
             }
             asm volatile("" : "+s"(rowb), "+v"(card));
         };
         ChipUnroll<0, NB>::run(batch);
-        // The sample behind the tiers (s = NO; c5's 201st) has no place to stay -- registers, AGPRs and LDS are full to the
-        // word -- so every pass fetches it again (an L1 / L2 hit), but AHEAD: its loads go out as the pass begins and its
-        // blend follows the last tier, a hundred blocks later (the ragged tail below waits for each of its loads instead).
-        const bool have = S > NO;   // wave-uniform
-        const float xoff_x = have ? otab[NO] : 0.0f;
-        const unsigned rowb_x = have ? (unsigned)NO * stride_b : 0u;
-
+        // Three samples (views NV + NA .. + 2) have no place to stay -- registers, AGPRs and LDS are full to the word, and
+        // the running best needs a corner of LDS -- so every pass fetches them again (L1 / L2 hits), but AHEAD: their
+        // loads go out before the AGPR tier's 42 blocks and their blends follow it (the ragged tail below waits for each
+        // of its loads instead).
         float rbar[C];
 #pragma unroll
         for (int c = 0; c < C; c++)
@@ -419,19 +493,29 @@ __device__ __forceinline__ void scan_chip_body(const ScanArgs& a, int v, int u, 
             const f2 m01 = {rbar[0], rbar[1]}, m2x = {rbar[2], rbar[2]};
             ChipPK pk;
             pk.P0 = pk.P1 = pk.P2 = pk.K = f2{0.0f, 0.0f};
-            float xe0[C], xe1[C], xtt;
-            bool xok;
-            taps(xoff_x, rowb_x, xe0, xe1, xtt, xok);
-            __builtin_amdgcn_sched_barrier(0);
             // VGPR tier
 #pragma unroll
             for (int p = 0; p < NV / 2; p++)
                 pk = chip_pair(Rv[0][p], Rv[1][p], Rv[2][p], m01, m2x, kq2, pk, A, B);
-            // AGPR tier
+            float xe0[kChipAhead][C], xe1[kChipAhead][C], xtt[kChipAhead];
+            bool xok[kChipAhead];
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int p = 0; p < NA / 2; p++)
-                pk = chip_pair_agpr(Ra[0][2 * p], Ra[0][2 * p + 1], Ra[1][2 * p], Ra[1][2 * p + 1], Ra[2][2 * p], Ra[2][2 * p + 1], m01, m2x,
-                                    kq2, pk, A, B);
+            for (int k = 0; k < kChipAhead; k++)
+                taps(otab[NO + k], (unsigned)(NV + NA + k) * stride_b, xe0[k], xe1[k], xtt[k], xok[k]);
+            __builtin_amdgcn_sched_barrier(0);
+            // AGPR tier
+            auto agpr_pair = [&](auto pc) { pk = chip_pair_agpr<decltype(pc)::value>(m01, m2x, kq2, pk, A, B); };
+            ChipUnroll<0, NA / 2>::run(agpr_pair);
+            // the three fetched ahead: a pair, and one with a sentinel for its partner (K = 0, P = 0 exactly)
+            {
+                float rx[kChipAhead][C];
+#pragma unroll
+                for (int k = 0; k < kChipAhead; k++)
+                    blend(xe0[k], xe1[k], xtt[k], xok[k], rx[k]);
+                pk = chip_pair(f2{rx[0][0], rx[1][0]}, f2{rx[0][1], rx[1][1]}, f2{rx[0][2], rx[1][2]}, m01, m2x, kq2, pk, A, B);
+                pk = chip_pair(f2{rx[2][0], kSentinel}, f2{rx[2][1], kSentinel}, f2{rx[2][2], kSentinel}, m01, m2x, kq2, pk, A, B);
+            }
             // LDS tier, fully unrolled (immediate offsets): the three ds_read_b64 of pair p + 1 are issued before pair p's
             // block, which then covers their latency
             f2 q[2][C];
@@ -451,22 +535,16 @@ __device__ __forceinline__ void scan_chip_body(const ScanArgs& a, int v, int u, 
                 pk = chip_pair(q[cur][0], q[cur][1], q[cur][2], m01, m2x, kq2, pk, A, B);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            // the sample behind the tiers, paired with a sentinel (K = 0, P = 0 exactly; so is a missing one: S == NO)
-            {
-                float rx[C];
-                blend(xe0, xe1, xtt, xok, rx);
-#pragma unroll
-                for (int c = 0; c < C; c++)
-                    rx[c] = have ? rx[c] : kSentinel;
-                pk = chip_pair(f2{rx[0], kSentinel}, f2{rx[1], kSentinel}, f2{rx[2], kSentinel}, m01, m2x, kq2, pk, A, B);
-            }
             chip_flush(pk, A, B);
             ncard = card;
-            if (BORDER)
-                ncard += (have && xok) ? 1 : 0;
+            if (BORDER) {
+#pragma unroll
+                for (int k = 0; k < kChipAhead; k++)
+                    ncard += xok[k] ? 1 : 0;
+            }
             // what is left: re-gathered on every pass, one sample at a time (none at c5)
 #pragma unroll 1
-            for (int s = NO + 1; s < S; s++) {
+            for (int s = NO + kChipAhead; s < S; s++) {
                 float e0[C], e1[C], tt, r[C], q[C];
                 bool ok;
                 taps(otab[s], (unsigned)s * stride_b, e0, e1, tt, ok);
@@ -500,6 +578,7 @@ __device__ __forceinline__ void scan_chip_body(const ScanArgs& a, int v, int u, 
         sc = (sc > 0.0f) ? sc : 0.0f;                   // core.hpp:622
         best.offer(sc, d, rbar);
     }
+    }
 }
 
 // Which form a hypothesis takes is decided per HYPOTHESIS (as scan_stream_rows does): the shared-tap form needs a dense
@@ -507,34 +586,47 @@ __device__ __forceinline__ void scan_chip_body(const ScanArgs& a, int v, int u, 
 // inside the row for every lane (two pixels of margin, which covers lane 63's extra pixel), and view offsets none of whose
 // fractions is within an ulp of 1 (positions are offset + integer u: the lanes then all floor alike).  Runs of
 // hypotheses of one kind go to one body call, in ascending order: first maximum wins (core.hpp:636-645).
-__device__ __forceinline__ void scan_chip_rows(const ScanArgs& a, int v, int u, bool active, int d0, int d1, Best<3>& result, float* otab)
+__device__ __forceinline__ void scan_chip_rows(const ScanArgs& a, int v, int e0, int width, int n, int d0, int d1, Best<3>& result, float* otab)
 {
-    float four[4];
     ChipBest best;
-    best.init(four);
+    best.init(otab + ((a.vol.S + 3) & ~3) + kChipNL * 3 * 64);
     const int S = a.vol.S;
-    const int ln = threadIdx.x & 63;
-    const int u0 = __builtin_amdgcn_readfirstlane(u), u62 = __builtin_amdgcn_readlane(u, 62);
-    // (every lane is compared, not just the ends: a short or gappy list can span 62 pixels too -- idle lanes shadow the last entry)
-    const bool consecutive = __all(ln > 62 || u == u0 + ln);
-    // (a row's last tile may hold a 64th entry, scan_tile: lane 63 is then a pixel of its own and cannot lend itself out)
-    const bool lane63_free = !__any(ln == 63 && active);
-    const bool dense = a.tile_w == 63 && consecutive && lane63_free;
-    const int ud = (ln == 63) ? u62 + 1 : u;
-    const float max_ds = (float)max(a.s_hat, S - 1 - a.s_hat);
-    const float range = a.dmax - a.dmin, denom = (float)(a.dim_d - 1);
-    const float uf = (float)u, Um1 = (float)(a.vol.U - 1);
+    ChipTile t;
+    t.row = a.list + (long long)v * a.vol.U;
+    t.e0 = e0;
+    t.last = min(e0 + width, n) - 1;
+    bool dense;
+    {
+        const int ln = chip_lane();
+        const int u = t.pixel(ln);
+        const bool active = ln < width && e0 + ln < n;   // scan_tile
+        const int u0 = __builtin_amdgcn_readfirstlane(u);
+        t.u0 = u0;
+        // (every lane is compared, not just the ends: a short or gappy list can span 62 pixels too -- idle lanes shadow the last entry)
+        const bool consecutive = __all(ln > 62 || u == u0 + ln);
+        // (a row's last tile may hold a 64th entry, scan_tile: lane 63 is then a pixel of its own and cannot lend itself out)
+        const bool lane63_free = !__any(ln == 63 && active);
+        dense = a.tile_w == 63 && consecutive && lane63_free;
+    }
+    // (uniform FLOATS are made in the vector ALU and would be carried in vector registers: they are made per call, from
+    // scalars the optimiser cannot see through)
     auto shared_form = [&](int d) -> bool {
         if (!dense)
             return false;
-        const float Dd = hypothesis(a.dmin, range, denom, d);
-        const float reach = max_ds * fabsf(Dd) * fabsf(a.k.slope) + 2.0f;
+        float dmin_s = a.dmin, dmax_s = a.dmax, slope_s = a.k.slope;
+        int dim_s = a.dim_d, reach_s = max(a.s_hat, S - 1 - a.s_hat), last_s = a.vol.U - 1;
+        asm volatile("" : "+s"(dmin_s), "+s"(dmax_s), "+s"(slope_s), "+s"(dim_s), "+s"(reach_s), "+s"(last_s));
+        const float max_ds = (float)reach_s, Um1 = (float)last_s;
+        const float Dd = hypothesis(dmin_s, dmax_s - dmin_s, (float)(dim_s - 1), d);
+        const float reach = max_ds * fabsf(Dd) * fabsf(slope_s) + 2.0f;
+        const int ln = chip_lane();
+        const float uf = (float)min(t.u0 + ln, t.u0 + 62);   // dense: lanes 0..62 hold u0 .. u0 + 62 (lane 63's extra pixel is within the margin)
         if (!__all((uf - reach >= 0.0f) && (uf + reach <= Um1)))
             return false;
         bool odd = false;
         for (int s = ln; s < S; s += 64) {
             float off = (float)(a.s_hat - s) * Dd;   // core.hpp:542,550 -- the very operations the body's table holds
-            off = off * a.k.slope;                   // core.hpp:551
+            off = off * slope_s;                     // core.hpp:551
             odd |= __builtin_amdgcn_fractf(off) > a.stream_frac_max;
         }
         return !__any(odd);
@@ -546,23 +638,47 @@ __device__ __forceinline__ void scan_chip_rows(const ScanArgs& a, int v, int u, 
         while (e < d1 && shared_form(e) == sh)
             e++;
         if (sh)
-            scan_chip_body<true>(a, v, ud, d, e, best, otab);
+            scan_chip_body<true>(a, v, t, d, e, best, otab);
         else
-            scan_chip_body<false>(a, v, u, d, e, best, otab);
+            scan_chip_body<false>(a, v, t, d, e, best, otab);
         d = e;
     }
     best.finish(a, result);
+}
+
+// scan_chunk with the wave's number handed in
+__device__ __forceinline__ void chip_chunk(const ScanArgs& a, int group, int wave, int& d0, int& d1)
+{
+    const int slices = kScanWaves * a.groups;
+    const int chunk = (a.dim_d + slices - 1) / slices;
+    d0 = min((group * kScanWaves + wave) * chunk, a.dim_d);
+    d1 = min(d0 + chunk, a.dim_d);
 }
 
 __global__ __launch_bounds__(64 * kScanWaves) __attribute__((amdgpu_waves_per_eu(1, 1))) void k2_scan_chip(ScanArgs a)
 {
     constexpr int C = 3;
     extern __shared__ __attribute__((aligned(16))) float s_chip_lds[];   // [kScanWaves][stream_wave_floats]
-    float* otab = s_chip_lds + (size_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * a.stream_wave_floats;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (a scalar: threadIdx.x itself is not kept)
+    float* otab = s_chip_lds + (size_t)wave * a.stream_wave_floats;
     constexpr bool kEpiDyn = true;   // the waves' results for the epilogue go to the head of their own regions
     float* const epi_lds = otab;
     const int epi_stride = a.stream_wave_floats;
-    RSLF_SCAN_ROW_TILE((scan_chip_rows(a, v, u, active, d0, d1, best, otab)))
+    // RSLF_SCAN_ROW_TILE, with the tile's per-lane state (pixel, active) derived AGAIN after the scan instead of carried
+    // through it (ChipTile): `lb` is made opaque in between, so the second derivation is not merged with the first
+    Best<C> best;
+    int v, d0, d1, e0, width, n;
+    int lb = xcd_logical_block(blockIdx.x, a.per_xcd);
+    if (!scan_tile_span(a, lb, v, e0, width, n))
+        return;
+    chip_chunk(a, lb % a.groups, wave, d0, d1);
+    scan_chip_rows(a, v, e0, width, n, d0, d1, best, otab);
+    asm volatile("" : "+s"(lb));
+    int u;
+    bool active;
+    const int lane = chip_lane();
+    scan_tile(a, lb, v, u, active, lane);
+    scan_epilogue<C, kEpiDyn>(a, lb, v, u, active, best, epi_lds, epi_stride, lane, wave);
 }
 
 }  // namespace rslf

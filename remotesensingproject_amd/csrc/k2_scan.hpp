@@ -175,21 +175,21 @@ struct BestLds {
 // Which tile does this workgroup own, which pixel this lane?  Block-uniform result
 // (every wave of the block takes the same branch, so the later barrier is safe).
 // `lb` = tile * groups + group.
-__device__ __forceinline__ bool scan_tile(const ScanArgs& a, int lb, int& v, int& u, bool& active)
+// (the uniform part: scanline, the tile's first entry, its width, the scanline's count)
+__device__ __forceinline__ bool scan_tile_span(const ScanArgs& a, int lb, int& v, int& e0, int& width, int& n)
 {
-    const int lane = threadIdx.x & 63;
     if (lb >= a.logical_blocks)
         return false;
     const int tile = lb / a.groups;
     const int vr = tile / a.tiles_per_row;
     const int j = tile - vr * a.tiles_per_row;
     v = vr + a.v0;
-    const int n = a.count[v];
+    n = a.count[v];
     if (j * a.tile_w >= n)
         return false;
     // 63-entry tiles (streaming kernel, lane 63 left to the shared taps): the row's LAST tile takes up to 64 entries, so
     // that a row of 63 k + 1 pixels (4096 = 65 * 63 + 1) does not end in a tile of one
-    int width = a.tile_w;
+    width = a.tile_w;
     if (a.tile_w == 63) {
         const int T = max(1, (n + 61) / 63);      // tiles of this row: 63 entries each, the last one 1..64
         if (j >= T)
@@ -197,10 +197,19 @@ __device__ __forceinline__ bool scan_tile(const ScanArgs& a, int lb, int& v, int
         if (j == T - 1)
             width = n - 63 * j;
     }
-    const int e = j * a.tile_w + lane;
+    e0 = j * a.tile_w;
+    return true;
+}
+// (`lane`, and `wave` below: a kernel that cannot afford to keep threadIdx.x alive hands in its own -- k2_chip.hpp)
+__device__ __forceinline__ bool scan_tile(const ScanArgs& a, int lb, int& v, int& u, bool& active, int lane = threadIdx.x & 63)
+{
+    int e0, width, n;
+    if (!scan_tile_span(a, lb, v, e0, width, n))
+        return false;
+    const int e = e0 + lane;
     active = lane < width && e < n;
     // idle lanes shadow the tile's last pixel so their addresses stay valid
-    u = a.list[(long long)v * a.vol.U + (active ? e : min(j * a.tile_w + width, n) - 1)];
+    u = a.list[(long long)v * a.vol.U + (active ? e : min(e0 + width, n) - 1)];
     return true;
 }
 
@@ -277,7 +286,7 @@ __device__ __forceinline__ unsigned load_coherent(const unsigned* p)
 constexpr int kRecordWords = 8;
 
 template <int C>
-__device__ __forceinline__ void combine_tile(const ScanArgs& a, int tile, int v, int u);
+__device__ __forceinline__ void combine_tile(const ScanArgs& a, int tile, int v, int u, int lane);
 
 // Merge the waves' partial results in hypothesis order (first maximum wins, cv::minMaxLoc) and either
 // write the pixel (groups == 1) or leave this group's record -- the last group to finish merges the records.
@@ -297,10 +306,10 @@ struct EpilogueBlock {
 
 template <int C, bool DYN = false>
 __device__ __forceinline__ void scan_epilogue(const ScanArgs& a, int lb, int v, int u, bool active, const Best<C>& mine,
-                                              float* wave_lds = nullptr, int wave_stride = 0)
+                                              float* wave_lds = nullptr, int wave_stride = 0, int lane = threadIdx.x & 63,
+                                              int wave = threadIdx.x >> 6)
 {
     __shared__ double s_static[DYN ? 1 : kScanWaves][DYN ? 1 : EpilogueBlock<C>::kDoubles];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     auto block_of = [&](int w) {
         return EpilogueBlock<C>(DYN ? reinterpret_cast<double*>(wave_lds + (long long)(w - wave) * wave_stride) : s_static[DYN ? 0 : w]);
     };
@@ -374,7 +383,7 @@ __device__ __forceinline__ void scan_epilogue(const ScanArgs& a, int lb, int v, 
             return;
         asm volatile("" ::: "memory");
         if (active)
-            combine_tile<C>(a, tile, v, u);
+            combine_tile<C>(a, tile, v, u, lane);
         if (lane == 0)
             a.ticket[tile] = 0;   // clean for the next launch (kernel boundary orders it)
         return;
@@ -385,9 +394,9 @@ __device__ __forceinline__ void scan_epilogue(const ScanArgs& a, int lb, int v, 
 
 // groups > 1: the wave that drew the tile's last ticket merges the groups' records in hypothesis order and writes the pixels.
 template <int C>
-__device__ __forceinline__ void combine_tile(const ScanArgs& a, int tile, int v, int u)
+__device__ __forceinline__ void combine_tile(const ScanArgs& a, int tile, int v, int u, int lane)
 {
-    const unsigned* pr = reinterpret_cast<const unsigned*>(a.partial) + ((long long)tile * a.groups * kRecordWords * 64 + (threadIdx.x & 63));
+    const unsigned* pr = reinterpret_cast<const unsigned*>(a.partial) + ((long long)tile * a.groups * kRecordWords * 64 + lane);
     float best = -1.0f, best_D = 0.0f;
     int best_d = -1;
     float best_rbar[C];

@@ -37,6 +37,7 @@ constexpr size_t kAutoGroupBudget = (size_t)96 << 20;              // ... of whi
 constexpr int kPackedItemTarget = 2048;                            // packed launches: (tile, group) items the device aims for
 constexpr int kSweepGroups = 32;                                   // workgroups sharing a packed tile on a sweep's sparse visits
 constexpr int kStreamGroups = 16;                                  // dense launches of the streaming kernel: workgroups per tile
+constexpr int kChipGroups = 8;                                     // ... of the on-chip kernel: half the records, same speed (profiles/r03_k2_variants.md)
 constexpr size_t kStreamLdsBytes = (size_t)80 << 10;               // dynamic LDS of one streaming workgroup (two per CU)
 constexpr size_t kStagingBudget = (size_t)256 << 20;               // device staging buffer of the chunked host upload
 constexpr int kMinSpatialDim = 10;                                 // _MIN_SPATIAL_DIM, rslf_fine_to_coarse.hpp:8
@@ -390,8 +391,14 @@ inline ScanPlan plan_scan(const ScanRequest& r, int nres)
     int groups = std::max(1, r.ctx_groups);
     bool packed = r.ctx_packed;
     // the streaming kernel's dense launches share tiles so that what an XCD's workgroups gather from fits its L2
-    if ((r.use_stream || r.use_chip) && groups == 1 && !packed)
+    if ((r.use_stream || r.use_chip) && groups == 1 && !packed) {
         groups = r.stream_groups > 0 ? r.stream_groups : kStreamGroups;
+        // the on-chip kernel reads a tile's samples once per workgroup whatever their number; fewer workgroups per tile leave
+        // fewer records -- unless the launch is then only a few rounds of workgroups
+        const long long tiles = (long long)r.V * ((r.U + 62) / 63);
+        if (r.use_chip && r.stream_groups <= 0 && (r.num_cus <= 0 || tiles * kChipGroups >= 8LL * r.num_cus))
+            groups = kChipGroups;
+    }
     // A dense launch of a register kernel whose grid is only a few rounds of workgroups pays for its last, partly empty
     // round: sharing each tile's hypotheses among 2-8 workgroups makes the rounds shorter and more numerous -- as long
     // as a wave keeps at least eight hypotheses and ~256 (hypothesis, view) pairs.

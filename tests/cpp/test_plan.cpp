@@ -268,13 +268,18 @@ static void test_scan_plans()
     p = plan_scan(c5, 68);
     CHECK(p.groups == 16 && p.tile_w == 63 && p.tiles_per_row == 65 && p.rows_per_launch == 126 && p.stream_park == 24);
     CHECK(p.lds_bytes == 4 * 4 * (204 + 24 * 3 * 64) && p.lds_bytes <= kStreamLdsBytes);
-    ScanRequest chip = c5;                                  // the on-chip kernel: the streaming kernel's groups and tiles, all of the CU's LDS
+    ScanRequest chip = c5;                                  // the on-chip kernel: the streaming kernel's tiles, half its groups, all of the CU's LDS
     chip.use_stream = false;
     chip.use_chip = true;
-    chip.chip_wave_floats = 204 + 52 * 3 * 64;
+    chip.chip_wave_floats = 204 + 50 * 3 * 64 + 256;
     p = plan_scan(chip, 0);
-    CHECK(p.groups == 16 && !p.packed && p.tile_w == 63 && p.tiles_per_row == 65 && p.rows_per_launch == 126 && p.stream_park == 0);
-    CHECK(p.lds_bytes == (size_t)4 * 4 * (204 + 52 * 3 * 64) && p.lds_bytes <= (size_t)160 << 10);
+    CHECK(p.groups == kChipGroups && !p.packed && p.tile_w == 63 && p.tiles_per_row == 65 && p.rows_per_launch == 252 && p.stream_park == 0);
+    chip.V = 3;                                             // a few scanlines: 3 x 65 tiles x 8 groups would be three rounds of workgroups on 256 CUs
+    chip.num_cus = 256;
+    CHECK(plan_scan(chip, 0).groups == kStreamGroups);
+    chip.stream_groups = 4;                                 // the debug override holds
+    CHECK(plan_scan(chip, 0).groups == 4);
+    CHECK(p.lds_bytes == (size_t)4 * 4 * (204 + 50 * 3 * 64 + 256) && p.lds_bytes <= (size_t)160 << 10);
     // the sweep's sparse visits: a packed list, 32 groups asked for
     ScanRequest sparse = request(512, 512, 33, 1, 128);
     sparse.ctx_groups = kSweepGroups;

@@ -24,7 +24,7 @@ from tests.util import assert_pile_parity
 
 S_CHOICES_1 = [1, 2, 3, 5, 8, 9, 15, 16, 17, 24, 31, 33, 40, 47, 56, 64, 65, 72, 90, 101, 104, 105, 120, 129, 150, 192, 201, 209, 256, 257, 300]
 S_CHOICES_3 = [1, 2, 3, 5, 8, 9, 16, 17, 24, 31, 40, 48, 49, 56, 57, 64, 70, 88, 100, 104, 105, 120,
-               199, 200, 201, 201, 203, 209, 230]   # 200 views and up, dense launch: the on-chip kernel (k2_chip.hpp)
+               199, 200, 201, 201, 202, 203, 209, 230, 256]   # 201 views and up, dense launch: the on-chip kernel (k2_chip.hpp)
 
 
 def draw_case(rng):

@@ -16,6 +16,10 @@ if os.environ.get("ITER"):      # passes of the mean shift: splits a kernel's ti
     params.par_mean_shift_max_iter = float(os.environ["ITER"])
 if os.environ.get("FORCE_SCAN"):
     v.ctx.set_debug(force_scan=int(os.environ["FORCE_SCAN"]))
+if os.environ.get("STREAM_SHARE"):   # 0: 64-pixel tiles, every hypothesis in the general two-tap form
+    v.ctx.set_debug(stream_share=int(os.environ["STREAM_SHARE"]))
+if os.environ.get("FORCE_GROUPS"):
+    v.ctx.set_debug(force_groups=int(os.environ["FORCE_GROUPS"]))
 comp = rs.Depth1DComputer_pile(v, dmin, dmax, D, parameters=params)
 comp.run(want_stats=True)
 torch.cuda.synchronize()
