@@ -214,6 +214,47 @@ def bench_f2c(args) -> None:
     }), flush=True)
 
 
+def bench_e2e(args) -> None:
+    """`--path e2e [--gpus N]`: the pipelined host path alone -- host EPIs in, host planes out (dc.hpp:97-122) -- in ONE
+    process that drives N devices through rslf_multi_create([0..N-1]) (one host thread per device, scanline blocks, no
+    collective).  RSLF_E2E_DEVICES="0,0" rehearses two workers on one GPU (never a result).  PCIe-inclusive: the line
+    carries no `value`; the figure is `e2e`.  N > 1 has not run on hardware here (one-GPU boxes)."""
+    import torch
+    from remotesensingproject_amd import depth as rs
+    from remotesensingproject_amd.synth import make_lightfield
+    cfg, cfg_name = pick_config(args)
+    if args.rows:
+        cfg["V"] = args.rows
+    if cfg["seed"] is None:
+        raise SystemExit("--path e2e takes the synthetic configs (c2, c3, c5) or --shape")
+    devices = [int(x) for x in os.environ["RSLF_E2E_DEVICES"].split(",")] if os.environ.get("RSLF_E2E_DEVICES") else list(range(args.gpus))
+    if max(devices) >= torch.cuda.device_count():
+        raise SystemExit("--gpus %d but %d device(s) visible" % (args.gpus, torch.cuda.device_count()))
+    U, V, S, C, D = cfg["U"], cfg["V"], cfg["S"], cfg["C"], cfg["D"]
+    host, _ = make_lightfield(U, V, S, C, seed=cfg["seed"], dmin=cfg["dmin"], dmax=cfg["dmax"])
+    epis = list(host[..., 0]) if C == 1 else list(host)
+    m = rs.MultiDevice(devices)
+    peer = m.peer_access()
+    ts, units = [], 0
+    calls = max(2, args.steps + 1) if host.nbytes <= (4 << 30) else 3
+    for _ in range(calls):
+        t0 = time.perf_counter()
+        out = m.depth1d_pile(epis, cfg["dmin"], cfg["dmax"], D, epi_scale_factor=1.0)
+        ts.append(time.perf_counter() - t0)
+    units = int((out["edge_mask"] > 0).sum()) * D
+    m.close()
+    t = sorted(ts[1:])[(calls - 1) // 2]
+    print(json.dumps({
+        "metric": "Mpixel*disparity-hypotheses/s", "value": None, "unit": "Mpixel*hyp/s", "n_gpus": len(devices), "path": "e2e",
+        "higher_is_better": True, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "%s: %dx%d px x %d views x %d ch, %d hypotheses in [%g, %g], seed %d" % (cfg_name, U, V, S, C, D, cfg["dmin"], cfg["dmax"], cfg["seed"]),
+                   "devices": devices, "peer_access": peer},
+        "e2e": {"ms": t * 1e3, "value": units / t / 1e6, "unit": "Mpixel*hyp/s", "calls_ms": [x * 1e3 for x in ts], "input_gb": host.nbytes / 1e9,
+                "what": "host EPIs (pageable) in -> host planes out through rslf_multi_depth1d_pile_f32 on %d device(s) of one process; "
+                        "median of the calls after the first; PCIe-inclusive, never `value`" % len(devices)},
+    }), flush=True)
+
+
 def launch_ranks(n: int) -> None:
     """`python bench.py --gpus N` typed as is: this process never touches the GPU; it starts N fresh rank
     processes (one per GPU) through torch.distributed.run with the same arguments, lets rank 0's JSON line
@@ -241,12 +282,14 @@ def main() -> None:
     ap.add_argument("--rows", type=int, default=0, help="override the number of scanlines (developer runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the host-in / host-out figure (the `e2e` key)")
-    ap.add_argument("--path", default="pile", choices=["pile", "sweep2d", "f2c"],
+    ap.add_argument("--path", default="pile", choices=["pile", "sweep2d", "f2c", "e2e"],
                     help="pile = Depth1DComputer_pile::run (the headline path); sweep2d = Depth2DComputer::run, the 'next' row "
                          "(all views, centre outwards, with propagation), 1 GPU only")
     args = ap.parse_args()
     args.config_given = args.config is not None
     args.config = args.config or "c3"
+    if args.path == "e2e":      # one process, N devices behind the C-ABI (no ranks)
+        return bench_e2e(args)
     if args.gpus > 1 and "RANK" not in os.environ:
         return launch_ranks(args.gpus)
     if args.path == "sweep2d":

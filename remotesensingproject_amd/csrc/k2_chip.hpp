@@ -206,7 +206,7 @@ __device__ __forceinline__ void chip_flush(const ChipPK& p, float (&A)[3], float
 // NOTHING a lane owns is carried through a hypothesis by the compiler's choice: with 192 of the 256 registers holding
 // samples, every per-lane value that lives across the gather and the passes -- the pixel's column, its float, its byte
 // offset, the lane's LDS addresses -- was spilled once per workgroup and re-read once per hypothesis (84 bytes of scratch
-// per lane; dirty scratch lines pushed out of the L2 by the streaming reads were a third of the kernel's HBM writes).
+// per lane; dirty scratch lines pushed out of the L2 by the streaming reads were four fifths of the kernel's HBM writes).
 // So a tile is known by wave-UNIFORM values only (scalar registers), and what a lane needs is made again where it is
 // used: its number from v_mbcnt (an asm the optimiser cannot hoist or merge), its pixel from the scanline's list
 // (K1's output, an L2 hit) -- or, on a dense tile, first pixel + lane.
@@ -227,12 +227,13 @@ struct ChipTile {
 
 // A wave's running result over its hypotheses, kept OUT of the allocator's vector registers.  With 192 of the 256
 // holding samples hipcc spilled Best (eight values per lane) to scratch and wrote it back after every hypothesis: 32 bytes
-// per lane and hypothesis, 4.3 GB of HBM writes per 64 scanlines of c5 against 0.64 GB of algorithmic traffic -- every
-// store leaves the L2.  (Index and rbar in scratch by hand, written only where a lane's best improves, still wrote
-// 1.1 GB: scores rise smoothly towards a pixel's disparity, so half the hypotheses improve on their predecessor.)
-// What every hypothesis touches -- the double sum of the scores (cv::mean, core.hpp:641) and the best score -- sits in
-// a253:a254 and a255; index and rbar sit in LDS, [4][64] behind the wave's sample tier, which gave up two samples for
-// them (kChipAhead).  Same operations in the same order as Best<3> (core.hpp:636-645: strictly greater, first maximum).
+// per lane and hypothesis, 4.3 GB of HBM writes per 64 scanlines of c5 against 0.64 GB of algorithmic traffic (the
+// streaming reads push the dirty lines out of the L2 as fast as they are made).  (Index and rbar in scratch by hand,
+// written only where a lane's best improves, still wrote 1.1 GB: scores rise smoothly towards a pixel's disparity, so
+// half the hypotheses improve on their predecessor.)  What every hypothesis touches -- the double sum of the scores
+// (cv::mean, core.hpp:641) and the best score -- sits in a253:a254 and a255; index and rbar sit in LDS, [4][64] behind the
+// wave's sample tier, which gave up two samples for them (kChipAhead).  Same operations in the same order as Best<3>
+// (core.hpp:636-645: strictly greater, first maximum).
 struct ChipBest {
     float* wave_blk;   // [index (bits), rbar0, rbar1, rbar2][64 lanes]
     __device__ __forceinline__ void init(float* wave_block)

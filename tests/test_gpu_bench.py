@@ -40,3 +40,14 @@ def test_bench_gpus_2_as_typed_starts_its_own_ranks():
     assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["value"] > 0
     assert "REHEARSAL" in j["data"]
     assert j["config"]["pixels_scanned"] >= 64 * 1920 - 64 and "halo" in j["config"]["sharding"]
+
+
+def test_bench_path_e2e_one_process_two_workers():
+    """`--path e2e --gpus N`: ONE process, N devices behind rslf_multi_create.  On a one-GPU box
+    RSLF_E2E_DEVICES="0,0" puts both workers on cuda:0: a rehearsal of the code path, never a result."""
+    j = _run(["--path", "e2e", "--gpus", "2", "--config", "c2", "--steps", "2"], env={"RSLF_E2E_DEVICES": "0,0"})
+    assert j["path"] == "e2e" and j["n_gpus"] == 2 and j["value"] is None
+    assert j["config"]["devices"] == [0, 0] and j["config"]["peer_access"] == [[1, 1], [1, 1]]
+    assert j["e2e"]["value"] > 0 and len(j["e2e"]["calls_ms"]) == 3
+    one = _run(["--path", "e2e", "--config", "c2", "--steps", "2"])
+    assert one["n_gpus"] == 1 and one["e2e"]["value"] > 0
