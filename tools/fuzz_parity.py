@@ -27,9 +27,14 @@ S_CHOICES_3 = [1, 2, 3, 5, 8, 9, 16, 17, 24, 31, 40, 48, 49, 56, 57, 64, 70, 88,
                199, 200, 201, 201, 202, 203, 209, 230, 256]   # 201 views and up, dense launch: the on-chip kernel (k2_chip.hpp)
 
 
+ONLY_CHIP = os.environ.get("FUZZ_ONLY_CHIP") == "1"   # RGB, 201..256 views, dense launches: what k2_scan_chip takes
+
+
 def draw_case(rng):
     C = int(rng.choice([1, 1, 3]))
     S = int(rng.choice(S_CHOICES_1 if C == 1 else S_CHOICES_3))
+    if ONLY_CHIP:
+        C, S = 3, int(rng.choice([201, 201, 202, 203, 204, 205, 217, 230, 255, 256]))
     budget = 600000 if C == 1 else 250000          # oracle work ~ V*U*D*S
     U = int(rng.choice([1, 2, 7, 33, 63, 64, 65, 100, 129, 200, 260, 513, 700]))
     V = int(rng.integers(1, 13))
@@ -41,6 +46,14 @@ def draw_case(rng):
     lo = float(rng.choice([-2.0, -1.0, -0.5, 0.0, 0.25]))
     hi = lo + float(rng.choice([0.0, 0.5, 1.0, 2.5, 4.0]))
     kind = str(rng.choice(["noise", "struct", "mixed", "dark"]))
+    if ONLY_CHIP:   # no per-pixel planes, no forced variant, no packed lists, non-negative: the launch shape the kernel takes
+        return dict(C=C, S=S, U=U, V=V, D=D, dmin=lo, dmax=hi, kind=str(rng.choice(["noise", "struct", "mixed", "dark"])),
+                    slope=float(rng.choice([1.0, 1.0, 0.5, 0.25, 1.5])), s_hat=int(rng.integers(0, S)) if rng.uniform() < 0.3 else -1,
+                    planes=False, mask=bool(rng.uniform() < 0.3), force="", packed=0, groups=int(rng.choice([1, 1, 2, 4, 8])),
+                    iters=float(rng.choice([10.0, 10.0, 1.0, 3.5, 12.0])), h=float(rng.choice([0.2, 0.2, 0.1, 0.5])),
+                    thr=float(rng.choice([0.02, 0.02, 0.0, 0.2])), raw_thr=float(rng.choice([0.0, 0.0, 0.3])),
+                    median=int(rng.choice([5, 5, 3, 7, 1])), shadows=bool(rng.uniform() < 0.8), negative=False, interp=0,
+                    opening=(2, 1), form=str(rng.choice(["dense", "dense", "epis_f32", "epis_u8"])))
     return dict(C=C, S=S, U=U, V=V, D=D, dmin=lo, dmax=hi, kind=kind,
                 slope=float(rng.choice([1.0, 1.0, 0.5, 0.25, 1.5])),
                 s_hat=int(rng.integers(0, S)) if rng.uniform() < 0.3 else -1,
