@@ -253,7 +253,9 @@ def selective_median(src, vol, s_hat, mask, size, eps):
             diff = ref[v, u][None, None] - ref[k0:k1, l0:l1]
             ok = (mask[k0:k1, l0:l1] != 0) & (_norm(diff) < F(eps))
             vals = np.sort(src[k0:k1, l0:l1][ok])
-            dst[v, u] = vals[len(vals) // 2]                 # nth_element at n/2
+            # nth_element at n/2; an empty candidate set (NaN centre radiance) is undefined in the reference
+            # (core.hpp:713-714 reads buffer[0] of a cleared vector): defined as 0 here, in the C oracle and in K3
+            dst[v, u] = vals[len(vals) // 2] if len(vals) else F(0)
     return dst
 
 

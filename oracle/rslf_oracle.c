@@ -759,9 +759,12 @@ void oracle_selective_median(const float* src_vu, float* dst_vu,
                         buf[n++] = src_vu[(size_t)k * U + l];
                 }
             }
-            /* std::nth_element(..., n/2): the n/2-th order statistic */
+            /* std::nth_element(..., n/2): the n/2-th order statistic.  n == 0 -- a masked pixel whose centre radiance is NaN,
+             * so that not even the pixel itself passes the test -- is undefined in the reference: core.hpp:713-714 reads
+             * buffer[0] of a vector it has just cleared (in practice a stale value of the thread's previous pixel).  Defined
+             * here, as in the HIP kernel (k3_median.hpp): 0, what a pixel outside the mask gets (core.hpp:678-679). */
             qsort(buf, (size_t)n, sizeof(float), cmp_float);
-            dst_vu[(size_t)v * U + u] = buf[n / 2];
+            dst_vu[(size_t)v * U + u] = n ? buf[n / 2] : 0.0f;
         }
         free(buf);
     }

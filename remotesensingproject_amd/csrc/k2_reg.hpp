@@ -44,10 +44,13 @@ constexpr int kPadSlack = 16;     // compiled slot counts step by at most this: 
 // GB:        samples whose loads are in flight together, 0 = the default (gather_batch).  The packed kernel of long
 //            one-channel units asks for a quarter of the unit at once: on a sparse launch a wave has its SIMD nearly to
 //            itself, and a hypothesis costs it one memory round trip per batch.
-template <int SPAD, int C, bool BORDER, bool UNIFORM_D, bool PK, int GB = 0, class BestT = Best<C>>
+// LANE_D:    the lanes of the wave own HYPOTHESES of one pixel instead of pixels (k2_scan_reg_px): lane `dlane` scores
+//            d0 + dlane, d0 + dlane + dstep, ... below d1 (a lane past the end repeats d1 - 1 and offers nothing).
+template <int SPAD, int C, bool BORDER, bool UNIFORM_D, bool PK, int GB = 0, class BestT = Best<C>, bool LANE_D = false>
 __device__ __forceinline__ void scan_reg_body(const ScanArgs& a, int v, int u, int d0, int d1, BestT& best,
-                                              float* __restrict__ otab)
+                                              float* __restrict__ otab, int dlane = 0, int dstep = 1)
 {
+    static_assert(!LANE_D || !UNIFORM_D, "hypotheses in the lanes: every lane has its own view offsets");
     // 104 slots (the c3 shape) have 15 registers to spare at three waves per SIMD: 13 loads in flight instead of 8
     // (8 batches instead of 13 per hypothesis) measured 0.5 % faster
     constexpr int kGatherBatch = GB > 0 ? GB : (C == 1 && !PK && SPAD == 104 && RSLF_REG_GB104 == 13) ? 13 : gather_batch(C);
@@ -75,7 +78,8 @@ __device__ __forceinline__ void scan_reg_body(const ScanArgs& a, int v, int u, i
         centre[c] = epi[(long long)a.s_hat * vol.stride_s + u * C + c];
 
 #pragma unroll 1
-    for (int d = d0; d < d1; d++) {
+    for (int dk = d0; dk < d1; dk += (LANE_D ? dstep : 1)) {
+        const int d = LANE_D ? min(dk + dlane, d1 - 1) : dk;
         const float Dd = hypothesis(dmin, range, denom, d);
         float R[PK ? 1 : C][PK ? 1 : SPAD];
         f2 R2[PK ? C : 1][PK ? SPAD / 2 : 1];
@@ -317,7 +321,8 @@ __device__ __forceinline__ void scan_reg_body(const ScanArgs& a, int v, int u, i
         const float cardf = (float)card;
         float sc = (card != 0) ? (B / cardf) : 0.0f;   // core.hpp:616-620: the last pass's sum of K
         sc = (sc > 0.0f) ? sc : 0.0f;                  // core.hpp:622
-        best.offer(sc, d, Dd, rbar);
+        if (!LANE_D || dk + dlane < d1)
+            best.offer(sc, d, Dd, rbar);
     }
 }
 
@@ -427,6 +432,108 @@ void k2_scan_reg_packed(ScanArgs a)
     float* const epi_lds = nullptr;
     const int epi_stride = 0;
     RSLF_SCAN_PACKED_LOOP((scan_reg_body<SPAD, C, true, false, packed_waves(SPAD, C) == 1, packed_gather_batch(SPAD, C)>(a, v, u, d0, d1, best, nullptr)))
+}
+
+// Sparse launches, lanes own HYPOTHESES (k2_scan_reg_px).  A sparse visit's pixels sit two or three to a scanline: with a
+// pixel per lane (k2_scan_reg_packed) every load of the gather touches up to 64 scanlines -- 64 cache lines for 512 useful
+// bytes -- and the kernel runs at 1.0 G units/s on a list of scattered pixels where the dense kernel makes 8 (c3 shape,
+// tools/probe_sparse.py).  Here a wave owns ONE pixel and its lanes score 64 hypotheses of it: a load's 64 taps lie within
+// (d_63 - d_0) * |s_hat - s| pixels of one EPI row, a handful of lines, the EPI base is a scalar, and nothing is shared
+// between workgroups -- no hypothesis groups, no records, no tickets.  px_waves = 1 / 2 / 4 waves share a pixel's
+// hypotheses (lane slot + k * 64 * px_waves; plan::px_waves picks by lane use), so a workgroup holds 4 / 2 / 1 pixels.
+// The arithmetic of a (pixel, hypothesis) unit is scan_reg_body's per-lane form, the one per-pixel [dmin, dmax] planes
+// take: same operations, same bits.  What changes is the reduction over hypotheses, now across lanes: the best score wins,
+// the LOWEST hypothesis among equal scores (first maximum, cv::minMaxLoc, core.hpp:634), and the score sum is a double
+// (cv::mean, core.hpp:641 -- C_d is held to 1e-5; sums of <= 4096 floats in [0, 1] are exact in a double unless a score
+// is below 2^-21, so in practice the same bits in any order).
+// Occupancy and gather batch: the ROW kernel's (scalar EPI base, near-coalesced loads: three waves per SIMD and 13 loads in
+// flight at 104 slots), not the packed kernel's (two waves, a quarter of the unit in flight): same-box A/B, c3 sweep 118.0
+// vs 120.0 ms, SkysatLR-like fine-to-coarse 257 vs 278 ms (profiles/r03_k2_variants.md section 5).  0 builds the other.
+#ifndef RSLF_PX_ROWLIKE
+#define RSLF_PX_ROWLIKE 1
+#endif
+constexpr int px_kernel_waves(int spad, int c) { return RSLF_PX_ROWLIKE ? scan_reg_waves(spad, c) : packed_waves(spad, c); }
+template <int SPAD, int C>
+__global__ __launch_bounds__(64 * kScanWaves) __attribute__((amdgpu_waves_per_eu(px_kernel_waves(SPAD, C), px_kernel_waves(SPAD, C))))
+void k2_scan_reg_px(ScanArgs a)
+{
+    __shared__ double s_sum[kScanWaves];
+    __shared__ float s_rec[kScanWaves][3 + C];   // score, hypothesis (bits), disparity, rbar
+    const int n = *a.packed_n;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wpp = a.px_waves, ppw = kScanWaves / wpp;   // waves per pixel, pixels per workgroup
+    const int items = (n + ppw - 1) / ppw;
+    const int sub = wave % wpp;
+    const int dlane = sub * 64 + lane, dstep = 64 * wpp;
+    for (int item = blockIdx.x; item < items; item += gridDim.x) {
+        const int e = item * ppw + wave / wpp;
+        const bool have = e < n;   // (a workgroup's last pixels may be missing: those waves shadow the list's last entry and write nothing)
+        const unsigned o = (unsigned)__builtin_amdgcn_readfirstlane(a.list[have ? e : n - 1]);
+        const int v = (int)(o / (unsigned)a.vol.U);
+        const int u = (int)(o - (unsigned)v * (unsigned)a.vol.U);
+        Best<C> best;
+        best.init();
+        // the validity test (interp.hpp:182) can go where every sample line of every hypothesis stays inside the row
+        const float dlo = a.dmin_vu ? a.dmin_vu[o] : a.dmin, dhi = a.dmax_vu ? a.dmax_vu[o] : a.dmax;
+        const float reach = (float)max(a.s_hat, a.vol.S - 1 - a.s_hat) * fmaxf(fabsf(dlo), fabsf(dhi)) * fabsf(a.k.slope) + 2.0f;
+        const bool interior = (float)u - reach >= 0.0f && (float)u + reach <= (float)(a.vol.U - 1);   // wave-uniform
+        constexpr int kGB = RSLF_PX_ROWLIKE ? 0 : packed_gather_batch(SPAD, C);
+        if (interior)
+            scan_reg_body<SPAD, C, false, false, false, kGB, Best<C>, true>(a, v, u, 0, a.dim_d, best, nullptr, dlane, dstep);
+        else
+            scan_reg_body<SPAD, C, true, false, false, kGB, Best<C>, true>(a, v, u, 0, a.dim_d, best, nullptr, dlane, dstep);
+        // ---- across the lanes
+        float bs = best.score;                        // -1 where a lane had no hypothesis
+        int bd = bs < 0.0f ? 0x7fffffff : best.d;
+        double sum = best.sum;
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            const float os = __shfl_xor(bs, m);
+            const int od = __shfl_xor(bd, m);
+            const bool take = os > bs || (os == bs && od < bd);
+            bs = take ? os : bs;
+            bd = take ? od : bd;
+            sum += __shfl_xor(sum, m);
+        }
+        const int owner = __ffsll((unsigned long long)__ballot(best.score == bs && best.d == bd)) - 1;   // exactly one lane scored bd
+        float bD = __shfl(best.D, owner);
+        float br[C];
+#pragma unroll
+        for (int c = 0; c < C; c++)
+            br[c] = __shfl(best.rbar[c], owner);
+        // ---- across the waves that share the pixel
+        if (wpp > 1) {
+            if (lane == 0) {
+                s_rec[wave][0] = bs;
+                s_rec[wave][1] = __int_as_float(bd);
+                s_rec[wave][2] = bD;
+#pragma unroll
+                for (int c = 0; c < C; c++)
+                    s_rec[wave][3 + c] = br[c];
+                s_sum[wave] = sum;
+            }
+            __syncthreads();
+            if (sub == 0) {
+                for (int w = wave + 1; w < wave + wpp; w++) {
+                    const float os = s_rec[w][0];
+                    const int od = __float_as_int(s_rec[w][1]);
+                    sum += s_sum[w];
+                    if (os > bs || (os == bs && od < bd)) {
+                        bs = os;
+                        bd = od;
+                        bD = s_rec[w][2];
+#pragma unroll
+                        for (int c = 0; c < C; c++)
+                            br[c] = s_rec[w][3 + c];
+                    }
+                }
+            }
+            __syncthreads();   // the next item's records may overwrite these
+        }
+        if (have && sub == 0 && lane == 0)
+            write_pixel<C>(a, (long long)o, bs, bd, bD, br, sum);
+    }
 }
 
 }  // namespace rslf

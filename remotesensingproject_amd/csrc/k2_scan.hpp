@@ -80,6 +80,8 @@ struct ScanArgs {
     // streaming kernel, shared-tap tail: a view offset whose fraction is above this could round a position up to
     // the next integer in some lanes and not in others (1 - ulp of the largest position, host-computed)
     float stream_frac_max;
+    // pixel-per-wave kernel (k2_scan_reg_px, sparse launches): waves that share one pixel's hypotheses, 1 / 2 / 4; 0 = not that kernel
+    int px_waves;
 };
 
 // Laid out WORD-major in memory ([item][word][lane], record_word): a wave's store of one word is then 256 contiguous bytes.

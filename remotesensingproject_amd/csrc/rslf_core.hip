@@ -275,6 +275,8 @@ extern "C" int rslf_ctx_set_debug(rslf_ctx* ctx, const char* key, int value) RSL
         ctx->force_groups = value;
     else if (strcmp(key, "force_packed") == 0 && value >= -1 && value <= 1)
         ctx->force_packed = value;
+    else if (strcmp(key, "px") == 0 && value >= -1 && value <= 1)
+        ctx->px_mode = value;
     else if (strcmp(key, "stream_share") == 0 && (value == 0 || value == 1))
         ctx->stream_share = value != 0;
     else if (strcmp(key, "claim_skip") == 0 && (value == 0 || value == 1))

@@ -181,6 +181,7 @@ struct rslf_ctx {
     int force_scan = 0;        // 1 generic kernel, 2 streaming kernel, 3 on-chip kernel
     int force_groups = 0;      // hypothesis groups per tile
     int force_packed = -1;     // 0 / 1
+    int px_mode = -1;          // pixel-per-wave kernel on packed launches: -1 automatic, 0 never, 1 whenever it can run
     int stream_groups = 0;     // streaming kernel, dense launches: hypothesis groups per tile (0 = kStreamGroups)
     bool stream_share = true;  // streaming kernel: 63-pixel row tiles whose tail shares taps between neighbouring lanes
     size_t stream_lds_bytes = rslf::plan::kStreamLdsBytes;   // dynamic LDS of one streaming workgroup

@@ -124,7 +124,9 @@ static int launch_scan_reg(int spad, int C, const ScanArgs& a, dim3 grid, hipStr
 {
 #define RSLF_CASE(N)                                                                                        \
     case N:                                                                                                 \
-        if (a.packed)                                                                                       \
+        if (a.packed && a.px_waves)                                                                         \
+            hipLaunchKernelGGL((k2_scan_reg_px<N, RSLF_C>), grid, dim3(64 * kScanWaves), 0, stream, a);     \
+        else if (a.packed)                                                                                  \
             hipLaunchKernelGGL((k2_scan_reg_packed<N, RSLF_C>), grid, dim3(64 * kScanWaves), 0, stream, a); \
         else                                                                                                \
             hipLaunchKernelGGL((k2_scan_reg<N, RSLF_C>), grid, dim3(64 * kScanWaves), 0, stream, a);        \
@@ -209,6 +211,7 @@ static plan::ScanRequest scan_request(const rslf_ctx* ctx, int V, int U, int S, 
     rq.precompacted = precompacted;
     rq.force_groups = ctx->force_groups;
     rq.force_packed = ctx->force_packed;
+    rq.px_mode = ctx->px_mode;
     rq.stream_groups = ctx->stream_groups;
     rq.stream_share = ctx->stream_share;
     rq.stream_lds_bytes = ctx->stream_lds_bytes;
@@ -337,6 +340,7 @@ extern "C" int rslf_depth_epi_scan(rslf_ctx* ctx, const rslf_volume* vol, const 
     a.packed = packed ? 1 : 0;
     a.packed_n = packed_n;
     a.packed_adapt = sp.packed_adapt ? 1 : 0;
+    a.px_waves = sp.px_waves;
     a.stream_park = sp.stream_park;
     a.stream_wave_floats = sp.stream_wave_floats;
     a.partial = nullptr;
@@ -385,7 +389,11 @@ extern "C" int rslf_depth_epi_scan(rslf_ctx* ctx, const rslf_volume* vol, const 
         a.logical_blocks = (int)(tiles * groups);   // `groups` workgroups per tile, their waves split the hypotheses
         a.per_xcd = (a.logical_blocks + 7) / 8;
         // packed: a fixed grid strides over the items (k2_scan.hpp); ~4 workgroups per CU cover any occupancy
-        const dim3 grid(packed ? (unsigned)std::min<long long>(tiles * groups, 1024) : (unsigned)(a.per_xcd * 8));
+        // (the pixel-per-wave kernel's items are 4 / px_waves pixels each)
+        const long long px_items = sp.px_waves ? ((long long)n * sp.px_waves + kScanWaves - 1) / kScanWaves : 0;
+        const dim3 grid(sp.px_waves ? (unsigned)std::min<long long>(px_items, 2048)
+                        : packed    ? (unsigned)std::min<long long>(tiles * groups, 1024)
+                                    : (unsigned)(a.per_xcd * 8));
         if (spad) {
             rc = launch_scan_reg(spad, vol->C, a, grid, st);
             if (rc)

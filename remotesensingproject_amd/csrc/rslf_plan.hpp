@@ -348,6 +348,24 @@ inline float stream_frac_max(int U)
     return 1.0f - std::ldexp(1.0f, std::max(e - 24, -24));
 }
 
+// The pixel-per-wave kernel of sparse launches (k2_reg.hpp, k2_scan_reg_px): a pixel's hypotheses sit in the LANES of 1, 2
+// or 4 waves (lane slot + k * 64 * waves), so what matters is how many lanes a pixel keeps busy.  Returns the number of
+// waves per pixel with the best lane use (the larger on ties: finer items), or 0 when no choice reaches 60 %.
+inline int px_waves(int dim_d)
+{
+    int best = 0;
+    double best_use = 0.0;
+    for (int w = 1; w <= kScanWavesPerTile; w *= 2) {
+        const int lanes = 64 * w, iters = (dim_d + lanes - 1) / lanes;
+        const double use = (double)dim_d / ((double)iters * lanes);
+        if (use >= best_use - 1e-12) {
+            best_use = use;
+            best = w;
+        }
+    }
+    return best_use >= 0.6 ? best : 0;
+}
+
 struct ScanRequest {
     int V, U, S, C, dim_d;
     int spad;              // register kernel's slot count, 0 = none
@@ -361,6 +379,7 @@ struct ScanRequest {
     int precompacted;      // 0: the scan compacts; 1: row lists are in place (K1); 2: the packed list is (sweep)
     int force_groups;      // debug hooks: 0 / -1 = automatic
     int force_packed;
+    int px_mode;           // pixel-per-wave kernel for packed launches of a register kernel: -1 automatic, 0 never, 1 whenever it can run
     int stream_groups;     // 0 = kStreamGroups
     bool stream_share;     // 63-pixel row tiles (shared taps)
     size_t stream_lds_bytes;
@@ -370,6 +389,7 @@ struct ScanPlan {
     int groups;            // workgroups sharing one tile's hypotheses
     bool packed;           // one packed list over all scanlines
     bool packed_adapt;     // the device settles the group count from the list length
+    int px_waves;          // > 0: the pixel-per-wave kernel takes the packed list, this many waves per pixel (no groups, no records)
     int tile_w;            // 63 or 64 entries per row tile
     int tiles_per_row;
     int rows_per_launch;   // grouped row-tile launches go by blocks of scanlines
@@ -435,6 +455,19 @@ inline ScanPlan plan_scan(const ScanRequest& r, int nres)
     if (packed && (r.use_stream || r.use_chip))
         while (groups > 1 && ((n + 63) / 64) * groups * 64 * kPartialRecordBytes > kPartialBudget)
             groups /= 2;
+    // Packed launches of a register kernel: lanes own hypotheses, a wave owns a pixel (the gather of a sparse list is then
+    // 64 neighbouring taps of one scanline instead of 64 scanlines) -- no hypothesis groups, no records
+    p.px_waves = 0;
+    if (packed && r.spad && !r.use_stream && !r.use_chip && r.px_mode != 0) {
+        int w = px_waves(r.dim_d);
+        if (w == 0 && r.px_mode == 1)
+            w = 1;
+        p.px_waves = w;
+        if (w) {
+            groups = 1;
+            p.packed_adapt = false;
+        }
+    }
     p.groups = groups;
     p.packed = packed;
     p.records = 0;

@@ -211,6 +211,7 @@ static ScanRequest request(int V, int U, int S, int C, int D)
     r.precompacted = 0;
     r.force_groups = 0;
     r.force_packed = -1;
+    r.px_mode = -1;
     r.stream_groups = 0;
     r.stream_share = true;
     r.stream_lds_bytes = kStreamLdsBytes;
@@ -286,7 +287,26 @@ static void test_scan_plans()
     sparse.ctx_packed = true;
     sparse.precompacted = 2;
     p = plan_scan(sparse, 0);
-    CHECK(p.packed && p.packed_adapt && p.groups == 16 && p.records == (size_t)kPackedItemTarget * 64);
+    // ... which the pixel-per-wave kernel does not need: 128 hypotheses = two waves of lanes per pixel, no groups, no records
+    CHECK(p.packed && !p.packed_adapt && p.px_waves == 2 && p.groups == 1 && p.records == 0 && p.tickets == 0);
+    sparse.px_mode = 0;                                     // switched off (debug key "px"): the pixel-per-lane kernel and its groups
+    p = plan_scan(sparse, 0);
+    CHECK(p.packed && p.packed_adapt && p.px_waves == 0 && p.groups == 16 && p.records == (size_t)kPackedItemTarget * 64);
+    sparse.px_mode = -1;
+    sparse.dim_d = 16;                                      // too few hypotheses to fill a wave's lanes: stays with the pixel-per-lane kernel
+    CHECK(plan_scan(sparse, 0).px_waves == 0);
+    sparse.px_mode = 1;                                     // ... unless forced (parity tests)
+    CHECK(plan_scan(sparse, 0).px_waves == 1);
+    sparse.px_mode = -1;
+    sparse.dim_d = 128;
+    CHECK(px_waves(256) == 4 && px_waves(128) == 2 && px_waves(120) == 2 && px_waves(64) == 1 && px_waves(40) == 1 && px_waves(512) == 4);
+    CHECK(px_waves(32) == 0 && px_waves(16) == 0 && px_waves(2) == 0 && px_waves(300) == 1 && px_waves(200) == 4 && px_waves(100) == 2);
+    {   // the streaming kernel's packed launches keep their groups
+        ScanRequest many = request(64, 512, 250, 1, 128);
+        many.ctx_packed = true;
+        many.ctx_groups = 8;
+        CHECK(many.use_stream && plan_scan(many, 192).px_waves == 0 && plan_scan(many, 192).groups == 8);
+    }
     // K1 left row lists: never packed, whatever the caller asked for
     sparse.precompacted = 1;
     p = plan_scan(sparse, 0);

@@ -151,7 +151,7 @@ def test_stream_kernel_per_pixel_ranges(rs, oracle_mod, hooks):
     assert np.array_equal(trbar.cpu().numpy(), ref.rbar)
 
 
-@pytest.mark.parametrize("packed", [0, 1])
+@pytest.mark.parametrize("packed", [0, 1, 2])   # 2 = packed, lanes own hypotheses (k2_scan_reg_px) wherever a register kernel runs
 @pytest.mark.parametrize("groups,force,C_,S,U,D", [
     (1, None, 1, 17, 130, 12),       # packed tiles alone
     (2, None, 1, 17, 130, 16),       # the smallest D a pair of groups accepts
@@ -172,7 +172,8 @@ def test_sparse_launch_shapes(rs, oracle_mod, hooks, packed, groups, force, C_, 
     by k2_scan_combine) and pack the pixels of all scanlines into one list, so that a wave's lanes sit on
     different scanlines: arg-max (first maximum), mean and r-bar must not depend on either."""
     hooks(force_groups=groups)
-    hooks(force_packed=packed)
+    hooks(force_packed=min(packed, 1))
+    hooks(px=1 if packed == 2 else 0)
     if force:
         hooks(force_scan=force)
     vol = _vol("noise" if C_ == 1 else "struct", U, 5, S, C_, 900 + D, -1.5, 2.5)
@@ -182,12 +183,14 @@ def test_sparse_launch_shapes(rs, oracle_mod, hooks, packed, groups, force, C_, 
     assert_pile_parity(got, ref, label="groups%d_packed%d_%s_C%d_D%d" % (groups, packed, force, C_, D))
 
 
-def test_packed_tiles_with_per_pixel_ranges_and_sparse_mask(rs, oracle_mod, hooks):
+@pytest.mark.parametrize("px", [0, 1])
+def test_packed_tiles_with_per_pixel_ranges_and_sparse_mask(rs, oracle_mod, hooks, px):
     """The fine-to-coarse shape of a sparse visit: per-pixel [dmin, dmax] planes, a caller mask that leaves
-    a few pixels per scanline (some scanlines none), packed tiles x 4 groups."""
+    a few pixels per scanline (some scanlines none), packed tiles x 4 groups -- or lanes that own hypotheses."""
     import torch
     hooks(force_groups=4)
     hooks(force_packed=1)
+    hooks(px=px)
     rng = np.random.default_rng(77)
     V, S, U, D = 9, 13, 150, 37
     vol = rng.uniform(0.0, 1.0, size=(V, S, U, 1)).astype(np.float32)
@@ -415,6 +418,26 @@ def test_selective_median_standalone(rs, oracle_mod):
             v = rs.Volume.from_dense(vol)
             got = rs.selective_median_filter(torch.from_numpy(src).cuda(), v, 2, size, torch.from_numpy(mask).cuda(), 0.1)
             assert np.array_equal(got.cpu().numpy(), want), (C_, size)
+
+
+def test_selective_median_of_a_pixel_with_no_candidate_is_zero(rs, oracle_mod):
+    """A masked pixel with a NaN centre radiance passes nobody's radiance test: undefined in the reference (core.hpp:713-714
+    reads buffer[0] of a cleared vector), 0 here and in the oracle, for every window size (fuzz seed 8302 case 4537)."""
+    import torch
+    rng = np.random.default_rng(43)
+    for C_ in (1, 3):
+        V, S, U = 7, 3, 40
+        vol = rng.uniform(0.0, 1.0, size=(V, S, U, C_)).astype(np.float32)
+        vol[3, 1, 17, C_ - 1] = np.nan
+        vol[0, 1, 0, 0] = np.nan
+        src = rng.uniform(0.5, 2.0, size=(V, U)).astype(np.float32)
+        mask = np.full((V, U), 255, np.uint8)
+        for size in (3, 5, 7):
+            want = oracle_mod.selective_median(src, vol, 1, mask, size, np.float32(10.0))
+            v = rs.Volume.from_dense(vol)
+            got = rs.selective_median_filter(torch.from_numpy(src).cuda(), v, 1, size, torch.from_numpy(mask).cuda(), 10.0).cpu().numpy()
+            assert got[3, 17] == 0.0 and got[0, 0] == 0.0 and np.count_nonzero(got) == V * U - 2, (C_, size)
+            assert np.array_equal(got, want), (C_, size)
 
 
 def test_analytic_known_answer(rs):
@@ -651,3 +674,37 @@ def test_stream_kernel_last_tile_of_a_row_takes_64_entries(rs, oracle_mod, hooks
     assert np.array_equal(tsc.cpu().numpy(), ref.score)
     assert np.array_equal(trb.cpu().numpy(), ref.rbar)
     assert np.array_equal(td.cpu().numpy(), ref.depth)
+
+
+@pytest.mark.parametrize("C_,S,U,V,D,dmin,dmax", [
+    (1, 101, 300, 4, 256, -2.0, 5.96875),   # the c3 shape's sparse visits: four waves of lanes per pixel, border pixels on both sides
+    (1, 100, 90, 3, 120, -1.0, 4.0),        # SkysatLR-like: two waves per pixel, 8 idle lanes; every pixel a border pixel
+    (1, 33, 140, 5, 128, -1.0, 2.96875),    # c2
+    (1, 9, 200, 3, 64, -2.0, 5.875),        # one wave per pixel, one trip
+    (1, 40, 70, 2, 300, -0.5, 0.5),         # one wave per pixel, five trips, 20 idle lanes in the last
+    (1, 17, 64, 2, 7, -1.0, 1.0),           # forced where the plan would not choose it: 7 of 64 lanes busy
+    (3, 24, 130, 3, 70, -1.0, 2.0),         # RGB, two waves per pixel (58 idle lanes: forced)
+    (3, 48, 100, 2, 256, -0.5, 1.5),        # RGB, the largest slot count
+    (1, 192, 80, 2, 64, -0.25, 0.25),       # the largest one-channel slot count
+])
+def test_pixel_per_wave_kernel_against_the_oracle(rs, oracle_mod, hooks, C_, S, U, V, D, dmin, dmax):
+    """k2_scan_reg_px: a wave owns one pixel, its lanes the hypotheses (the kernel of the sweep's sparse visits): first
+    maximum over the lanes and waves that share a pixel, double score sum, every plane bit-identical to the oracle and to
+    the pixel-per-lane kernels (row tiles, and packed tiles with hypothesis groups)."""
+    hooks(force_packed=1)
+    hooks(px=1)
+    vol = _vol("struct" if U >= 100 else "noise", U, V, S, C_, 4000 + S + D, dmin, dmax)
+    vol[:, :, U // 2: U // 2 + 3] *= np.float32(0.03)      # a dark band: gaps in the pixel list
+    ref = oracle_mod.depth1d_pile_run(vol, dmin, dmax, D)
+    comp, got = _run(rs, vol, dmin, dmax, D)
+    assert comp.stats.scan_kernel == 1
+    assert_pile_parity(got, ref, label="px_C%d_S%d_D%d" % (C_, S, D))
+    hooks(px=0)
+    hooks(force_groups=2 if D >= 16 else 1)
+    _, other = _run(rs, vol, dmin, dmax, D)
+    hooks(force_packed=0)
+    hooks(force_groups=0)
+    _, rows = _run(rs, vol, dmin, dmax, D)
+    for k in got:
+        assert np.array_equal(got[k], other[k]), k
+        assert np.array_equal(got[k], rows[k]), k

@@ -345,3 +345,21 @@ def test_downsample_u8_c_and_numpy_restatements_agree(oracle_mod):
         assert np.abs(c - oracle_mod.downsample_epis(lev)).max() < 1.0
     flat = np.full((12, 2, 12, 1), 77.0, np.float32)       # a constant image stays constant: the taps sum to 256
     assert np.all(oracle_mod.downsample_epis_u8(flat) == 77.0)
+
+
+def test_selective_median_of_a_pixel_with_no_candidate_is_zero(oracle_mod):
+    """A masked pixel whose centre radiance is NaN passes nobody's radiance test, not even its own: the reference then reads
+    buffer[0] of a vector it has just cleared (core.hpp:713-714, undefined; in practice a stale value).  Defined as 0 in
+    both restatements and in K3 (found by tools/fuzz_parity.py seed 8302 case 4537)."""
+    from oracle import oracle_np as onp
+    rng = np.random.default_rng(12)
+    V, S, U = 6, 3, 9
+    vol = rng.uniform(0.0, 1.0, size=(V, S, U, 1)).astype(np.float32)
+    vol[2, 1, 4, 0] = np.nan
+    src = rng.uniform(-1.0, 1.0, size=(V, U)).astype(np.float32)
+    mask = np.full((V, U), 255, np.uint8)
+    c = oracle_mod.selective_median(src, vol, 1, mask, 5, np.float32(10.0))
+    n = onp.selective_median(src, vol, 1, mask, 5, np.float32(10.0))
+    assert c[2, 4] == 0.0 and n[2, 4] == 0.0
+    assert np.array_equal(c, n)
+    assert np.count_nonzero(c) == V * U - 1      # every other pixel has candidates (and a NaN neighbour is never one)

@@ -67,7 +67,9 @@ def draw_case(rng):
                 opening=(int(rng.choice([0, 1, 2])), int(rng.choice([2, 3, 4, 5, 7]))) if rng.uniform() < 0.15 else (2, 1),
                 # how the light field reaches the device: dense device tensor, host EPIs (f32, scale 1), host EPIs
                 # normalised by their max (dc.hpp:442-460), uint8 EPIs (x/255, dc.hpp:470), uint8 image stack (io.cpp:194-227)
-                form=str(rng.choice(["dense", "dense", "epis_f32", "epis_max", "epis_u8", "images_u8"])))
+                form=str(rng.choice(["dense", "dense", "epis_f32", "epis_max", "epis_u8", "images_u8"])),
+                # packed launches of a register kernel: lanes own hypotheses (k2_scan_reg_px) -- automatic / never / whenever it can run
+                px=int(rng.choice([-1, -1, 0, 1])))
 
 
 def make_volume(c, rng):
@@ -92,7 +94,7 @@ def make_volume(c, rng):
 
 def run_case(i, c, rng):
     # per-context hooks (rslf_ctx_set_debug)
-    rs.default_context(0).set_debug(force_scan=c["force"], force_packed=c["packed"], force_groups=c["groups"])
+    rs.default_context(0).set_debug(force_scan=c["force"], force_packed=c["packed"], force_groups=c["groups"], px=c.get("px", -1))
     vol = make_volume(c, rng)
     V, S, U, C = vol.shape
     po = oracle.default_params()
