@@ -442,7 +442,8 @@ def main() -> None:
                     "24-row crop of data/000.tif tiled to %d scanlines, %d identical views, real edge mask" % (V, S)),
                 "sharding": "none" if world == 1 else "scanline blocks + %d-row recomputed halo, RCCL gather of the output planes per step" % sharding.halo_rows(
                     params.par_median_filter_size, params.par_edge_confidence_opening_size),
-                "scan_kernel": {1: "k2_scan_reg<%d,%d>" % (comp.stats.s_pad, C), 2: "k2_scan_stream<%d>" % C, 3: "k2_scan_chip"}.get(
+                "scan_kernel": {1: "k2_scan_reg<%d,%d>" % (comp.stats.s_pad, C), 2: "k2_scan_stream<%d>" % C, 3: "k2_scan_chip",
+                                4: "k2_scan_reg_px<%d,%d>" % (comp.stats.s_pad, C)}.get(
                     comp.stats.scan_kernel, "k2_scan_generic<%d>" % C),
                 "pixels_scanned": pixels,
             },

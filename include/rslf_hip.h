@@ -113,8 +113,9 @@ typedef struct rslf_stats {
 #define RSLF_SCAN_GENERIC   0  /* any S, C in {1,3}, any sign: re-gathers every mean-shift pass */
 #define RSLF_SCAN_STREAM    2  /* volume >= 0, any S: a resident prefix of the samples (registers + LDS), the rest re-gathered every pass */
 #define RSLF_SCAN_REG       1  /* volume >= 0 and C=1, S<=192 or C=3, S<=48: every sample held in registers */
-#define RSLF_SCAN_CHIP      3  /* volume >= 0, C=3, S>=200, dense launch with one hypothesis grid: one wave per SIMD, every sample
+#define RSLF_SCAN_CHIP      3  /* volume >= 0, C=3, S>=201, dense launch with one hypothesis grid: one wave per SIMD, 198 samples
                                   of a unit on chip (VGPRs + AGPRs + LDS), packed-fp32 passes */
+#define RSLF_SCAN_REG_PX    4  /* RSLF_SCAN_REG's shapes on a packed (sparse) launch: a wave owns one pixel, its lanes the hypotheses */
 
 int         rslf_abi_version(void);
 const char* rslf_status_string(int status);
@@ -132,6 +133,8 @@ int rslf_ctx_synchronize(rslf_ctx* ctx);
  *   "force_scan"     0 automatic | 1 generic scan kernel | 2 streaming scan kernel (never the on-chip one)
  *   "force_groups"   0 automatic | 1..64 hypothesis groups per tile
  *   "force_packed"   -1 automatic | 0 row tiles | 1 one packed pixel list
+ *   "px"             -1 automatic | 0 never | 1 whenever it can run: packed launches of a register kernel put a pixel's
+ *                    HYPOTHESES in the lanes of a wave (k2_scan_reg_px) instead of 64 pixels
  *   "claim_skip"     1 (default) the 2-D sweep's claims skip views with nothing left to paint within reach | 0 off
  *   "stream_share"   1 (default) 63-pixel tiles sharing taps between lanes in the streaming kernel | 0 off
  *   "stream_groups"  0 automatic | hypothesis groups per tile of the streaming kernel's dense launches

@@ -372,7 +372,7 @@ extern "C" int rslf_depth_epi_scan(rslf_ctx* ctx, const rslf_volume* vol, const 
 
     HIP_TRY(hipGetLastError());   // anything an earlier enqueue left behind is not this launch's fault
     ctx->last_spad = spad;
-    ctx->last_kernel = spad ? RSLF_SCAN_REG : use_chip ? RSLF_SCAN_CHIP : (stream_ok ? RSLF_SCAN_STREAM : RSLF_SCAN_GENERIC);
+    ctx->last_kernel = spad ? (sp.px_waves ? RSLF_SCAN_REG_PX : RSLF_SCAN_REG) : use_chip ? RSLF_SCAN_CHIP : (stream_ok ? RSLF_SCAN_STREAM : RSLF_SCAN_GENERIC);
     // The events that time K2 are marker packets of their own: ~5.6 us each before the next kernel starts (measured,
     // tools/probe_gaps.py) -- nothing beside a 66 ms scan, a tenth of a sweep's sparse visit.  A sweep times its first
     // (dense) visit only.

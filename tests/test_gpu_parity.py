@@ -179,7 +179,7 @@ def test_sparse_launch_shapes(rs, oracle_mod, hooks, packed, groups, force, C_, 
     vol = _vol("noise" if C_ == 1 else "struct", U, 5, S, C_, 900 + D, -1.5, 2.5)
     ref = oracle_mod.depth1d_pile_run(vol, -1.5, 2.5, D)
     comp, got = _run(rs, vol, -1.5, 2.5, D)
-    assert comp.stats.scan_kernel == {None: 1, "stream": 2, "generic": 0}[force]
+    assert comp.stats.scan_kernel == {None: 4 if packed == 2 else 1, "stream": 2, "generic": 0}[force]
     assert_pile_parity(got, ref, label="groups%d_packed%d_%s_C%d_D%d" % (groups, packed, force, C_, D))
 
 
@@ -210,7 +210,7 @@ def test_packed_tiles_with_per_pixel_ranges_and_sparse_mask(rs, oracle_mod, hook
     st = rs.compute_1D_depth_epi_pile(v, t(dmin), t(dmax), D, 6, tCe, tcm, tCd, tdepth, trbar, None, tmask, idx_v_u=tidx,
                                       score_v_u=tsc, want_stats=True)
     torch.cuda.synchronize()
-    assert st.scan_kernel == 1
+    assert st.scan_kernel == (4 if px else 1)
     assert st.pixels_scanned == int(np.count_nonzero(cm & mask))
     assert np.array_equal(tidx.cpu().numpy(), ref.depth_idx)
     assert np.array_equal(tsc.cpu().numpy(), ref.score)
@@ -697,11 +697,12 @@ def test_pixel_per_wave_kernel_against_the_oracle(rs, oracle_mod, hooks, C_, S, 
     vol[:, :, U // 2: U // 2 + 3] *= np.float32(0.03)      # a dark band: gaps in the pixel list
     ref = oracle_mod.depth1d_pile_run(vol, dmin, dmax, D)
     comp, got = _run(rs, vol, dmin, dmax, D)
-    assert comp.stats.scan_kernel == 1
+    assert comp.stats.scan_kernel == 4
     assert_pile_parity(got, ref, label="px_C%d_S%d_D%d" % (C_, S, D))
     hooks(px=0)
     hooks(force_groups=2 if D >= 16 else 1)
-    _, other = _run(rs, vol, dmin, dmax, D)
+    comp2, other = _run(rs, vol, dmin, dmax, D)
+    assert comp2.stats.scan_kernel == 1
     hooks(force_packed=0)
     hooks(force_groups=0)
     _, rows = _run(rs, vol, dmin, dmax, D)

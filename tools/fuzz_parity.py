@@ -189,7 +189,7 @@ def main():
         if (i + 1) % 50 == 0:
             print("... %d cases, %d failures, %.0f s" % (i + 1, bad, time.time() - t0), flush=True)
     print("fuzz_parity: %d cases (seed %d), %d failures, %.0f s; %d pixels with a disparity compared; kernel variants of the "
-          "Depth1DComputer_pile cases (0 generic, 1 register, 2 stream, 3 on-chip; -1 = plane form) %s" % (
+          "Depth1DComputer_pile cases (0 generic, 1 register, 2 stream, 3 on-chip, 4 register with hypotheses in the lanes; -1 = plane form) %s" % (
               cases, seed, bad, time.time() - t0, pixels, dict(sorted(kernels.items()))))
     return 1 if bad else 0
 

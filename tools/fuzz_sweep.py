@@ -146,6 +146,9 @@ def main():
             continue
         rng = np.random.default_rng([seed, i])
         which = "f2c" if i % 3 == 2 else "sweep"
+        # the sparse visits' kernel: lanes own hypotheses where the plan says so / never / whenever it can run (a generator of
+        # its own, so the cases themselves are the ones earlier campaigns drew)
+        rs.default_context(0).set_debug(px=int(np.random.default_rng([seed, i, 77]).choice([-1, 0, 1])))
         try:
             pixels += (f2c_case if which == "f2c" else sweep_case)(i, rng)
             n[which] += 1
