@@ -10,7 +10,7 @@
 //     [NV, NV + NA)               in AGPRs, laid out by hand: one v_accvgpr_read_b32 per value and pass (VALU operands cannot name an AGPR)
 //     the next three              fetched AGAIN on every pass (L1 / L2 hits), their loads issued a tier ahead of their use
 //     [NV + NA + 3, .. + NL)      in LDS, [pair][channel][lane] as 8-byte pairs: one conflict-free ds_read_b64 per pair and channel
-//     the rest (none at c5: 64 + 84 + 3 + 50 = 201) re-gathered per pass one by one, as the streaming kernel's tail is
+//     the rest (none at c5: 64 + 84 + 3 + 50 = 201) fetched again per pass too, in pairs, one pair ahead (up to 220 views)
 // -- the 198 gathered ONCE per hypothesis.  (The chip is full to the word: 201 x 3 samples + the wave's running result
 // -- a double sum and the best score in three AGPRs, the best index and rbar in LDS -- is what 192 + 256 registers and
 // 157 words of LDS per lane hold, less two samples.)  A wave alone on its SIMD issues one instruction every ~5 clocks
@@ -46,6 +46,7 @@ constexpr int kChipNV = RSLF_CHIP_NV, kChipNA = RSLF_CHIP_NA, kChipNL = RSLF_CHI
 constexpr int kChipOnChip = kChipNV + kChipNA + kChipNL;   // samples that stay on the chip for a hypothesis
 constexpr int kChipAhead = 3;                              // samples fetched again on every pass, ahead of their use
 constexpr int kChipMinS = kChipOnChip + kChipAhead;
+constexpr int kChipMaxS = 220;                             // beyond, the per-pass fetches cost more than the streaming kernel's tail
 constexpr int kChipBestFloats = 4 * 64;                    // a wave's running index and rbar (ChipBest)
 constexpr size_t kChipLdsBytes = (size_t)160 << 10;        // one workgroup per CU takes all of it
 static_assert(kChipNV % 4 == 0 && kChipNA % 4 == 0 && kChipNL % 2 == 0, "gather batches of four samples, pairs in the pass");
@@ -56,7 +57,7 @@ __host__ __device__ constexpr int chip_wave_floats(int S) { return ((S + 3) & ~3
 // the kernel takes volumes whose on-chip tiers and fetched-ahead slots are all in use and whose per-wave LDS share fits
 __host__ __device__ constexpr bool chip_takes(int S, int C)
 {
-    return C == 3 && S >= kChipMinS && (size_t)chip_wave_floats(S) * 4 * kScanWaves <= kChipLdsBytes;
+    return C == 3 && S >= kChipMinS && S <= kChipMaxS && (size_t)chip_wave_floats(S) * 4 * kScanWaves <= kChipLdsBytes;
 }
 
 // f(integral_constant<int, G>) for G = 0 .. N-1, in order: a loop unrolled by the type system -- `#pragma unroll` leaves the
@@ -299,7 +300,9 @@ struct ChipBest {
 // neighbour's left tap, so a sample costs ONE 12-byte load, the right tap comes from lane + 1 (v_mul_f32_dpp wave_shl:1),
 // and with 4 registers per sample in flight instead of 7 the gather runs TWO batches ahead of its blends -- a wave alone on
 // its SIMD has nobody to hide an L2 round trip behind (the general form, one batch ahead, waits a third of its gather).
-template <bool SHARED>
+// TAIL = false: exactly kChipMinS views (c5's 201): the per-pass fetches of further views are not compiled in (their
+// registers cost the 201-view kernel 0.5 %).
+template <bool SHARED, bool TAIL>
 __device__ __forceinline__ void scan_chip_body(const ScanArgs& a, int v, const ChipTile& t, int d0, int d1, ChipBest& best, float* __restrict__ otab)
 {
     constexpr int C = 3, NV = kChipNV, NA = kChipNA, NL = kChipNL, GB = 4;
@@ -536,38 +539,66 @@ __device__ __forceinline__ void scan_chip_body(const ScanArgs& a, int v, const C
                 pk = chip_pair(q[cur][0], q[cur][1], q[cur][2], m01, m2x, kq2, pk, A, B);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            chip_flush(pk, A, B);
             ncard = card;
             if (BORDER) {
 #pragma unroll
                 for (int k = 0; k < kChipAhead; k++)
                     ncard += xok[k] ? 1 : 0;
             }
-            // what is left: re-gathered on every pass, one sample at a time (none at c5)
+            // What is left (none at c5) is fetched again on every pass, two views at a time and one pair AHEAD: the loads of
+            // views s + 2, s + 3 go out before the pair (s, s + 1) is blended and run through the same packed block as the
+            // tiers.  One view at a time with each load waited for cost 2.6 % of a hypothesis per view and the streaming
+            // kernel overtook this one at 215 views; a pipelined pair costs 2.0 % per view, the crossover is at 220, and
+            // chip_takes leaves more views than that to the streaming kernel (profiles/r03_k2_variants.md section 7).
+            constexpr int T0 = NO + kChipAhead;
+            if (TAIL && S > T0) {   // wave-uniform
+                float ae0[2][C], ae1[2][C], att[2], be0[2][C], be1[2][C], btt[2];
+                bool aok[2], bok[2];
+                auto issue = [&](int s, float (&e0)[2][C], float (&e1)[2][C], float (&tt)[2], bool (&ok)[2]) {
+#pragma unroll
+                    for (int k = 0; k < 2; k++) {
+                        const int sk = min(s + k, S - 1);   // a missing partner repeats the last view (its result is dropped)
+                        taps(otab[sk], (unsigned)sk * stride_b, e0[k], e1[k], tt[k], ok[k]);
+                    }
+                };
+                auto consume = [&](int s, const float (&e0)[2][C], const float (&e1)[2][C], const float (&tt)[2], const bool (&ok)[2]) {
+                    float r[2][C];
+                    blend(e0[0], e1[0], tt[0], ok[0], r[0]);
+                    blend(e0[1], e1[1], tt[1], ok[1], r[1]);
+                    const bool partner = s + 1 < S;   // wave-uniform
+#pragma unroll
+                    for (int c = 0; c < C; c++)
+                        r[1][c] = partner ? r[1][c] : kSentinel;
+                    pk = chip_pair(f2{r[0][0], r[1][0]}, f2{r[0][1], r[1][1]}, f2{r[0][2], r[1][2]}, m01, m2x, kq2, pk, A, B);
+                    if (BORDER)
+                        ncard += (ok[0] ? 1 : 0) + ((partner && ok[1]) ? 1 : 0);
+                };
+                if constexpr (SHARED) {
+                    // (two buffers; a third -- two pairs ahead -- does not fit the registers: 28 B/lane of scratch written per hypothesis)
+                    issue(T0, ae0, ae1, att, aok);
 #pragma unroll 1
-            for (int s = NO + kChipAhead; s < S; s++) {
-                float e0[C], e1[C], tt, r[C], q[C];
-                bool ok;
-                taps(otab[s], (unsigned)s * stride_b, e0, e1, tt, ok);
-                blend(e0, e1, tt, ok, r);
-#pragma unroll
-                for (int c = 0; c < C; c++) {
-                    const float delta = r[c] - rbar[c];     // core.hpp:591
-                    const float tq = a.k.inv_h2 * delta;    // kernels.cpp:43
-                    q[c] = tq * delta;
+                    for (int s = T0; s < S; s += 4) {
+                        if (s + 2 < S)
+                            issue(s + 2, be0, be1, btt, bok);
+                        __builtin_amdgcn_sched_barrier(0);
+                        consume(s, ae0, ae1, att, aok);
+                        if (s + 2 < S) {
+                            if (s + 4 < S)
+                                issue(s + 4, ae0, ae1, att, aok);
+                            __builtin_amdgcn_sched_barrier(0);
+                            consume(s + 2, be0, be1, btt, bok);
+                        }
+                    }
+                } else {
+                    // (border and ragged tiles: seven registers per view in flight -- a pair at a time, nothing ahead)
+#pragma unroll 1
+                    for (int s = T0; s < S; s += 2) {
+                        issue(s, ae0, ae1, att, aok);
+                        consume(s, ae0, ae1, att, aok);
+                    }
                 }
-                float qs = q[0] + q[2];                     // OpenCV 3.x reduceC_: (q0 + q2) + q1
-                qs = qs + q[1];
-                const float Kw = kernel_weight(qs);         // kernels.cpp:51-53
-#pragma unroll
-                for (int c = 0; c < C; c++) {
-                    const float pr = r[c] * Kw;             // core.cpp:36
-                    A[c] = A[c] + pr;                       // core.hpp:602
-                }
-                B = B + Kw;                                 // core.hpp:603
-                if (BORDER)
-                    ncard += ok ? 1 : 0;
             }
+            chip_flush(pk, A, B);
 #pragma unroll
             for (int c = 0; c < C; c++) {
                 const float qd = (B != 0.0f) ? (A[c] / B) : 0.0f;   // core.cpp:50, OpenCV 3.x: /0 -> 0
@@ -587,6 +618,7 @@ __device__ __forceinline__ void scan_chip_body(const ScanArgs& a, int v, const C
 // inside the row for every lane (two pixels of margin, which covers lane 63's extra pixel), and view offsets none of whose
 // fractions is within an ulp of 1 (positions are offset + integer u: the lanes then all floor alike).  Runs of
 // hypotheses of one kind go to one body call, in ascending order: first maximum wins (core.hpp:636-645).
+template <bool TAIL>
 __device__ __forceinline__ void scan_chip_rows(const ScanArgs& a, int v, int e0, int width, int n, int d0, int d1, Best<3>& result, float* otab)
 {
     ChipBest best;
@@ -639,9 +671,9 @@ __device__ __forceinline__ void scan_chip_rows(const ScanArgs& a, int v, int e0,
         while (e < d1 && shared_form(e) == sh)
             e++;
         if (sh)
-            scan_chip_body<true>(a, v, t, d, e, best, otab);
+            scan_chip_body<true, TAIL>(a, v, t, d, e, best, otab);
         else
-            scan_chip_body<false>(a, v, t, d, e, best, otab);
+            scan_chip_body<false, TAIL>(a, v, t, d, e, best, otab);
         d = e;
     }
     best.finish(a, result);
@@ -656,6 +688,7 @@ __device__ __forceinline__ void chip_chunk(const ScanArgs& a, int group, int wav
     d1 = min(d0 + chunk, a.dim_d);
 }
 
+template <bool TAIL>
 __global__ __launch_bounds__(64 * kScanWaves) __attribute__((amdgpu_waves_per_eu(1, 1))) void k2_scan_chip(ScanArgs a)
 {
     constexpr int C = 3;
@@ -673,7 +706,7 @@ __global__ __launch_bounds__(64 * kScanWaves) __attribute__((amdgpu_waves_per_eu
     if (!scan_tile_span(a, lb, v, e0, width, n))
         return;
     chip_chunk(a, lb % a.groups, wave, d0, d1);
-    scan_chip_rows(a, v, e0, width, n, d0, d1, best, otab);
+    scan_chip_rows<TAIL>(a, v, e0, width, n, d0, d1, best, otab);
     asm volatile("" : "+s"(lb));
     int u;
     bool active;

@@ -358,7 +358,9 @@ extern "C" int rslf_depth_epi_scan(rslf_ctx* ctx, const rslf_volume* vol, const 
     }
     const size_t lds = sp.lds_bytes;
     if (use_chip && !ctx->chip_attr_set) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k2_scan_chip), hipFuncAttributeMaxDynamicSharedMemorySize,
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k2_scan_chip<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)kChipLdsBytes));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k2_scan_chip<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)kChipLdsBytes));
         ctx->chip_attr_set = true;
     }
@@ -399,7 +401,10 @@ extern "C" int rslf_depth_epi_scan(rslf_ctx* ctx, const rslf_volume* vol, const 
             if (rc)
                 return rc;
         } else if (use_chip) {
-            hipLaunchKernelGGL(k2_scan_chip, grid, dim3(64 * kScanWaves), lds, st, a);
+            if (vol->S == kChipMinS)   // c5's view count: every view has a place (or a fetched-ahead slot), no ragged tail compiled in
+                hipLaunchKernelGGL(k2_scan_chip<false>, grid, dim3(64 * kScanWaves), lds, st, a);
+            else
+                hipLaunchKernelGGL(k2_scan_chip<true>, grid, dim3(64 * kScanWaves), lds, st, a);
         } else if (use_stream) {
             if (vol->C == 1)
                 hipLaunchKernelGGL(k2_scan_stream<1>, grid, dim3(64 * kScanWaves), lds, st, a);

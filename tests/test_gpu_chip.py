@@ -1,5 +1,5 @@
-"""The on-chip scan kernel (k2_scan_chip, remotesensingproject_amd/csrc/k2_chip.hpp): RGB light fields of 201 views and
-up -- BASELINE.json configs[4]'s 201 -- with 198 samples of a unit held in VGPRs + AGPRs + LDS at one wave per SIMD, three
+"""The on-chip scan kernel (k2_scan_chip, remotesensingproject_amd/csrc/k2_chip.hpp): RGB light fields of 201 to 220
+views -- BASELINE.json configs[4]'s 201 -- with 198 samples of a unit held in VGPRs + AGPRs + LDS at one wave per SIMD, three
 fetched ahead on every pass, and the mean-shift passes in packed fp32.  Bit-exact against the CPU oracle (core.hpp:480-661 restated) on small fields with
 border and interior hypotheses, ragged rows, hypothesis groups and views beyond the tiers; bit-exact against the
 streaming kernel at c5's real row length and hypothesis count."""
@@ -38,7 +38,8 @@ def _run(rs, vol, dmin, dmax, D, **debug):
 @pytest.mark.parametrize("U,V,S,D,dmin,dmax,groups", [
     (200, 3, 201, 12, -0.3, 0.3, 0),     # tile 0 and the last tile are border, the middle one interior for every hypothesis
     (70, 2, 202, 9, -1.0, 1.0, 0),       # one view in the ragged tail; all border
-    (131, 3, 230, 16, -0.25, 0.5, 0),    # 29 views beyond what the chip holds (re-gathered per pass), a ragged last tile
+    (131, 3, 220, 16, -0.25, 0.5, 0),    # 19 views beyond what the chip holds (fetched per pass, in pairs, the odd one last), a ragged last tile
+    (140, 2, 207, 10, -0.5, 0.25, 0),    # six of them: a pair, a pair ahead of it, and one more trip
     (260, 2, 201, 24, -0.2, 0.2, 4),     # hypothesis groups: four workgroups share a tile, the last one merges
     (65, 1, 203, 8, 0.0, 0.0, 0),        # dmin == dmax
 ])
@@ -84,3 +85,8 @@ def test_chip_kernel_leaves_other_launch_shapes_to_the_streaming_kernel(rs):
     assert st.scan_kernel == 2
     _, st = _run(rs, vol[:, :200], -0.3, 0.3, D)          # fewer views than the tiers and the fetched-ahead slots hold
     assert st.scan_kernel == 2
+    more = np.concatenate([vol, vol[:, :20]], axis=1)       # 221 views: beyond, the streaming kernel's tail is the cheaper one
+    _, st = _run(rs, more, -0.3, 0.3, D)
+    assert st.scan_kernel == 2
+    _, st = _run(rs, more[:, :220], -0.3, 0.3, D)
+    assert st.scan_kernel == 3

@@ -53,6 +53,7 @@ def test_c5_traffic_is_within_twice_the_algorithmic_bytes():
 
 def test_on_chip_kernel_has_no_scratch_in_the_resource_table():
     rows = [ln for ln in open(os.path.join(PROF, "r03_resource_table.txt")) if re.match(r"^(rslf::)?k2_scan_chip\b", ln)]
-    assert len(rows) == 1, rows
-    vgpr, sgpr, scratch, occ, lds = [int(x) for x in rows[0].split()[-5:]]
-    assert scratch == 0 and vgpr == 256 and occ == 1
+    assert len(rows) == 2, rows      # <false>: exactly 201 views (c5); <true>: 202 .. 220, the rest fetched per pass
+    for row in rows:
+        vgpr, sgpr, scratch, occ, lds = [int(x) for x in row.split()[-5:]]
+        assert scratch == 0 and vgpr == 256 and occ == 1, row
