@@ -59,3 +59,35 @@ def test_on_chip_kernel_has_no_scratch_in_the_resource_table():
     for row in rows:
         vgpr, sgpr, scratch, occ, lds = [int(x) for x in row.split()[-5:]]
         assert scratch == 0 and vgpr == 256 and occ == 1, row
+
+
+def test_shipped_library_carries_the_scratch_figures_of_the_table():
+    """Not a compile log: the kernels' metadata read back from the built librslf_hip.so (tools/kernel_metadata.py unbundles the
+    gfx950 code objects and parses their amdhsa notes).  The on-chip kernels and the c1 / c2 register kernels have no
+    scratch; where the committed table was generated from this tree, every kernel's scratch in it equals the binary's."""
+    import sys
+    sys.path.insert(0, ROOT)
+    from remotesensingproject_amd import build
+    from tools import kernel_metadata
+    lib = os.path.join(ROOT, "remotesensingproject_amd", "csrc", "librslf_hip.so")
+    if not os.path.exists(lib):
+        build.build()
+    ks = {k.replace("rslf::", ""): v for k, v in kernel_metadata.kernels(lib).items()}
+    assert len(ks) > 100
+    for name in ("k2_scan_chip<false>", "k2_scan_chip<true>", "k2_scan_reg<40, 1>", "k2_scan_reg<16, 1>", "k2_scan_reg_px<40, 1>"):
+        assert ks[name]["private_segment_fixed_size"] == 0, (name, ks[name])
+    assert ks["k2_scan_chip<false>"]["agpr_count"] == 256
+    table = open(os.path.join(PROF, "r03_resource_table.txt")).read().splitlines()
+    if table[0].strip() != "# source hash %s" % build.source_hash():
+        warnings.warn("the resource table is of another tree: not compared with this binary")
+        return
+    seen = 0
+    for ln in table[2:]:
+        f = ln.split()
+        if len(f) < 6:      # nameless rows (compiler-generated helpers), the library's path on the last line
+            continue
+        name = " ".join(f[:-5]).replace("rslf::", "")
+        if name in ks:
+            assert int(f[-3]) == ks[name]["private_segment_fixed_size"], (name, ln, ks[name])
+            seen += 1
+    assert seen > 80, seen
