@@ -281,24 +281,27 @@ def test_sweep_steps_enforce_the_reference_order_and_recover(rs):
 
 
 def test_sweep_group_merge_is_exact_at_scale(rs):
-    """The sparse visits' hypothesis groups hand their records from workgroup to workgroup across XCDs (agent-coherent
-    stores and loads, a ticket per tile, the group count settled on the device): on a c2-sized sweep whose views
-    disagree enough for ~10^5 pixels to be scanned on sparse visits, every plane must equal the run that never splits
-    a tile's hypotheses (force_groups = 1: no records, no merge)."""
+    """The sparse visits at scale, in their three forms: lanes that own hypotheses (k2_scan_reg_px, what a sweep takes since
+    round 3), and the pixel-per-lane kernel whose hypothesis groups hand their records from workgroup to workgroup across
+    XCDs (agent-coherent stores and loads, a ticket per tile, the group count settled on the device) -- on a c2-sized
+    sweep whose views disagree enough for ~10^5 pixels to be scanned on sparse visits, every plane must equal the run that
+    never splits a tile's hypotheses (px = 0, force_groups = 1: no records, no merge)."""
     import torch
     from remotesensingproject_amd.synth import make_lightfield
     vol, _ = make_lightfield(512, 256, 17, 1, seed=123, dmin=-2.0, dmax=2.0, band=16)
     rng = np.random.default_rng(5)
     vol = (vol + rng.normal(0.0, 0.04, size=vol.shape)).clip(0.0, 1.0).astype(np.float32)   # propagation fails for many pixels
     out = []
-    for hooks in ({}, dict(force_groups=1)):
+    for hooks, kernel in (({}, 4), (dict(px=0), 1), (dict(px=0, force_groups=1), 1)):
         ctx = rs.Context(0)
         ctx.set_debug(**hooks)
         comp = rs.Depth2DComputer(rs.Volume.from_dense(torch.from_numpy(vol).cuda(), 1.0, ctx), -2.0, 2.0, 128, ctx=ctx)
         comp.run()
+        assert comp.stats.scan_kernel == kernel, (hooks, comp.stats.scan_kernel)      # the kernel of the LAST visit's scan
         out.append((comp.results(), int(comp.stats.pixels_scanned)))
         ctx.reset_debug()
-    (a, na), (b, nb) = out
-    assert na == nb and na > 256 * 512 + 50000, na          # well beyond the dense first visit
+    (a, na), (b, nb), (c, nc) = out
+    assert na == nb == nc and na > 256 * 512 + 50000, na          # well beyond the dense first visit
     for k in a:
         assert np.array_equal(a[k], b[k]), k
+        assert np.array_equal(a[k], c[k]), k
