@@ -86,17 +86,24 @@ def source_hash() -> str:
 
 def build_variant(name: str, defines: list[str]) -> str:
     """A/B builds (developer tool): the library with extra -D flags, as ab/librslf_<name>.so (git-ignored; it travels to
-    the GPU box).  Only the scan unit takes the defines; the other objects are the in-tree ones."""
-    build()
+    the GPU box).  EVERY translation unit is compiled with the defines (the first version passed them to the scan unit
+    only: an A/B of a macro that lives in the sweep's kernels then compared a build with itself)."""
+    import concurrent.futures
     out_dir = os.path.join(os.path.dirname(HERE), "ab")
     os.makedirs(out_dir, exist_ok=True)
-    obj = os.path.join(OBJ, "rslf_pile_%s.o" % name)
-    r = subprocess.run([_hipcc()] + HIPCC_FLAGS + ["-D" + d for d in defines] + ["-I", INCLUDE, "-c", "rslf_pile.hip", "-o", obj],
-                       cwd=CSRC, capture_output=True, text=True)
-    if r.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + r.stderr[-4000:])
+    os.makedirs(OBJ, exist_ok=True)
+
+    def compile_unit(u: str) -> str:
+        obj = os.path.join(OBJ, "%s_%s.o" % (os.path.splitext(u)[0], name))
+        r = subprocess.run([_hipcc()] + HIPCC_FLAGS + ["-D" + d for d in defines] + ["-I", INCLUDE, "-c", u, "-o", obj],
+                           cwd=CSRC, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed on %s:\n%s" % (u, r.stderr[-4000:]))
+        return obj
+
+    with concurrent.futures.ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(compile_unit, SOURCES))
     so = os.path.join(out_dir, "librslf_%s.so" % name)
-    objs = [obj if u == "rslf_pile.hip" else _obj(u) for u in SOURCES]
     r = subprocess.run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so] + objs, cwd=CSRC, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n" + r.stderr[-4000:])
