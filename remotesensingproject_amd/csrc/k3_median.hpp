@@ -46,7 +46,8 @@ __device__ __forceinline__ float selective_median_pixel(const VolView& vol, cons
         for (int j = 0; j < kMedianMaxSize; j++) {
             const bool in = l0 + j < l1;
             const int l = in ? l0 + j : l0;
-            mk[j] = in ? mask[rowo + l] : (uint8_t)0;
+            mk[j] = mask[rowo + l];                 // (unconditional, gated afterwards: see the 5 x 5 form)
+            mk[j] = in ? mk[j] : (uint8_t)0;
             sv[j] = src[rowo + l];
 #pragma unroll
             for (int c = 0; c < C; c++)
@@ -121,7 +122,10 @@ __device__ __forceinline__ float selective_median_pixel_5x5(const VolView& vol, 
             const int l = u - W / 2 + j;
             const bool in = kin && l >= 0 && l < U;
             const int lc = in ? l : u;
-            mk[j] = in ? mask[rowo + lc] : (uint8_t)0;
+            // (loaded unconditionally, at the clamped column, and gated afterwards: `in ? mask[..] : 0` became a branch
+            // around the load and a full wait behind it -- 25 round trips one after the other per pixel)
+            mk[j] = mask[rowo + lc];
+            mk[j] = in ? mk[j] : (uint8_t)0;
             sv[j] = src[rowo + lc];
 #pragma unroll
             for (int c = 0; c < C; c++)

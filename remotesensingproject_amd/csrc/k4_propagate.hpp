@@ -54,6 +54,10 @@ __device__ __forceinline__ void propagate_claim_pixel(const VolView& vol, int s_
         static_assert(64 % B == 0, "a batch of views sits in one word of the live-view bits");
         if (live_views && ((live_views[s0 >> 6] >> (s0 & 63)) & ((1ull << B) - 1ull)) == 0)
             continue;   // workgroup-uniform: nothing left to paint in these views within the workgroup's reach
+        // (every load below is UNCONDITIONAL, its address clamped into the row: a load under `if (live)` sits in a basic
+        // block of its own and hipcc waits for it there -- eight round trips one after the other per batch where this
+        // was written to have eight in flight; k34_median_claim 217 -> 160 us per visit of a c3 sweep)
+        uint8_t mb[B];
 #pragma unroll
         for (int j = 0; j < B; j++) {
             const int s = s0 + j;
@@ -62,18 +66,26 @@ __device__ __forceinline__ void propagate_claim_pixel(const VolView& vol, int s_
             off = off * slope;
             ri[j] = u + (int)roundf(off);
             live[j] = source && s < vol.S && ri[j] >= 0 && ri[j] < vol.U;
-            if (live[j])
-                live[j] = mask_svu[(long long)s * plane + row + ri[j]] != 0;
+            ri[j] = min(max(ri[j], 0), vol.U - 1);
+            mb[j] = mask_svu[(long long)min(s, vol.S - 1) * plane + row + ri[j]];
         }
+        bool any = false;
+#pragma unroll
+        for (int j = 0; j < B; j++) {
+            live[j] = live[j] && mb[j] != 0;
+            any |= live[j];
+        }
+        if (!__any(any))
+            continue;   // wave-uniform: nobody in this wave has an unpainted target in these views
         float e[B][C];
 #pragma unroll
         for (int j = 0; j < B; j++) {
-            if (live[j]) {
-                const float* er = vol.row(v, s0 + j);
+            // (a lane without a live target in view s0 + j reads its own column: the line its neighbours read)
+            const float* er = vol.row(v, min(s0 + j, vol.S - 1));
+            const int col = live[j] ? ri[j] : u;
 #pragma unroll
-                for (int c = 0; c < C; c++)
-                    e[j][c] = er[ri[j] * C + c];
-            }
+            for (int c = 0; c < C; c++)
+                e[j][c] = er[col * C + c];
         }
 #pragma unroll
         for (int j = 0; j < B; j++) {
@@ -153,9 +165,17 @@ __global__ __launch_bounds__(256) void k34_median_claim(VolView vol, int s_hat, 
                 const float a0 = cur_lo * k, a1 = cur_hi * k;
                 const int lo = max(0, (int)floorf((float)u_first + fminf(a0, a1) - 1.5f)) >> 8;
                 const int hi = min(vol.U - 1, max(0, (int)ceilf((float)(u_first + 255) + fmaxf(a0, a1) + 1.5f))) >> 8;
+                // eight segments' counts at a time, every load issued before the first is looked at
                 const int* rr = remain + ((long long)s * vol.V + v) * nseg;
-                for (int g = lo; g <= hi; g++)
-                    any |= rr[g] != 0;
+                for (int g0 = lo; g0 <= hi; g0 += 8) {
+                    int r8[8];
+#pragma unroll
+                    for (int k = 0; k < 8; k++)
+                        r8[k] = rr[min(g0 + k, hi)];
+#pragma unroll
+                    for (int k = 0; k < 8; k++)
+                        any |= r8[k] != 0;
+                }
             }
             const unsigned long long b = __ballot(any);
             if ((threadIdx.x & 63) == 0)
