@@ -64,7 +64,7 @@ typedef struct rslf_params {
     int   edge_confidence_opening_type; /* cv::MORPH_RECT 0 / MORPH_CROSS 1 / MORPH_ELLIPSE 2 (default) */
     int   edge_confidence_opening_size; /* 1 = no morphological opening (default); k in 2..31: cv::morphologyEx(MORPH_OPEN)
                                            with getStructuringElement(type, Size(k, k)) on the edge mask (core.hpp:759-768) */
-    int   median_filter_size;           /* 5 (odd, <= 7) */
+    int   median_filter_size;           /* 5; any size >= 0: window half-width (size - 1) / 2, core.hpp:686 */
     float median_filter_epsilon;        /* 0.1 */
     float propagation_epsilon;          /* 0.1 (unused by this path) */
     float slope_factor;                 /* 1.0 */
@@ -138,8 +138,14 @@ int rslf_ctx_synchronize(rslf_ctx* ctx);
  *   "claim_skip"     1 (default) the 2-D sweep's claims skip views with nothing left to paint within reach | 0 off
  *   "stream_share"   1 (default) 63-pixel tiles sharing taps between lanes in the streaming kernel | 0 off
  *   "stream_groups"  0 automatic | hypothesis groups per tile of the streaming kernel's dense launches
- *   "stream_lds_kib" dynamic LDS of one streaming workgroup, KiB (default 72)
- * Results never depend on these (the parity tests drive every combination); speed does. */
+ *   "stream_lds_kib" dynamic LDS of one streaming workgroup, KiB (default 80)
+ * Results do not depend on these (the parity tests drive every combination; "claim_skip" on / off is compared plane by
+ * plane in tests/test_gpu_sweep2d.py); speed does.  One qualification: the disparity confidence C_d = C_e * |max - mean of
+ * the scores| takes the mean through a double sum whose ORDER differs between launch shapes (per wave in the row kernels,
+ * a butterfly over lanes in k2_scan_reg_px / k2_scan_stream_px); sums of <= 4096 floats in [0, 1] are exact in a double
+ * unless a score is below 2^-21, so C_d of two launch shapes is equal to within 1e-5 (the tolerance the reference's float
+ * output is held to), not guaranteed bitwise.  Every other plane -- masks, arg-max indices, disparities, scores, r-bar,
+ * C_e -- is bit-identical whatever the hooks say. */
 int rslf_ctx_set_debug(rslf_ctx* ctx, const char* key, int value);
 /* Fault injection for the tests of the error paths (process-wide, off unless armed): the next `count` visits of `site`
  * fail as if the runtime had -- "worker": a device worker of rslf_multi_* throws std::runtime_error; "thread_create":

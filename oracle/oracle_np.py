@@ -241,7 +241,7 @@ def depth_epi(epi, dmin_u, dmax_u, D, s_hat, Ce_u, Ce_mask_u, p, mask_u=None):
 def selective_median(src, vol, s_hat, mask, size, eps):
     """core.hpp:663-718. vol [V,S,U,C]."""
     V, S, U, C = vol.shape
-    w = (size - 1) // 2
+    w = int((size - 1) / 2)                                  # core.hpp:686: C++ division truncates (size 0 -> 0)
     dst = np.zeros((V, U), F)
     ref = vol[:, s_hat]                                      # [V,U,C]
     for v in range(V):

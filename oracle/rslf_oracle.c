@@ -737,7 +737,10 @@ void oracle_selective_median(const float* src_vu, float* dst_vu,
     const int width = (size - 1) / 2; /* core.hpp:686 */
 #pragma omp parallel for schedule(static)
     for (int v = 0; v < V; v++) {
-        float* buf = (float*)malloc(sizeof(float) * (size_t)size * size);
+        /* the window holds at most (2*width+1)^2 pixels and never more than the image (size 0: width 0, one pixel) */
+        const long long side = 2 * (long long)(width < 0 ? 0 : width) + 1;
+        const size_t side_v = side < V ? (size_t)side : (size_t)V, side_u = side < U ? (size_t)side : (size_t)U;
+        float* buf = (float*)malloc(sizeof(float) * side_v * side_u);
         for (int u = 0; u < U; u++) {
             if (!mask_vu[(size_t)v * U + u]) /* core.hpp:695 */
                 continue;

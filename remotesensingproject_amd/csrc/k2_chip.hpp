@@ -80,7 +80,10 @@ struct ChipUnroll<N, N> {
 // The 256 AGPRs are laid out BY HAND: sample i of the AGPR tier has its channels in a[3i .. 3i + 2], a253:a254 hold a
 // lane's running score sum (a double) and a255 its best score (ChipBest, below).  The register numbers are template
 // constants printed into the instruction text ("a%c[n]"), and every statement that touches one lists ALL of them as
-// clobbered, so hipcc keeps nothing of its own there.  (Left to the allocator as "a"-constrained values, 252 + 3 of 256
+// clobbered.  A clobber list binds the allocator across that one statement only -- between statements it could still park
+// a value of its own in an AGPR -- so the layout is VERIFIED PER BUILD, not guaranteed: tests/test_isa_cpu.py disassembles
+// the shipped kernel and requires exactly the accumulator reads and writes written here, none moved, none named by any
+// other instruction.  (Left to the allocator as "a"-constrained values, 252 + 3 of 256
 // was more than it could colour: it spilled an AGPR value per hypothesis in one build and five in the next.)
 #define RSLF_CHIP_AGPRS \
     "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", \

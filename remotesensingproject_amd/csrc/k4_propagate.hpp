@@ -35,7 +35,7 @@ template <int C>
 __device__ __forceinline__ void propagate_claim_pixel(const VolView& vol, int s_hat, int v, int u, float cur, bool source,
                                                       const float* __restrict__ rbar_vu, const uint8_t* __restrict__ mask_svu,
                                                       int* __restrict__ winner_svu, uint8_t* __restrict__ dirty, float slope,
-                                                      float prop_eps, const unsigned long long* live_views)
+                                                      const plan::NormThreshold& prop_thr, const unsigned long long* live_views)
 {
     const int nseg = (vol.U + 255) >> 8;
     const long long o = (long long)v * vol.U + u;
@@ -82,7 +82,7 @@ __device__ __forceinline__ void propagate_claim_pixel(const VolView& vol, int s_
         for (int j = 0; j < B; j++) {
             // (a lane without a live target in view s0 + j reads its own column: the line its neighbours read)
             const float* er = vol.row(v, min(s0 + j, vol.S - 1));
-            const int col = live[j] ? ri[j] : u;
+            const int col = live[j] ? ri[j] : min(u, vol.U - 1);   // (a lane past the row's end: the last column, not the pitch's padding)
 #pragma unroll
             for (int c = 0; c < C; c++)
                 e[j][c] = er[col * C + c];
@@ -95,8 +95,7 @@ __device__ __forceinline__ void propagate_claim_pixel(const VolView& vol, int s_
 #pragma unroll
             for (int c = 0; c < C; c++)
                 df[c] = e[j][c] - rb[c];
-            const float nr = (C == 1) ? norm1(df[0]) : norm3(df[0], df[C > 1 ? 1 : 0], df[C > 2 ? 2 : 0]);
-            if (nr < prop_eps) {   // core.hpp:1116
+            if (norm_below<C>(df, prop_thr)) {   // core.hpp:1116: norm<T>(..) < par_propagation_epsilon
                 atomicMin(&winner_svu[(long long)(s0 + j) * plane + row + ri[j]], u);
                 dirty[((long long)(s0 + j) * vol.V + v) * nseg + (ri[j] >> 8)] = 1;   // this 256-column segment holds a claim
             }
@@ -107,12 +106,12 @@ __device__ __forceinline__ void propagate_claim_pixel(const VolView& vol, int s_
 // K3 + claim in one launch (a sweep visit): a pixel's median needs its neighbours' RAW depths only (what the scan
 // left), and its claims need its own median only -- so the thread that filters a pixel also makes its claims.  The
 // filtered plane is still written: the apply pass reads the winners' values from it.
-template <int C>
+template <int C, int MODE>
 __global__ __launch_bounds__(256) void k34_median_claim(VolView vol, int s_hat, const float* __restrict__ raw_vu,
                                                        float* __restrict__ filtered_vu, const uint8_t* __restrict__ edge_mask_vu,
-                                                       int size, float eps, const float* __restrict__ rbar_vu,
+                                                       int w, plan::NormThreshold median_thr, const float* __restrict__ rbar_vu,
                                                        const uint8_t* __restrict__ mask_svu, int* __restrict__ winner_svu,
-                                                       uint8_t* __restrict__ dirty, float slope, float prop_eps,
+                                                       uint8_t* __restrict__ dirty, float slope, plan::NormThreshold prop_thr,
                                                        const float* __restrict__ gate_Cd_vu, float disp_thr, int* __restrict__ reset,
                                                        const int* __restrict__ remain)
 {
@@ -120,19 +119,17 @@ __global__ __launch_bounds__(256) void k34_median_claim(VolView vol, int s_hat, 
     // it counts up again from 0
     if (reset && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
         *reset = 0;
-    extern __shared__ __attribute__((aligned(16))) float s_median_cand[];   // [size*size][256]
-    float (*cand)[256] = reinterpret_cast<float (*)[256]>(s_median_cand);
+    static_assert(kMedianBlock == 256, "one median tile per claim workgroup");
+    extern __shared__ __attribute__((aligned(16))) float s_median_tile[];   // the window tile (k3_median.hpp)
     const int v = blockIdx.y;
     const int u_first = blockIdx.x * blockDim.x;
     const int u = u_first + threadIdx.x;
     const bool inside = u < vol.U;
     const long long o = (long long)v * vol.U + (inside ? u : vol.U - 1);
     // core.hpp:678-679, :881-892: the median over the edge mask, 0 elsewhere
-    float cur = 0.0f;
-    if (inside) {
-        cur = edge_mask_vu[o] ? selective_median_any<C>(vol, raw_vu, edge_mask_vu, s_hat, size, eps, v, u, cand) : 0.0f;
+    const float cur = selective_median_block<C, MODE>(vol, raw_vu, edge_mask_vu, s_hat, w, median_thr, v, u_first, s_median_tile);
+    if (inside)
         filtered_vu[o] = cur;
-    }
     const bool source = inside && (gate_Cd_vu ? gate_Cd_vu[o] > disp_thr : edge_mask_vu[o] != 0);   // core.hpp:1097-1103
     // the range of the disparities the workgroup's sources hold (a non-finite one: everywhere)
     __shared__ float s_lo[4], s_hi[4];
@@ -183,7 +180,7 @@ __global__ __launch_bounds__(256) void k34_median_claim(VolView vol, int s_hat, 
         }
         __syncthreads();
     }
-    propagate_claim_pixel<C>(vol, s_hat, v, u, cur, source, rbar_vu, mask_svu, winner_svu, dirty, slope, prop_eps, skipping ? s_live : nullptr);
+    propagate_claim_pixel<C>(vol, s_hat, v, u, cur, source, rbar_vu, mask_svu, winner_svu, dirty, slope, prop_thr, skipping ? s_live : nullptr);
 }
 
 // The apply pass of a visit (core.hpp:1119-1127) and, in the same launch, the pixel list of the NEXT visit's scan: one

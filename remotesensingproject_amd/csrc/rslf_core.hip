@@ -176,8 +176,10 @@ int rslf::check_params(const rslf_params* p)
                     p->edge_confidence_opening_type);
     if (p->edge_confidence_filter_size < 1 || (p->edge_confidence_filter_size & 1) == 0)
         return fail(RSLF_ERR_INVALID_ARG, "edge_confidence_filter_size must be odd and >= 1");
-    if (p->median_filter_size < 1 || (p->median_filter_size & 1) == 0 || p->median_filter_size > kMedianMaxSize)
-        return fail(RSLF_ERR_UNSUPPORTED, "median_filter_size must be odd and <= %d", kMedianMaxSize);
+    // any window the reference runs: width = (size - 1) / 2 (core.hpp:686), so even sizes and 0 are fine; a negative size
+    // has no window at all (the reference then reads an empty vector, core.hpp:713-714)
+    if (p->median_filter_size < 0 || p->median_filter_size > plan::kMedianMaxSize)
+        return fail(RSLF_ERR_INVALID_ARG, "median_filter_size=%d: must be in [0, %d]", p->median_filter_size, plan::kMedianMaxSize);
     if (!(p->kernel_bandwidth > 0.0f))
         return fail(RSLF_ERR_INVALID_ARG, "kernel_bandwidth must be > 0");
     if (!(p->mean_shift_max_iter > 0.0f))
@@ -217,7 +219,7 @@ extern "C" int rslf_ctx_create(int device, rslf_ctx** out) RSLF_API_TRY
     if (e == hipSuccess)
         e = hipEventCreate(&ctx->ev1);
     if (e != hipSuccess) {
-        delete ctx;
+        (void)rslf_ctx_destroy(ctx);   // frees whatever of total / minmax / the events was made
         return fail(RSLF_ERR_HIP, "context setup failed: %s", hipGetErrorString(e));
     }
     *out = ctx;

@@ -97,6 +97,12 @@ extern "C" int rslf_multi_create(const int* devices, int n_devices, rslf_multi**
     // pair does not allow it hipMemcpyPeerAsync still works, staged through the host: correct, slower, and reported by
     // rslf_multi_peer_access (tools/multi_gpu_selftest.py prints the matrix).
     m->peer.assign((size_t)n * n, 0);
+    int caller_device = -1;
+    (void)hipGetDevice(&caller_device);   // enabling peers selects devices in turn: the caller's current one is put back
+    struct RestoreDevice {
+        int dev;
+        ~RestoreDevice() { if (dev >= 0) (void)hipSetDevice(dev); }
+    } restore{caller_device};
     for (int i = 0; i < n; i++)
         for (int k = 0; k < n; k++) {
             const int di = m->devs[(size_t)i].ctx->device, dk = m->devs[(size_t)k].ctx->device;

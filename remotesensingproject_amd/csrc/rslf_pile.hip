@@ -101,19 +101,29 @@ extern "C" int rslf_selective_median(rslf_ctx* ctx, const rslf_volume* vol, cons
         return fail(RSLF_ERR_INVALID_ARG, "NULL argument");
     if (d_src_vu == d_dst_vu)
         return fail(RSLF_ERR_INVALID_ARG, "selective median cannot run in place");
-    if (size < 1 || (size & 1) == 0 || size > kMedianMaxSize)
-        return fail(RSLF_ERR_UNSUPPORTED, "median size must be odd and <= %d", kMedianMaxSize);
+    if (size < 0 || size > plan::kMedianMaxSize)
+        return fail(RSLF_ERR_INVALID_ARG, "median size %d: must be in [0, %d] (width = (size - 1) / 2, core.hpp:686)", size, plan::kMedianMaxSize);
     if (s_hat < 0 || s_hat >= vol->S)
         return fail(RSLF_ERR_INVALID_ARG, "s_hat=%d outside [0,%d)", s_hat, vol->S);
     HIP_TRY(hipSetDevice(ctx->device));
-    const dim3 grid((vol->U + 255) / 256, vol->V);
-    const size_t lds = size == 5 ? 0 : (size_t)size * size * 256 * sizeof(float);   // one candidate slot per window pixel and thread (5 x 5 sorts in registers)
-    if (vol->C == 1)
-        hipLaunchKernelGGL(k3_selective_median<1>, grid, dim3(256), lds, ctx->stream, view_of(vol), d_src_vu, d_dst_vu, d_mask_vu,
-                           s_hat, size, epsilon);
-    else
-        hipLaunchKernelGGL(k3_selective_median<3>, grid, dim3(256), lds, ctx->stream, view_of(vol), d_src_vu, d_dst_vu, d_mask_vu,
-                           s_hat, size, epsilon);
+    const plan::MedianPlan mp = plan::median_plan(size, vol->C);
+    const plan::NormThreshold thr = plan::norm_threshold(epsilon);
+    const dim3 grid((vol->U + kMedianBlock - 1) / kMedianBlock, vol->V);
+    bool launched = false;
+#define RSLF_K3_CASE(CC, MODE)                                                                                                   \
+    if (!launched && vol->C == CC && mp.mode == MODE) {                                                                           \
+        if (mp.lds_bytes > ((size_t)64 << 10))                                                                                    \
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k3_selective_median<CC, MODE>),                           \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)mp.lds_bytes));                         \
+        hipLaunchKernelGGL((k3_selective_median<CC, MODE>), grid, dim3(kMedianBlock), mp.lds_bytes, ctx->stream, view_of(vol), d_src_vu, \
+                           d_dst_vu, d_mask_vu, s_hat, mp.w, thr);                                                                \
+        launched = true;                                                                                                          \
+    }
+    RSLF_MEDIAN_MODES(RSLF_K3_CASE, 1)
+    RSLF_MEDIAN_MODES(RSLF_K3_CASE, 3)
+#undef RSLF_K3_CASE
+    if (!launched)
+        return fail(RSLF_ERR_INTERNAL, "no selective-median kernel for %d channels, mode %d", vol->C, mp.mode);
     HIP_TRY(hipGetLastError());
     return RSLF_OK;
 }

@@ -12,6 +12,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <string.h>
+
 #include <algorithm>
 #include <cmath>
 #include <vector>
@@ -23,8 +25,6 @@ struct MorphElement {
     int k;
     unsigned rows[31];
 };
-
-constexpr int kMedianMaxSize = 7;   // selective median: window side; 49 candidate slots per thread (k3_median.hpp)
 
 namespace plan {
 
@@ -175,12 +175,92 @@ inline std::vector<LevelDims> f2c_pyramid(int V, int U, int max_depth)
     return levels;
 }
 
+// ---- the selective median (core.hpp:663-718; k3_median.hpp) -------------------------------------------------------
+
+constexpr int kMedianBlock = 256;          // pixels of one scanline per workgroup
+constexpr int kMedianNetMaxSide = 11;      // window sides up to this sort their slots in registers
+constexpr int kMedianTileMaxSide = 31;     // ... up to this keep the window tile in LDS (one predicate word per window row)
+constexpr int kMedianMaxSize = 1 << 30;    // sizes past this are refused as invalid (v + width must stay an int)
+
+// core.hpp:686: `int width = (a_size-1)/2;` -- C++ division truncates, so size 0 is the 1 x 1 window too
+inline int median_width(int size) { return (size - 1) / 2; }
+
+// floats of dynamic LDS a median workgroup needs for window half-width w: depths + C radiance planes of the tile
+inline size_t median_lds_bytes(int w, int C)
+{
+    return (size_t)(1 + C) * (size_t)(2 * w + 1) * (size_t)(kMedianBlock + 2 * w) * sizeof(float);
+}
+
+struct MedianPlan {
+    int w;             // window half-width
+    int mode;          // > 0: window side of the register network; 0: LDS tile + radix select; < 0: global radix select
+    size_t lds_bytes;
+};
+
+inline MedianPlan median_plan(int size, int C)
+{
+    MedianPlan m;
+    m.w = std::max(0, median_width(size));
+    const int side = 2 * m.w + 1;
+    m.mode = side <= kMedianNetMaxSide ? side : side <= kMedianTileMaxSide ? 0 : -1;
+    m.lds_bytes = m.mode >= 0 ? median_lds_bytes(m.w, C) : 0;
+    return m;
+}
+
+// norm<T>(x) < eps (src/rslf_types.cpp:80-91; core.hpp:703-706, :1116) as ONE compare, exactly.
+//   1 channel:  float(double(|x|) * 1.73205080757) < eps   -- non-decreasing in |x|  <=>  |x| < a1
+//   3 channels: float(sqrt(s)) < eps, s = the double sum of squares  -- non-decreasing in s  <=>  s < s3
+// a1 / s3 = the smallest non-negative float / double for which the test FAILS, found by bisection over bit patterns
+// (ordered like the values).  eps <= 0 or NaN: nothing passes (a1 = s3 = 0).  The kernels then need no double multiply
+// (1 channel) and no double square root (3 channels) per window pixel.
+struct NormThreshold {
+    float a1;
+    double s3;
+};
+
+inline bool norm1_below(float ax, float eps) { return (float)((double)ax * 1.73205080757) < eps; }
+inline bool norm3_below(double s, float eps) { return (float)std::sqrt(s) < eps; }
+
+inline NormThreshold norm_threshold(float eps)
+{
+    NormThreshold t;
+    t.a1 = 0.0f;
+    t.s3 = 0.0;
+    if (norm1_below(0.0f, eps)) {
+        uint32_t lo = 0u, hi = 0x7F800000u;   // test(lo) true; test(+inf) false: float(inf) < eps never holds
+        while (hi - lo > 1) {
+            const uint32_t mid = lo + (hi - lo) / 2;
+            float x;
+            memcpy(&x, &mid, sizeof x);
+            if (norm1_below(x, eps))
+                lo = mid;
+            else
+                hi = mid;
+        }
+        memcpy(&t.a1, &hi, sizeof hi);
+    }
+    if (norm3_below(0.0, eps)) {
+        uint64_t lo = 0u, hi = 0x7FF0000000000000ull;
+        while (hi - lo > 1) {
+            const uint64_t mid = lo + (hi - lo) / 2;
+            double x;
+            memcpy(&x, &mid, sizeof x);
+            if (norm3_below(x, eps))
+                lo = mid;
+            else
+                hi = mid;
+        }
+        memcpy(&t.s3, &hi, sizeof hi);
+    }
+    return t;
+}
+
 // ---- scanline partitions ------------------------------------------------------------------------------------------
 
 // rows either side of a block that must be recomputed (pile path) or exchanged (sweep) for the block's own rows to come
 // out exact: the median reads +-(size-1)/2 rows (core.hpp:686), and through the optional opening +-2*(k/2) rows more
 // (core.hpp:759-768)
-inline int median_halo(int median_filter_size) { return (median_filter_size - 1) / 2; }
+inline int median_halo(int median_filter_size) { return std::max(0, median_width(median_filter_size)); }
 inline int halo_rows(int median_filter_size, int opening_size)
 {
     return median_halo(median_filter_size) + (opening_size > 1 ? 2 * (opening_size / 2) : 0);

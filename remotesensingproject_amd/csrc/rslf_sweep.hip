@@ -166,8 +166,8 @@ extern "C" int rslf_sweep_visit_finish(rslf_ctx* ctx, const rslf_volume* vol, in
         return fail(RSLF_ERR_INVALID_ARG, "rslf_sweep_visit_finish without rslf_sweep_begin");
     if (s_hat != ctx->sweep_expect)
         return fail(RSLF_ERR_INVALID_ARG, "rslf_sweep_visit_finish(%d): the open visit is view %d", s_hat, ctx->sweep_expect);
-    if (p->median_filter_size < 1 || (p->median_filter_size & 1) == 0 || p->median_filter_size > kMedianMaxSize)
-        return fail(RSLF_ERR_UNSUPPORTED, "median size must be odd and <= %d", kMedianMaxSize);
+    if (p->median_filter_size < 0 || p->median_filter_size > plan::kMedianMaxSize)
+        return fail(RSLF_ERR_INVALID_ARG, "median_filter_size=%d: must be in [0, %d]", p->median_filter_size, plan::kMedianMaxSize);
     HIP_TRY(hipSetDevice(ctx->device));
     const int S = vol->S, V = vol->V, U = vol->U, C = vol->C;
     const size_t n = (size_t)V * U;
@@ -176,8 +176,9 @@ extern "C" int rslf_sweep_visit_finish(rslf_ctx* ctx, const rslf_volume* vol, in
     const dim3 grid_vu((U + 255) / 256, V);
     if ((long long)S * V > (1ll << 31) - 1 || U > 65536)
         return fail(RSLF_ERR_UNSUPPORTED, "%d views x %d scanlines x %d columns: too large for one apply launch", S, V, U);
-    // the 5 x 5 window sorts in registers (selective_median_pixel_5x5); other sizes keep their candidates in LDS
-    const size_t median_lds = p->median_filter_size == 5 ? 0 : (size_t)p->median_filter_size * p->median_filter_size * 256 * sizeof(float);
+    const plan::MedianPlan mp = plan::median_plan(p->median_filter_size, C);   // window tile in LDS (k3_median.hpp)
+    const plan::NormThreshold median_thr = plan::norm_threshold(p->median_filter_epsilon);
+    const plan::NormThreshold prop_thr = plan::norm_threshold(p->propagation_epsilon);
     int* packed_n = reinterpret_cast<int*>(ctx->total + 1);
     float* depth = d_depth_svu + (size_t)s_hat * n;
     float* Cd = d_Cd_svu + (size_t)s_hat * n;
@@ -191,16 +192,23 @@ extern "C" int rslf_sweep_visit_finish(rslf_ctx* ctx, const rslf_volume* vol, in
     const int s_after = s_next;
     if (ctx->force_packed == 0 || n > (size_t)INT32_MAX)
         s_next = -1;   // that scan will not take a packed list: it compacts for itself
-    if (C == 1)
-        hipLaunchKernelGGL(k34_median_claim<1>, grid_vu, dim3(256), median_lds, st, view_of(vol), s_hat, depth, ctx->filtered, cem,
-                           p->median_filter_size, p->median_filter_epsilon, rbar, mask_svu, ctx->winner, ctx->dirty, p->slope_factor,
-                           p->propagation_epsilon, p->use_disp_confidence_score ? Cd : nullptr, p->disp_score_threshold, packed_n,
-                           ctx->claim_skip ? ctx->remain : nullptr);
-    else
-        hipLaunchKernelGGL(k34_median_claim<3>, grid_vu, dim3(256), median_lds, st, view_of(vol), s_hat, depth, ctx->filtered, cem,
-                           p->median_filter_size, p->median_filter_epsilon, rbar, mask_svu, ctx->winner, ctx->dirty, p->slope_factor,
-                           p->propagation_epsilon, p->use_disp_confidence_score ? Cd : nullptr, p->disp_score_threshold, packed_n,
-                           ctx->claim_skip ? ctx->remain : nullptr);
+    bool launched = false;
+#define RSLF_K34_CASE(CC, MODE)                                                                                                  \
+    if (!launched && C == CC && mp.mode == MODE) {                                                                                \
+        if (mp.lds_bytes > ((size_t)64 << 10))                                                                                    \
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k34_median_claim<CC, MODE>),                              \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)mp.lds_bytes));                         \
+        hipLaunchKernelGGL((k34_median_claim<CC, MODE>), grid_vu, dim3(256), mp.lds_bytes, st, view_of(vol), s_hat, depth, ctx->filtered, \
+                           cem, mp.w, median_thr, rbar, mask_svu, ctx->winner, ctx->dirty, p->slope_factor, prop_thr,             \
+                           p->use_disp_confidence_score ? Cd : nullptr, p->disp_score_threshold, packed_n,                       \
+                           ctx->claim_skip ? ctx->remain : nullptr);                                                             \
+        launched = true;                                                                                                          \
+    }
+    RSLF_MEDIAN_MODES(RSLF_K34_CASE, 1)
+    RSLF_MEDIAN_MODES(RSLF_K34_CASE, 3)
+#undef RSLF_K34_CASE
+    if (!launched)
+        return fail(RSLF_ERR_INTERNAL, "no median + claims kernel for %d channels, mode %d", C, mp.mode);
     HIP_TRY(hipGetLastError());
     const unsigned apply_blocks = (unsigned)((s_next >= 0 ? V : 0) + ((long long)S * V + kApplyRowsPerBlock - 1) / kApplyRowsPerBlock);
     hipLaunchKernelGGL(k4_propagate_apply, dim3(apply_blocks), dim3(256), 0, st, S, V, U, s_hat, ctx->filtered, Cd, d_depth_svu,

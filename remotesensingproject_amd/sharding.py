@@ -73,7 +73,7 @@ def halo_rows(median_filter_size: int = 5, opening_size: int = 1) -> int:
     """Scanlines either side of a block that must be recomputed for the block's rows to come out exact: the
     selective median reads +-(size-1)/2 rows (core.hpp:686), and those rows' masks depend, through the optional
     opening (erosion then dilation, core.hpp:759-768), on +-2*(k/2) rows more."""
-    halo = (median_filter_size - 1) // 2
+    halo = max(0, int((median_filter_size - 1) / 2))   # C++ division truncates: size 0 is the 1 x 1 window too
     if opening_size > 1:
         halo += 2 * (opening_size // 2)
     return halo
@@ -299,7 +299,7 @@ class ShardedDepth2D:
         self.p = parameters or rs.Depth1DParameters()
         self.dmin, self.dmax = (0.0, 0.0) if self.bounds else (float(dmin), float(dmax))
         self.dim_d = int(dim_d)
-        self.h = (int(self.p.par_median_filter_size) - 1) // 2          # rows the median reads either side
+        self.h = halo_rows(int(self.p.par_median_filter_size), 1)         # rows the median reads either side
         self.own = shard.interior                                         # own rows in the local frame
         if vol.V != shard.hi - shard.lo:
             raise ValueError("the volume must hold rows [%d, %d) of the light field" % (shard.lo, shard.hi))

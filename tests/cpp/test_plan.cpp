@@ -2,7 +2,10 @@
 //   g++ -std=c++17 -O1 -g -fsanitize=address,undefined -fno-sanitize-recover=all
 // by tests/test_plan_cpu.py.  No HIP, no GPU: the same header the .hip translation units include.
 #include <cstdio>
+#include <cmath>
 #include <cstdlib>
+#include <cstring>
+#include <limits>
 #include <random>
 #include <set>
 #include <vector>
@@ -420,8 +423,92 @@ static void test_visit_schedule()
             }
 }
 
+static void test_median_plan()
+{
+    // core.hpp:686: width = (size - 1) / 2 -- an even size is the next smaller odd window, 0 the 1 x 1 window
+    CHECK(median_width(5) == 2 && median_width(4) == 1 && median_width(6) == 2 && median_width(11) == 5 && median_width(1) == 0);
+    CHECK(median_width(0) == 0 && median_width(2) == 0 && median_width(15) == 7 && median_width(16) == 7);
+    CHECK(median_halo(11) == 5 && median_halo(0) == 0 && median_halo(6) == 2 && halo_rows(11, 1) == 5 && halo_rows(4, 3) == 3);
+    for (int C : {1, 3})
+        for (int size = 0; size <= 80; size++) {
+            const MedianPlan m = median_plan(size, C);
+            CHECK(m.w == std::max(0, (size - 1) / 2));
+            const int side = 2 * m.w + 1;
+            if (side <= kMedianNetMaxSide)
+                CHECK(m.mode == side);
+            else if (side <= kMedianTileMaxSide)
+                CHECK(m.mode == 0);
+            else
+                CHECK(m.mode == -1 && m.lds_bytes == 0);
+            if (m.mode >= 0) {
+                CHECK(m.lds_bytes == (size_t)(1 + C) * side * (256 + 2 * m.w) * 4);
+                CHECK(m.lds_bytes <= (size_t)160 << 10);   // a CU's LDS
+            }
+        }
+    CHECK(median_plan(5, 1).mode == 5 && median_plan(11, 3).mode == 11 && median_plan(12, 3).mode == 11 && median_plan(15, 3).mode == 0);
+    CHECK(median_plan(32, 3).mode == 0 && median_plan(33, 3).mode == -1);
+}
+
+static float norm1_ref(float x) { return (float)((double)std::fabs(x) * 1.73205080757); }                          // rslf_types.cpp:80-84
+static float norm3_ref(float x, float y, float z) { double s = (double)x * x; s += (double)y * y; s += (double)z * z; return (float)std::sqrt(s); }
+
+static void test_norm_thresholds()
+{
+    // norm<T>(x) < eps  <=>  |x| < a1  /  sum of squares < s3, exactly: on both sides of the thresholds and at random
+    std::mt19937 rng(20260411);
+    std::uniform_real_distribution<float> u01(0.0f, 1.0f);
+    const float inf = std::numeric_limits<float>::infinity();
+    std::vector<float> epss = {0.1f, 0.25f, 0.05f, 1.0f, 10.0f, 1e-30f, 1e30f, 3.0e38f, inf, 0.0f, -1.0f, std::nanf(""), 1.17549435e-38f, 1e-44f};
+    for (int i = 0; i < 40; i++)
+        epss.push_back(std::ldexp(u01(rng) + 0.5f, (int)(u01(rng) * 60) - 40));
+    for (float eps : epss) {
+        const NormThreshold t = norm_threshold(eps);
+        CHECK(t.a1 >= 0.0f && t.s3 >= 0.0);
+        // neighbours of the thresholds
+        for (int d = -3; d <= 3; d++) {
+            uint32_t b;
+            memcpy(&b, &t.a1, 4);
+            if ((long long)b + d >= 0 && (long long)b + d <= 0x7F800000ll) {
+                const uint32_t bb = (uint32_t)((long long)b + d);
+                float x;
+                memcpy(&x, &bb, 4);
+                CHECK((norm1_ref(x) < eps) == (std::fabs(x) < t.a1));
+                CHECK((norm1_ref(-x) < eps) == (std::fabs(-x) < t.a1));
+            }
+            uint64_t q;
+            memcpy(&q, &t.s3, 8);
+            if (d >= 0 || q >= (uint64_t)(-d)) {
+                const uint64_t qq = q + (uint64_t)(long long)d;
+                if (qq <= 0x7FF0000000000000ull) {
+                    double s;
+                    memcpy(&s, &qq, 8);
+                    CHECK(((float)std::sqrt(s) < eps) == (s < t.s3));
+                }
+            }
+        }
+        for (int it = 0; it < 2000; it++) {
+            const float scale = std::isfinite(eps) && eps > 0 ? eps : 1.0f;
+            const float x = (u01(rng) * 2 - 1) * scale * (it % 3 == 0 ? 0.58f : 1.5f);
+            const float y = (u01(rng) * 2 - 1) * scale * 0.7f, z = (u01(rng) * 2 - 1) * scale * 0.7f;
+            CHECK((norm1_ref(x) < eps) == (std::fabs(x) < t.a1));
+            double s = (double)x * x;
+            s += (double)y * y;
+            s += (double)z * z;
+            CHECK((norm3_ref(x, y, z) < eps) == (s < t.s3));
+        }
+        const float nan = std::nanf("");
+        CHECK(!(std::fabs(nan) < t.a1) && !((double)nan < t.s3));   // NaN fails, as in the reference
+        CHECK(!(std::fabs(inf) < t.a1));
+    }
+    // the defaults: median_filter_epsilon 0.1, propagation_epsilon 0.1 -> |x| < 0.1 / 1.7320508...
+    const NormThreshold d = norm_threshold(0.1f);
+    CHECK(std::fabs(d.a1 - 0.0577350f) < 1e-6f && std::fabs(d.s3 - 0.01) < 1e-8);
+}
+
 int main()
 {
+    test_median_plan();
+    test_norm_thresholds();
     test_sweep_order();
     test_small_rules();
     test_pyramid();

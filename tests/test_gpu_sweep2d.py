@@ -305,3 +305,44 @@ def test_sweep_group_merge_is_exact_at_scale(rs):
     for k in a:
         assert np.array_equal(a[k], b[k]), k
         assert np.array_equal(a[k], c[k]), k
+
+
+@pytest.mark.parametrize("case", ["plain", "gate", "nan_range"])
+def test_claims_with_and_without_view_skipping_agree(rs, hooks, case):
+    """rslf_ctx_set_debug("claim_skip", 0 / 1): the claims' skip of views with nothing left to paint within reach is a
+    pure shortcut -- every plane of every view identical with and without it, also under the disparity-
+    confidence gate and with NaN / huge disparities among the sources (per-pixel ranges holding NaN and 1e12: the
+    workgroup's disparity range then falls back to +-1e9, i.e. "every segment")."""
+    import torch
+    rng = np.random.default_rng(321)
+    V, S, U, D = 18, 9, 600, 12
+    vol_np = rng.uniform(0.0, 1.0, size=(V, S, U, 1)).astype(np.float32)
+    vol_np[:, :, 100:400] = np.round(vol_np[:, :, 100:400] * 2) / 2
+    p = rs.Depth1DParameters()
+    if case == "gate":
+        p.par_use_disp_confidence_score = True
+        p.par_disp_score_threshold = 0.02
+    out = {}
+    for skip in (1, 0):
+        hooks(claim_skip=skip)
+        vol = rs.Volume.from_dense(torch.from_numpy(vol_np).cuda(), 1.0)
+        Ce = torch.zeros((S, V, U), dtype=torch.float32, device="cuda")
+        cem = rs.compute_2D_edge_confidence(vol, Ce, p)
+        Cd, depth = torch.zeros_like(Ce), torch.zeros_like(Ce)
+        rbar = torch.zeros((S, V, U, 1), dtype=torch.float32, device="cuda")
+        scan = torch.empty((S, V, U), dtype=torch.uint8, device="cuda")
+        if case == "nan_range":
+            dmin = torch.full((S, V, U), -1.0, dtype=torch.float32, device="cuda")
+            dmax = torch.full((S, V, U), 1.0, dtype=torch.float32, device="cuda")
+            dmin[:, 3, 50:60] = float("nan")
+            dmin[:, 7, 300:310], dmax[:, 7, 300:310] = 1.0e12, 2.0e12
+            rs.compute_2D_depth_epi(vol, dmin, dmax, D, Ce, cem, Cd, depth, rbar, p, scan_mask_s_v_u=scan)
+        else:
+            rs.compute_2D_depth_epi(vol, -1.0, 1.0, D, Ce, cem, Cd, depth, rbar, p, scan_mask_s_v_u=scan)
+        torch.cuda.synchronize()
+        out[skip] = dict(depth=depth.cpu().numpy(), Cd=Cd.cpu().numpy(), rbar=rbar.cpu().numpy(), scan=scan.cpu().numpy(),
+                         cem=cem.cpu().numpy(), Ce=Ce.cpu().numpy())
+    for k in out[1]:
+        assert np.array_equal(out[1][k], out[0][k], equal_nan=True), (case, k)
+    if case == "nan_range":
+        assert np.isnan(out[1]["depth"]).any()

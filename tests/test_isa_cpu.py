@@ -1,0 +1,51 @@
+"""What the shipped gfx950 code must look like, checked by disassembling librslf_hip.so on the CPU (llvm-objdump).
+
+k2_scan_chip keeps 252 samples and its running result in hand-numbered AGPRs a0..a255 (k2_chip.hpp).  The clobber lists
+on its asm statements constrain the register allocator only ACROSS each statement: between them hipcc could legally
+park a live range or a spill copy in an AGPR and corrupt a parked sample, and `agpr_count == 256`, `scratch == 0` would
+both still hold.  So the layout is verified per build: the kernel must contain exactly the accumulator
+reads and writes the source's asm statements state, name no accumulator register anywhere else, and move none."""
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+CSRC = os.path.join(ROOT, "remotesensingproject_amd", "csrc")
+
+
+def _macro(name):
+    txt = open(os.path.join(CSRC, "k2_chip.hpp")).read()
+    return int(re.search(r"#define %s (\d+)" % name, txt).group(1))
+
+
+def test_chip_kernel_touches_agprs_only_where_its_asm_says():
+    from remotesensingproject_amd import build
+    from tools import kernel_metadata as km
+    so = build.build()
+    dis = km.disassemble(so, "k2_scan_chip")
+    assert sorted(dis) == ["rslf::k2_scan_chip<false>", "rslf::k2_scan_chip<true>"], sorted(dis)
+    NA = _macro("RSLF_CHIP_NA")
+    tier = set(range(3 * NA))                 # sample i of the AGPR tier: a[3i .. 3i + 2]
+    named = {253, 254, 255}                   # running score sum (a double) and best score
+    assert not (tier & named)
+    # two forms of the hypothesis body (shared taps / general gather), each: the tier written once by the gather and read
+    # once by the (rolled) pass loop, the three named registers read and written once by the update; plus the three
+    # initial writes and the three final reads
+    bodies = 2
+    expect = bodies * (3 * NA + 3) + 3
+    for name, ins in dis.items():
+        writes = [i for i in ins if i.startswith("v_accvgpr_write_b32")]
+        reads = [i for i in ins if i.startswith("v_accvgpr_read_b32")]
+        assert len(writes) == expect and len(reads) == expect, (name, len(writes), len(reads), expect)
+        w_regs = [int(re.match(r"v_accvgpr_write_b32 a(\d+),", i).group(1)) for i in writes]
+        r_regs = [int(re.match(r"v_accvgpr_read_b32 v\d+, a(\d+)", i).group(1)) for i in reads]
+        assert set(w_regs) == tier | named and set(r_regs) == tier | named, name
+        for reg in tier:
+            assert w_regs.count(reg) == bodies and r_regs.count(reg) == bodies, (name, reg)
+        for reg in named:
+            assert w_regs.count(reg) == bodies + 1 and r_regs.count(reg) == bodies + 1, (name, reg)
+        others = [i for i in ins if re.search(r"\ba\[?\d", i) and i not in writes and i not in reads]
+        assert not others, (name, others[:5])          # no MFMA, no AV-class load / store, no spill through an AGPR
+        assert not [i for i in ins if i.startswith("v_accvgpr_mov")], name
+        assert not [i for i in ins if i.startswith(("scratch_", "buffer_store", "buffer_load"))], name   # and no scratch at all

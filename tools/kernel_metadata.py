@@ -7,21 +7,48 @@ LLVM = "/opt/rocm/lib/llvm/bin"
 MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
 
 
+def code_objects(lib, d):
+    """The gfx950 code objects of the library (one per translation unit), unbundled into directory d."""
+    fat = os.path.join(d, "fat.bin")
+    subprocess.run([os.path.join(LLVM, "llvm-objcopy"), "-O", "binary", "--only-section=.hip_fatbin", lib, fat], check=True)
+    blob = open(fat, "rb").read()
+    starts = [m.start() for m in re.finditer(re.escape(MAGIC), blob)]
+    objs = []
+    for i, a in enumerate(starts):
+        part = os.path.join(d, "b%d.bin" % i)
+        open(part, "wb").write(blob[a:starts[i + 1] if i + 1 < len(starts) else len(blob)])
+        obj = os.path.join(d, "b%d.o" % i)
+        r = subprocess.run([os.path.join(LLVM, "clang-offload-bundler"), "--unbundle", "--type=o", "--input=" + part,
+                            "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + obj], capture_output=True, text=True)
+        if r.returncode == 0 and os.path.exists(obj) and os.path.getsize(obj) > 0:
+            objs.append(obj)
+    return objs
+
+
+def disassemble(lib, substring):
+    """{demangled kernel name: [instruction text, ...]} for the kernels of the shipped library whose name contains
+    `substring` (llvm-objdump -d of the unbundled gfx950 code objects)."""
+    out = {}
+    with tempfile.TemporaryDirectory() as d:
+        for obj in code_objects(lib, d):
+            txt = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", "--no-show-raw-insn", "--demangle", obj],
+                                 capture_output=True, text=True).stdout
+            cur = None
+            for line in txt.splitlines():
+                m = re.match(r"^[0-9a-f]+ <(.*)>:$", line)
+                if m:
+                    name = re.sub(r"\(.*", "", m.group(1)).replace("void ", "")
+                    cur = out.setdefault(name, []) if substring in name else None
+                    continue
+                if cur is not None and line.startswith("\t"):
+                    cur.append(line.split("//")[0].strip())
+    return out
+
+
 def kernels(lib):
     out = {}
     with tempfile.TemporaryDirectory() as d:
-        fat = os.path.join(d, "fat.bin")
-        subprocess.run([os.path.join(LLVM, "llvm-objcopy"), "-O", "binary", "--only-section=.hip_fatbin", lib, fat], check=True)
-        blob = open(fat, "rb").read()
-        starts = [m.start() for m in re.finditer(re.escape(MAGIC), blob)]
-        for i, a in enumerate(starts):
-            part = os.path.join(d, "b%d.bin" % i)
-            open(part, "wb").write(blob[a:starts[i + 1] if i + 1 < len(starts) else len(blob)])
-            obj = os.path.join(d, "b%d.o" % i)
-            r = subprocess.run([os.path.join(LLVM, "clang-offload-bundler"), "--unbundle", "--type=o", "--input=" + part,
-                                "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + obj], capture_output=True, text=True)
-            if r.returncode != 0 or not os.path.exists(obj) or os.path.getsize(obj) == 0:
-                continue
+        for obj in code_objects(lib, d):
             notes = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", obj], capture_output=True, text=True).stdout
             cur = {}
             for line in notes.splitlines():
