@@ -70,10 +70,10 @@ def cpu_baseline(cfg: dict, budget_s: float = 12.0) -> dict:
     threads = int(os.environ.get("RSLF_CPU_THREADS", "0")) or min(oracle.usable_cpus(), 16)
     oracle.set_num_threads(threads)
     rows = max(2 * threads, 8)
-    if cfg["seed"] is None:   # c1: the committed crop of data/000.tif, 9 identical views (see main)
-        crop = np.load(os.path.join(ROOT, "tests", "golden", "c1_crop_000tif_rows400_424.npy"))
+    if cfg["seed"] is None:   # c1: scanlines 400.. of data/000.tif (the committed frame), 9 identical views (see main)
+        img = np.load(os.path.join(ROOT, "tests", "golden", "c1_000tif_960x540_f32.npz"))["image"]
         tif_max = json.load(open(os.path.join(ROOT, "tests", "golden", "c1_anchor.json")))["tif_max"]
-        plane = crop[np.arange(rows) % crop.shape[0]] * np.float32(1.0 / float(tif_max))
+        plane = img[(400 + np.arange(rows)) % img.shape[0]] * np.float32(1.0 / float(tif_max))
         vol = np.ascontiguousarray(np.repeat(plane[:, None, :, None], cfg["S"], axis=1), np.float32)
     else:
         vol, _ = make_lightfield(cfg["U"], rows, cfg["S"], cfg["C"], seed=cfg["seed"], dmin=cfg["dmin"], dmax=cfg["dmax"])
@@ -125,6 +125,62 @@ def end_to_end(rs, host: np.ndarray, cfg: dict, units: int, device: int) -> dict
             "input_gb": host.nbytes / 1e9, "upload_alone_ms": up * 1e3, "upload_alone_gbs": host.nbytes / 1e9 / up}
 
 
+PEAK_FP32_TFLOPS = 157.3   # MI355X fp32 vector peak (MI355X_MICROARCH.md), FMA counted as two
+
+
+def flops_per_unit(S: int, C: int) -> int:
+    """algorithmic flops of one (pixel, hypothesis) unit."""
+    return 95 * S + 21 if C == 1 else 230 * S + 40
+
+
+def rows_roofline(ctx, run_once, units: int, S: int, C: int, wall_ms: float) -> dict:
+    """`roofline` of the rows around the path (2-D sweep, fine-to-coarse): one more, instrumented pass -- every scan launch
+    bracketed by its own pair of HIP events (rslf_ctx_set_debug "time_all") -- gives the SUMMED K2 time of the run; achieved =
+    units x algorithmic flops / that time.  `k2_share` = summed K2 time / wall time of an (un-instrumented) step."""
+    ctx.set_debug(time_all=1)
+    ctx.scan_time_total_ms()
+    run_once()
+    k2_ms, launches = ctx.scan_time_total_ms()
+    ctx.set_debug(time_all=0)
+    flops = units * flops_per_unit(S, C)
+    achieved = flops / (k2_ms * 1e-3) / 1e12
+    return {"bound": "fp32 VALU (non-MFMA)", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_TFLOPS,
+            "traffic": None, "kernel_ms": k2_ms, "scan_launches": launches, "k2_share": k2_ms / wall_ms,
+            "what": "units x %d algorithmic flop/unit (SURVEY 8d) / summed K2 time of one run (HIP events around every scan launch, "
+                    "a separate instrumented pass); k2_share = that time / wall time of a step" % flops_per_unit(S, C)}
+
+
+def rows_cpu_baseline(kind: str, cfg: dict, budget_s: float = 12.0) -> dict:
+    """`cpu_baseline` of the same rows: the oracle's Depth2DComputer / FineToCoarse restatement on a bounded sample of the
+    same field (a block of whole scanlines, all views), OpenMP over scanlines as the reference (core.hpp:799)."""
+    import oracle
+    from remotesensingproject_amd.synth import make_lightfield
+    threads = int(os.environ.get("RSLF_CPU_THREADS", "0")) or min(oracle.usable_cpus(), 16)
+    oracle.set_num_threads(threads)
+    rows = max(2 * threads, 24) if kind == "sweep2d" else max(4 * threads, 48)     # f2c: enough rows for a few pyramid levels
+    rows = min(rows, cfg["V"])
+    vol, _ = make_lightfield(cfg["U"], rows, cfg["S"], cfg["C"], seed=cfg["seed"], dmin=cfg["dmin"], dmax=cfg["dmax"])
+    units, elapsed, reps = 0, 0.0, 0
+    while elapsed < budget_s and reps < 16:
+        oracle.sweep_pixels_scanned(reset=True)
+        t0 = time.perf_counter()
+        if kind == "sweep2d":
+            oracle.depth2d_run(vol, cfg["dmin"], cfg["dmax"], cfg["D"])
+        else:
+            oracle.fine_to_coarse_run((vol * 200.0 + 3.0).astype(np.float32), cfg["dmin"], cfg["dmax"], cfg["D"])
+        elapsed += time.perf_counter() - t0
+        scanned = oracle.sweep_pixels_scanned(reset=True)
+        if not scanned:
+            raise RuntimeError("the oracle did not report its scanned pixels")
+        units += scanned * cfg["D"]
+        reps += 1
+    return {"value": units / elapsed / 1e6, "unit": "Mpixel*hyp/s", "cores": threads, "kind": "port",
+            "sample": "%s of %d scanlines x %d px x %d views x %d ch x %d hypotheses of the same field (units = pixels the oracle "
+                      "scanned x hypotheses), %d passes, %.1f s" % (
+                          "Depth2DComputer::run" if kind == "sweep2d" else "FineToCoarse ctor + run + get_results",
+                          rows, cfg["U"], cfg["S"], cfg["C"], cfg["D"], reps, elapsed)}
+
+
 def pick_config(args, default_for_c3: str | None = None) -> tuple[dict, str]:
     """--config, or --shape U,V,S,C,D,dmin,dmax for a synthetic field of another size (context lines)."""
     from remotesensingproject_amd.synth import CONFIGS
@@ -163,7 +219,8 @@ def bench_sweep2d(args) -> None:
         comp.run(want_stats=False)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    print(json.dumps({
+    roof = rows_roofline(ctx, lambda: (comp.run(want_stats=False), torch.cuda.synchronize()), units, S, C, elapsed / args.steps * 1e3)
+    line = {
         "metric": "Mpixel*disparity-hypotheses/s", "value": units / (elapsed / args.steps) / 1e6, "unit": "Mpixel*hyp/s",
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -171,7 +228,11 @@ def bench_sweep2d(args) -> None:
                                "%d pixels scanned in total (%.2f views' worth)" % (
                                    cfg_name, U, V, S, C, D, S, units // D, units / D / (U * V)),
                    "path": "sweep2d"},
-    }), flush=True)
+        "roofline": roof,
+    }
+    if not args.no_cpu_baseline:
+        line["cpu_baseline"] = rows_cpu_baseline("sweep2d", cfg)
+    print(json.dumps(line), flush=True)
 
 
 def bench_f2c(args) -> None:
@@ -204,14 +265,19 @@ def bench_f2c(args) -> None:
     for _ in range(args.steps):
         once()
     elapsed = time.perf_counter() - t0
-    print(json.dumps({
+    roof = rows_roofline(rs.default_context(), once, units, S, C, elapsed / args.steps * 1e3)
+    line = {
         "metric": "Mpixel*disparity-hypotheses/s", "value": units / (elapsed / args.steps) / 1e6, "unit": "Mpixel*hyp/s",
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "fine-to-coarse (FineToCoarse ctor + run + get_results, host upload included) over %s: %dx%d px x %d views "
                                "x %d ch, %d hypotheses; pyramid %s" % (cfg_name, U, V, S, C, D, dims),
                    "path": "f2c", "pixels_scanned": units // D},
-    }), flush=True)
+        "roofline": roof,
+    }
+    if not args.no_cpu_baseline:
+        line["cpu_baseline"] = rows_cpu_baseline("f2c", cfg)
+    print(json.dumps(line), flush=True)
 
 
 def bench_e2e(args) -> None:
@@ -277,7 +343,8 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", default=None, help="synthetic config of BASELINE.md section 4 (c1, c2, c3, c5); default c3")
+    ap.add_argument("--config", default=None, help="synthetic config of BASELINE.md section 4 (c1, c2, c3, c5; default c3), or a published shape of the reference's "
+                                                    "report for the sweep2d / f2c paths (skysat_lr, mansion_lr)")
     ap.add_argument("--shape", default="", help="U,V,S,C,D,dmin,dmax: a synthetic field of another size (sweep2d / f2c paths)")
     ap.add_argument("--rows", type=int, default=0, help="override the number of scanlines (developer runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -328,13 +395,13 @@ def main() -> None:
     shard = sharding.make_shard(V, rank, world, params.par_median_filter_size, params.par_edge_confidence_opening_size)
 
     if cfg["seed"] is None:
-        # c1 (BASELINE.json configs[0]): data/000.tif replicated into 9 identical views.  The file itself does not
-        # travel; the committed 24-row crop (tests/golden, rows 400-424) is tiled to the config's 960 scanlines and
-        # normalised by the file's max as the constructor does (dc.hpp:474).
-        crop = np.load(os.path.join(ROOT, "tests", "golden", "c1_crop_000tif_rows400_424.npy"))
+        # c1 (BASELINE.json configs[0]): data/000.tif replicated into 9 identical views.  The decoded frame travels as
+        # a fixture (tests/golden/c1_000tif_960x540_f32.npz: data, 960 scanlines x 540 columns) and is normalised by its
+        # max as the constructor does (dc.hpp:474); --rows beyond 960 wrap around.
+        img = np.load(os.path.join(ROOT, "tests", "golden", "c1_000tif_960x540_f32.npz"))["image"]
         tif_max = json.load(open(os.path.join(ROOT, "tests", "golden", "c1_anchor.json")))["tif_max"]
-        rows_v = np.arange(V)[shard.rows] % crop.shape[0]
-        plane = crop[rows_v] * np.float32(1.0 / float(tif_max))
+        rows_v = np.arange(V)[shard.rows] % img.shape[0]
+        plane = img[rows_v] * np.float32(1.0 / float(tif_max))
         host = np.ascontiguousarray(np.repeat(plane[:, None, :, None], S, axis=1), np.float32)
     else:
         # synthetic light field: every rank draws the same textures and keeps its scanlines (+halo)
@@ -434,16 +501,16 @@ def main() -> None:
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": ("synthetic" if cfg["seed"] is not None else "crop of the reference's data/000.tif, tiled") if backend == "nccl" else "synthetic (REHEARSAL: %s backend, not a result)" % backend,
+            "data": ("synthetic" if cfg["seed"] is not None else "the reference's data/000.tif (decoded frame, a committed fixture), 9 identical views") if backend == "nccl" else "synthetic (REHEARSAL: %s backend, not a result)" % backend,
             "config": {
                 "workload": "%s: %dx%d px x %d views x %d ch, %d hypotheses in [%g, %g], %s" % (
                     args.config, U, V, S, C, D, cfg["dmin"], cfg["dmax"],
                     "seed %d, all pixels confident" % cfg["seed"] if cfg["seed"] is not None else
-                    "24-row crop of data/000.tif tiled to %d scanlines, %d identical views, real edge mask" % (V, S)),
+                    "data/000.tif, %d scanlines, %d identical views, real edge mask" % (V, S)),
                 "sharding": "none" if world == 1 else "scanline blocks + %d-row recomputed halo, RCCL gather of the output planes per step" % sharding.halo_rows(
                     params.par_median_filter_size, params.par_edge_confidence_opening_size),
                 "scan_kernel": {1: "k2_scan_reg<%d,%d>" % (comp.stats.s_pad, C), 2: "k2_scan_stream<%d>" % C, 3: "k2_scan_chip",
-                                4: "k2_scan_reg_px<%d,%d>" % (comp.stats.s_pad, C)}.get(
+                                4: "k2_scan_reg_px<%d,%d>" % (comp.stats.s_pad, C), 5: "k2_scan_stream_px<%d>" % C}.get(
                     comp.stats.scan_kernel, "k2_scan_generic<%d>" % C),
                 "pixels_scanned": pixels,
             },

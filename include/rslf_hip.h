@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define RSLF_ABI_VERSION 5
+#define RSLF_ABI_VERSION 6
 
 typedef enum rslf_status {
     RSLF_OK = 0,
@@ -116,6 +116,7 @@ typedef struct rslf_stats {
 #define RSLF_SCAN_CHIP      3  /* volume >= 0, C=3, S in [201, 220], dense launch with one hypothesis grid: one wave per SIMD, 198 samples
                                   of a unit on chip (VGPRs + AGPRs + LDS), packed-fp32 passes */
 #define RSLF_SCAN_REG_PX    4  /* RSLF_SCAN_REG's shapes on a packed (sparse) launch: a wave owns one pixel, its lanes the hypotheses */
+#define RSLF_SCAN_STREAM_PX 5  /* RSLF_SCAN_STREAM's shapes on a packed (sparse) launch, the same way */
 
 int         rslf_abi_version(void);
 const char* rslf_status_string(int status);
@@ -133,12 +134,14 @@ int rslf_ctx_synchronize(rslf_ctx* ctx);
  *   "force_scan"     0 automatic | 1 generic scan kernel | 2 streaming scan kernel (never the on-chip one)
  *   "force_groups"   0 automatic | 1..64 hypothesis groups per tile
  *   "force_packed"   -1 automatic | 0 row tiles | 1 one packed pixel list
- *   "px"             -1 automatic | 0 never | 1 whenever it can run: packed launches of a register kernel put a pixel's
- *                    HYPOTHESES in the lanes of a wave (k2_scan_reg_px) instead of 64 pixels
+ *   "px"             -1 automatic | 0 never | 1 whenever it can run: packed launches of a register or streaming kernel put a pixel's
+ *                    HYPOTHESES in the lanes of a wave (k2_scan_reg_px, k2_scan_stream_px) instead of 64 pixels
  *   "claim_skip"     1 (default) the 2-D sweep's claims skip views with nothing left to paint within reach | 0 off
  *   "stream_share"   1 (default) 63-pixel tiles sharing taps between lanes in the streaming kernel | 0 off
  *   "stream_groups"  0 automatic | hypothesis groups per tile of the streaming kernel's dense launches
  *   "stream_lds_kib" dynamic LDS of one streaming workgroup, KiB (default 80)
+ *   "time_all"       0 (default) | 1: every scan launch is bracketed by its own pair of HIP events, summed and reset by
+ *                    rslf_scan_time_total_ms (the K2 time of a whole sweep or pyramid; each event costs ~5.6 us in the queue)
  * Results do not depend on these (the parity tests drive every combination; "claim_skip" on / off is compared plane by
  * plane in tests/test_gpu_sweep2d.py); speed does.  One qualification: the disparity confidence C_d = C_e * |max - mean of
  * the scores| takes the mean through a double sum whose ORDER differs between launch shapes (per wave in the row kernels,
@@ -437,6 +440,11 @@ int rslf_multi_fine_to_coarse_run_host(rslf_multi* m, const void* const* h_epis,
  * the first (dense, centre-view) visit is timed: an event is a packet of
  * its own in the queue, and two per sparse visit cost a tenth of the visit. */
 int rslf_last_scan_kernel_ms(rslf_ctx* ctx, float* ms);
+/* With rslf_ctx_set_debug(ctx, "time_all", 1): the SUM of the durations of every scan launch sequence queued on this
+ * context since the last call (or since the hook was set) and their number; blocks until they have finished, then starts
+ * a new sum.  For the roofline of the rows around the path: a 2-D sweep is one dense and S - 1 sparse scan launches, a
+ * fine-to-coarse run that per pyramid level (core.hpp:993-1028). */
+int rslf_scan_time_total_ms(rslf_ctx* ctx, float* ms, int* launches);
 
 #ifdef __cplusplus
 }

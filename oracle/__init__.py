@@ -363,6 +363,14 @@ def fine_to_coarse_run(raw_vsuc, dmin, dmax, dim_d, params=None, max_pyr_depth=-
                 params=pars)
 
 
+def sweep_pixels_scanned(reset: bool = True) -> int:
+    """Pixels the sweeps (depth2d_run, depth2d_run_planes, fine_to_coarse_run) have scanned since the last reset."""
+    L = lib()
+    L.oracle_sweep_pixels_scanned.restype = C.c_longlong
+    L.oracle_sweep_pixels_scanned.argtypes = [C.c_int]
+    return int(L.oracle_sweep_pixels_scanned(1 if reset else 0))
+
+
 def num_threads() -> int:
     return int(lib().oracle_num_threads())
 

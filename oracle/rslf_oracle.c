@@ -861,6 +861,17 @@ void oracle_edge_confidence_2d(const float* vol, int V, int S, int U, int C,
         oracle_edge_confidence_pile(vol, V, S, U, C, s, Ce_svu + (size_t)s * n, mask_svu + (size_t)s * n, p);
 }
 
+/* pixels the sweeps have scanned since the last reset: the sum over visits of the pixels in both the view's edge mask and
+ * its running mask on entry to the pile scan (core.hpp:515-527) -- bench.py's cpu_baseline counts its units from this */
+static long long g_sweep_pixels_scanned = 0;
+long long oracle_sweep_pixels_scanned(int reset)
+{
+    const long long v = g_sweep_pixels_scanned;
+    if (reset)
+        g_sweep_pixels_scanned = 0;
+    return v;
+}
+
 void oracle_depth_epi_2d(const float* vol, int V, int S, int U, int C,
                          const float* dmin_svu, const float* dmax_svu, int dim_d,
                          float* Ce_svu, uint8_t* Ce_mask_svu, float* Cd_svu,
@@ -896,6 +907,8 @@ void oracle_depth_epi_2d(const float* vol, int V, int S, int U, int C,
         float* rbar = rbar_svu + (size_t)s_hat * n * C;
         uint8_t* mask = mask_svu + (size_t)s_hat * n;
 
+        for (size_t i = 0; i < n; i++)
+            g_sweep_pixels_scanned += (Cem[i] && mask[i]) ? 1 : 0;
         /* core.hpp:1012-1028: the pile scan writes raw depths into the stored plane ... */
         memcpy(tmp, depth, sizeof(float) * n);
         oracle_depth_epi_pile(vol, V, S, U, C, dmin_svu + (size_t)s_hat * n, dmax_svu + (size_t)s_hat * n,

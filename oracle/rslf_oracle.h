@@ -162,6 +162,9 @@ void oracle_edge_confidence_2d(const float* vol, int V, int S, int U, int C,
  * Note core.hpp:892 rebinds only the LOCAL header best_depth_v_u to the median
  * result: the stored plane of the visited view keeps the raw arg-max depths and
  * then receives the median-filtered values the propagation paints into it. */
+/* pixels scanned by the sweeps (oracle_depth_epi_2d, oracle_depth2d_run) since the last reset; reset != 0 clears the count */
+long long oracle_sweep_pixels_scanned(int reset);
+
 void oracle_depth_epi_2d(const float* vol, int V, int S, int U, int C,
                          const float* dmin_svu, const float* dmax_svu, int dim_d,
                          float* Ce_svu, uint8_t* Ce_mask_svu, float* Cd_svu,

@@ -12,7 +12,7 @@ from . import build as _build
 
 _LIB = None
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 # every symbol include/rslf_hip.h declares
 SYMBOLS = [
@@ -25,7 +25,7 @@ SYMBOLS = [
     "rslf_volume_upload_epis_f32", "rslf_volume_upload_epis_u8",
     "rslf_volume_upload_images_f32", "rslf_volume_upload_images_u8", "rslf_volume_pack_device_f32",
     "rslf_edge_confidence_pile", "rslf_depth_epi_pile", "rslf_selective_median",
-    "rslf_depth1d_pile_run", "rslf_depth1d_pile_run_host", "rslf_last_scan_kernel_ms",
+    "rslf_depth1d_pile_run", "rslf_depth1d_pile_run_host", "rslf_last_scan_kernel_ms", "rslf_scan_time_total_ms",
     "rslf_edge_confidence_2d", "rslf_depth_epi_2d", "rslf_depth2d_run",
     "rslf_sweep_begin", "rslf_sweep_visit_scan", "rslf_sweep_visit_finish", "rslf_sweep_end",
     "rslf_depth_epi_scan", "rslf_depth1d_run",
@@ -145,6 +145,7 @@ def lib():
                                         C.POINTER(RslfStats)]
     L.rslf_depth1d_pile_run_host.argtypes = L.rslf_depth1d_pile_run.argtypes
     L.rslf_last_scan_kernel_ms.argtypes = [vp, C.POINTER(cf)]
+    L.rslf_scan_time_total_ms.argtypes = [vp, C.POINTER(cf), C.POINTER(ci)]
     L.rslf_sweep_begin.argtypes = [vp, vp, vp, vp, ci, ci, ci]
     L.rslf_sweep_visit_scan.argtypes = [vp, vp, vp, vp, cf, cf, ci, ci, vp, vp, vp, vp, vp, C.POINTER(RslfParams)]
     L.rslf_sweep_visit_finish.argtypes = [vp, vp, ci, vp, vp, vp, vp, C.POINTER(RslfParams)]

@@ -24,10 +24,11 @@ namespace rslf {
 // ---------------------------------------------------------------------------
 // samples whose loads are in flight together (2 registers per sample and channel while they are)
 #ifndef RSLF_REG_GB104
-#define RSLF_REG_GB104 13   // loads in flight per gather round of the 104-slot (c3) kernel.  13 = eight rounds per hypothesis instead
-                            // of thirteen: 67.24 vs 67.85 ms on one box (profiles/r03_k2_variants.md) at the price of 20 B/lane of
-                            // scratch -- per-tile values (the pixel index, the centre texel's address) stored once per workgroup,
-                            // outside every loop: 0.27 GB of HBM writes per launch, 1.3x the algorithmic bytes.  8: no scratch.
+#define RSLF_REG_GB104 8    // loads in flight per gather round of the 104-slot (c3) kernel.  8: no scratch, HBM traffic 1.03x the
+                            // algorithmic bytes.  13 (eight rounds per hypothesis instead of thirteen; round 3's default) is 0.86 % faster
+                            // -- four same-box alternations, 65.67-65.84 vs 66.24-66.41 ms -- at the price of 28 B/lane of per-tile
+                            // scratch that reaches HBM: 1.41x the algorithmic bytes.  Below the 1 % bar: the scratch-free build ships
+                            // (profiles/r04_k2_variants.md).
 #endif
 constexpr int gather_batch(int c) { return c == 1 ? 8 : 4; }
 constexpr int kPadSlack = 16;     // compiled slot counts step by at most this: only the last kPadSlack slots can be padding
@@ -442,10 +443,8 @@ void k2_scan_reg_packed(ScanArgs a)
 // between workgroups -- no hypothesis groups, no records, no tickets.  px_waves = 1 / 2 / 4 waves share a pixel's
 // hypotheses (lane slot + k * 64 * px_waves; plan::px_waves picks by lane use), so a workgroup holds 4 / 2 / 1 pixels.
 // The arithmetic of a (pixel, hypothesis) unit is scan_reg_body's per-lane form, the one per-pixel [dmin, dmax] planes
-// take: same operations, same bits.  What changes is the reduction over hypotheses, now across lanes: the best score wins,
-// the LOWEST hypothesis among equal scores (first maximum, cv::minMaxLoc, core.hpp:634), and the score sum is a double
-// (cv::mean, core.hpp:641 -- C_d is held to 1e-5; sums of <= 4096 floats in [0, 1] are exact in a double unless a score
-// is below 2^-21, so in practice the same bits in any order).
+// take: same operations, same bits.  What changes is the reduction over hypotheses, now across lanes (scan_px_finish,
+// k2_scan.hpp).
 // Occupancy and gather batch: the ROW kernel's (scalar EPI base, near-coalesced loads: three waves per SIMD and 13 loads in
 // flight at 104 slots), not the packed kernel's (two waves, a quarter of the unit in flight): same-box A/B, c3 sweep 118.0
 // vs 120.0 ms, SkysatLR-like fine-to-coarse 257 vs 278 ms (profiles/r03_k2_variants.md section 5).  0 builds the other.
@@ -458,7 +457,7 @@ __global__ __launch_bounds__(64 * kScanWaves) __attribute__((amdgpu_waves_per_eu
 void k2_scan_reg_px(ScanArgs a)
 {
     __shared__ double s_sum[kScanWaves];
-    __shared__ float s_rec[kScanWaves][3 + C];   // score, hypothesis (bits), disparity, rbar
+    __shared__ float s_rec[kScanWaves][kPxRecFloats];
     const int n = *a.packed_n;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -483,56 +482,7 @@ void k2_scan_reg_px(ScanArgs a)
             scan_reg_body<SPAD, C, false, false, false, kGB, Best<C>, true>(a, v, u, 0, a.dim_d, best, nullptr, dlane, dstep);
         else
             scan_reg_body<SPAD, C, true, false, false, kGB, Best<C>, true>(a, v, u, 0, a.dim_d, best, nullptr, dlane, dstep);
-        // ---- across the lanes
-        float bs = best.score;                        // -1 where a lane had no hypothesis
-        int bd = bs < 0.0f ? 0x7fffffff : best.d;
-        double sum = best.sum;
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) {
-            const float os = __shfl_xor(bs, m);
-            const int od = __shfl_xor(bd, m);
-            const bool take = os > bs || (os == bs && od < bd);
-            bs = take ? os : bs;
-            bd = take ? od : bd;
-            sum += __shfl_xor(sum, m);
-        }
-        const int owner = __ffsll((unsigned long long)__ballot(best.score == bs && best.d == bd)) - 1;   // exactly one lane scored bd
-        float bD = __shfl(best.D, owner);
-        float br[C];
-#pragma unroll
-        for (int c = 0; c < C; c++)
-            br[c] = __shfl(best.rbar[c], owner);
-        // ---- across the waves that share the pixel
-        if (wpp > 1) {
-            if (lane == 0) {
-                s_rec[wave][0] = bs;
-                s_rec[wave][1] = __int_as_float(bd);
-                s_rec[wave][2] = bD;
-#pragma unroll
-                for (int c = 0; c < C; c++)
-                    s_rec[wave][3 + c] = br[c];
-                s_sum[wave] = sum;
-            }
-            __syncthreads();
-            if (sub == 0) {
-                for (int w = wave + 1; w < wave + wpp; w++) {
-                    const float os = s_rec[w][0];
-                    const int od = __float_as_int(s_rec[w][1]);
-                    sum += s_sum[w];
-                    if (os > bs || (os == bs && od < bd)) {
-                        bs = os;
-                        bd = od;
-                        bD = s_rec[w][2];
-#pragma unroll
-                        for (int c = 0; c < C; c++)
-                            br[c] = s_rec[w][3 + c];
-                    }
-                }
-            }
-            __syncthreads();   // the next item's records may overwrite these
-        }
-        if (have && sub == 0 && lane == 0)
-            write_pixel<C>(a, (long long)o, bs, bd, bD, br, sum);
+        scan_px_finish<C>(a, o, have, best, wave, lane, wpp, s_rec, s_sum);   // across the lanes, then the waves that share the pixel
     }
 }
 

@@ -267,6 +267,68 @@ __device__ __forceinline__ void write_pixel(const ScanArgs& a, long long o, floa
     }
 }
 
+// Pixel-per-wave launches (k2_scan_reg_px, k2_scan_stream_px): the lanes of `wpp` waves hold one pixel's hypotheses, each
+// lane its own running result.  Across the lanes the best score wins and the LOWEST hypothesis among equal scores (first
+// maximum, cv::minMaxLoc, core.hpp:634); the winner's disparity and rbar come from the one lane that scored it; the score
+// sum is a double (cv::mean, core.hpp:641 -- C_d is held to 1e-5; sums of <= 4096 floats in [0, 1] are exact in a double
+// unless a score is below 2^-21, so in practice the same bits in any order).  Then across the waves that share the pixel
+// through `rec` / `wsum` (LDS, one row per wave of the workgroup), and the pixel is written by the first of them.
+constexpr int kPxRecFloats = 3 + 3;   // score, hypothesis (bits), disparity, rbar[<= 3]
+template <int C>
+__device__ __forceinline__ void scan_px_finish(const ScanArgs& a, unsigned o, bool have, const Best<C>& best, int wave, int lane, int wpp,
+                                               float (*rec)[kPxRecFloats], double* wsum)
+{
+    const int sub = wave % wpp;
+    float bs = best.score;                        // -1 where a lane had no hypothesis
+    int bd = bs < 0.0f ? 0x7fffffff : best.d;
+    double sum = best.sum;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const float os = __shfl_xor(bs, m);
+        const int od = __shfl_xor(bd, m);
+        const bool take = os > bs || (os == bs && od < bd);
+        bs = take ? os : bs;
+        bd = take ? od : bd;
+        sum += __shfl_xor(sum, m);
+    }
+    const int owner = __ffsll((unsigned long long)__ballot(best.score == bs && best.d == bd)) - 1;   // exactly one lane scored bd
+    float bD = __shfl(best.D, owner);
+    float br[C];
+#pragma unroll
+    for (int c = 0; c < C; c++)
+        br[c] = __shfl(best.rbar[c], owner);
+    if (wpp > 1) {
+        if (lane == 0) {
+            rec[wave][0] = bs;
+            rec[wave][1] = __int_as_float(bd);
+            rec[wave][2] = bD;
+#pragma unroll
+            for (int c = 0; c < C; c++)
+                rec[wave][3 + c] = br[c];
+            wsum[wave] = sum;
+        }
+        __syncthreads();
+        if (sub == 0) {
+            for (int w = wave + 1; w < wave + wpp; w++) {
+                const float os = rec[w][0];
+                const int od = __float_as_int(rec[w][1]);
+                sum += wsum[w];
+                if (os > bs || (os == bs && od < bd)) {
+                    bs = os;
+                    bd = od;
+                    bD = rec[w][2];
+#pragma unroll
+                    for (int c = 0; c < C; c++)
+                        br[c] = rec[w][3 + c];
+                }
+            }
+        }
+        __syncthreads();   // the next item's records may overwrite these
+    }
+    if (have && sub == 0 && lane == 0)
+        write_pixel<C>(a, (long long)o, bs, bd, bD, br, sum);
+}
+
 // Word accesses that are coherent at agent scope by themselves (sc1: to / from the memory side), for data handed from one
 // workgroup to another that may run on a different XCD -- no cache-wide write-back or invalidate.
 // The hand-off built on them (scan_epilogue) leans on gfx9 behaviour, not on the language memory model: stores count in

@@ -48,11 +48,15 @@ __host__ __device__ constexpr int stream_resident_for(int S, int C)
 // per lane and sample and takes the other from lane + 1 (v_mov_b32 wave_shl:1) -- half the vector-memory
 // instructions of the tail, which is what bounds it (the CU's texture data path takes ~17 clocks per multi-dword
 // wave-instruction whatever its width, tools/ubench_ta.hip; PMC: TD_BUSY 90 %).
-template <int C, bool BORDER, bool UNIFORM_D, int NRES, bool DENSE = false>
+// LANE_D: the lanes of the wave own HYPOTHESES of one pixel instead of pixels (k2_scan_stream_px): lane `dlane` scores
+// d0 + dlane, d0 + dlane + dstep, ... below d1 (a lane past the end repeats d1 - 1 and offers nothing); v and u are then
+// wave-uniform and every lane has its own view offsets (UNIFORM_D is false).
+template <int C, bool BORDER, bool UNIFORM_D, int NRES, bool DENSE = false, bool LANE_D = false>
 __device__ __forceinline__ void scan_stream_body(const ScanArgs& a, int v, int u, int d0, int d1, Best<C>& best,
-                                                 float* __restrict__ otab)
+                                                 float* __restrict__ otab, int dlane = 0, int dstep = 1)
 {
     static_assert(!DENSE || (UNIFORM_D && !BORDER), "shared taps need a common hypothesis grid and no border lane");
+    static_assert(!LANE_D || (!UNIFORM_D && !DENSE), "hypotheses in the lanes: every lane has its own view offsets");
     const VolView& vol = a.vol;
     const float* epi = vol.row(v, 0);
     const float uf = (float)u;
@@ -72,7 +76,8 @@ __device__ __forceinline__ void scan_stream_body(const ScanArgs& a, int v, int u
     for (int c = 0; c < C; c++)
         centre[c] = epi[(long long)a.s_hat * vol.stride_s + u * C + c];
 
-    for (int d = d0; d < d1; d++) {
+    for (int dk = d0; dk < d1; dk += (LANE_D ? dstep : 1)) {
+        const int d = LANE_D ? min(dk + dlane, d1 - 1) : dk;
         const float Dd = hypothesis(dmin, range, denom, d);
         bool shared_taps = false;
         if (UNIFORM_D) {
@@ -488,7 +493,8 @@ __device__ __forceinline__ void scan_stream_body(const ScanArgs& a, int v, int u
         const float cardf = (float)card;
         float sc = (card != 0) ? (B / cardf) : 0.0f;     // core.hpp:616-620
         sc = (sc > 0.0f) ? sc : 0.0f;                    // core.hpp:622
-        best.offer(sc, d, Dd, rbar);
+        if (!LANE_D || dk + dlane < d1)
+            best.offer(sc, d, Dd, rbar);
     }
 }
 
@@ -572,6 +578,60 @@ __global__ __launch_bounds__(64 * kScanWaves) __attribute__((amdgpu_waves_per_eu
     } else {
         RSLF_SCAN_KERNEL_BODY((scan_stream_rows<C, 0>(a, v, u, active, d0, d1, best, otab)),
                               (scan_stream_body<C, true, false, 0>(a, v, u, d0, d1, best, otab)))
+    }
+}
+
+// Sparse launches of the stream-class units (RGB above 48 views, one channel above 192), lanes own HYPOTHESES
+// (k2_scan_stream_px; the register kernels' form of this is k2_scan_reg_px, k2_reg.hpp).  With a pixel per lane a sparse
+// list puts a wave's 64 lanes on up to 64 scanlines: every load of the gather -- and of the tail re-gathered on every
+// pass -- touches up to 64 cache lines.  Here a wave owns ONE pixel: a load's 64 taps lie within (d_63 - d_0) * |s_hat - s|
+// pixels of one EPI row, the EPI base is a scalar, nothing is shared between workgroups (no hypothesis groups, records or
+// tickets).  px_waves = 1 / 2 / 4 waves share a pixel's hypotheses (plan::px_waves).  A unit's arithmetic is
+// scan_stream_body's per-lane-offset form -- the one per-pixel [dmin, dmax] planes and the packed tiles have always taken:
+// same operations, same bits -- with the same three tiers (resident prefix, samples parked in LDS, re-gathered tail); the
+// reduction over hypotheses is scan_px_finish (k2_scan.hpp).  The fine-to-coarse run of the report's MansionLR shape
+// (1146 x 720, 100 views RGB, report/rs_report.tex:406,427; core.hpp:993-1028 is the caller) spends nine tenths of its time
+// in these launches.
+template <int C>
+__global__ __launch_bounds__(64 * kScanWaves) __attribute__((amdgpu_waves_per_eu(RSLF_STREAM_WAVES, 8))) void k2_scan_stream_px(ScanArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float s_stream_otab[];   // [kScanWaves][stream_wave_floats]
+    __shared__ double s_sum[kScanWaves];
+    __shared__ float s_rec[kScanWaves][kPxRecFloats];
+    const int n = *a.packed_n;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float* otab = s_stream_otab + (size_t)wave * a.stream_wave_floats;
+    const int wpp = a.px_waves, ppw = kScanWaves / wpp;   // waves per pixel, pixels per workgroup
+    const int items = (n + ppw - 1) / ppw;
+    const int sub = wave % wpp;
+    const int dlane = sub * 64 + lane, dstep = 64 * wpp;
+    for (int item = blockIdx.x; item < items; item += gridDim.x) {
+        const int e = item * ppw + wave / wpp;
+        const bool have = e < n;   // (a workgroup's last pixels may be missing: those waves shadow the list's last entry and write nothing)
+        const unsigned o = (unsigned)__builtin_amdgcn_readfirstlane(a.list[have ? e : n - 1]);
+        const int v = (int)(o / (unsigned)a.vol.U);
+        const int u = (int)(o - (unsigned)v * (unsigned)a.vol.U);
+        Best<C> best;
+        best.init();
+        // the validity test (interp.hpp:182) can go where every sample line of every hypothesis stays inside the row
+        const float dlo = a.dmin_vu ? a.dmin_vu[o] : a.dmin, dhi = a.dmax_vu ? a.dmax_vu[o] : a.dmax;
+        const float reach = (float)max(a.s_hat, a.vol.S - 1 - a.s_hat) * fmaxf(fabsf(dlo), fabsf(dhi)) * fabsf(a.k.slope) + 2.0f;
+        const bool interior = (float)u - reach >= 0.0f && (float)u + reach <= (float)(a.vol.U - 1);   // wave-uniform
+        auto run = [&](auto nres_tag) {
+            constexpr int NRES = decltype(nres_tag)::value;
+            if (interior)
+                scan_stream_body<C, false, false, NRES, false, true>(a, v, u, 0, a.dim_d, best, otab, dlane, dstep);
+            else
+                scan_stream_body<C, true, false, NRES, false, true>(a, v, u, 0, a.dim_d, best, otab, dlane, dstep);
+        };
+        if (a.vol.S >= stream_resident_hi(C))
+            run(std::integral_constant<int, stream_resident_hi(C)>{});
+        else if (stream_resident_lo(C) > 0 && a.vol.S >= stream_resident_lo(C))
+            run(std::integral_constant<int, stream_resident_lo(C)>{});
+        else
+            run(std::integral_constant<int, 0>{});
+        scan_px_finish<C>(a, o, have, best, wave, lane, wpp, s_rec, s_sum);
     }
 }
 

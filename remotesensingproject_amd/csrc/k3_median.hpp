@@ -221,21 +221,36 @@ __device__ __forceinline__ float median_select_radix(const MedianTile& t, const 
     uint32_t pm[R];
     uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
     int n = 0;
+    // (eight window columns at a time, their LDS reads issued together: one read, one wait per candidate left the two
+    // waves a SIMD holds at this register count waiting most of the time)
+    constexpr int B = 8;
 #pragma unroll
     for (int dk = 0; dk < R; dk++) {
         uint32_t m = 0;
         if (dk < t.rows)
-            for (int j = 0; j < t.rows; j++) {
-                float df[C];
+            for (int j0 = 0; j0 < t.rows; j0 += B) {
+                float rv[C][B];
+                uint32_t kv[B];
 #pragma unroll
-                for (int c = 0; c < C; c++)
-                    df[c] = ec[c] - t.rad[(c * t.rows + dk) * t.tw + tx + j];
-                if (norm_below<C>(df, thr)) {
-                    const uint32_t k = keys[dk * t.tw + tx + j];
-                    m |= 1u << j;
-                    kmin = min(kmin, k);
-                    kmax = max(kmax, k);
-                    n++;
+                for (int b = 0; b < B; b++) {
+                    const int j = min(j0 + b, t.rows - 1);
+#pragma unroll
+                    for (int c = 0; c < C; c++)
+                        rv[c][b] = t.rad[(c * t.rows + dk) * t.tw + tx + j];
+                    kv[b] = keys[dk * t.tw + tx + j];
+                }
+#pragma unroll
+                for (int b = 0; b < B; b++) {
+                    float df[C];
+#pragma unroll
+                    for (int c = 0; c < C; c++)
+                        df[c] = ec[c] - rv[c][b];
+                    if (j0 + b < t.rows && norm_below<C>(df, thr)) {
+                        m |= 1u << (j0 + b);
+                        kmin = min(kmin, kv[b]);
+                        kmax = max(kmax, kv[b]);
+                        n++;
+                    }
                 }
             }
         pm[dk] = m;
@@ -249,8 +264,16 @@ __device__ __forceinline__ float median_select_radix(const MedianTile& t, const 
             if (dk < t.rows) {
                 const uint32_t m = pm[dk];
                 const uint32_t* kr = keys + dk * t.tw + tx;
-                for (int j = 0; j < t.rows; j++)
-                    cnt += (int)((m >> j) & 1u) & (int)(kr[j] < trial);
+                for (int j0 = 0; j0 < t.rows; j0 += B) {
+                    uint32_t kv[B];
+#pragma unroll
+                    for (int b = 0; b < B; b++)
+                        kv[b] = kr[min(j0 + b, t.rows - 1)];
+                    const uint32_t mb = m >> j0;   // (bits past the row's last column are 0)
+#pragma unroll
+                    for (int b = 0; b < B; b++)
+                        cnt += (int)((mb >> b) & 1u) & (int)(kv[b] < trial);
+                }
             }
         return cnt;
     });

@@ -249,6 +249,8 @@ extern "C" int rslf_ctx_destroy(rslf_ctx* ctx) RSLF_API_TRY
     (void)hipFree(ctx->remain);
     (void)hipFree(ctx->sweep_mask);
     (void)hipFree(ctx->filtered);
+    for (hipEvent_t e : ctx->ev_pool)
+        (void)hipEventDestroy(e);
     if (ctx->ev0)
         (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1)
@@ -283,7 +285,10 @@ extern "C" int rslf_ctx_set_debug(rslf_ctx* ctx, const char* key, int value) RSL
         ctx->stream_share = value != 0;
     else if (strcmp(key, "claim_skip") == 0 && (value == 0 || value == 1))
         ctx->claim_skip = value;
-    else if (strcmp(key, "stream_groups") == 0 && value >= 0 && value <= 64)
+    else if (strcmp(key, "time_all") == 0 && (value == 0 || value == 1)) {
+        ctx->time_all = value;
+        ctx->ev_used = 0;
+    } else if (strcmp(key, "stream_groups") == 0 && value >= 0 && value <= 64)
         ctx->stream_groups = value;
     else if (strcmp(key, "stream_lds_kib") == 0 && value >= 16 && value <= 152) {
         ctx->stream_lds_bytes = (size_t)value << 10;

@@ -171,6 +171,12 @@ struct rslf_ctx {
     size_t staging_cap = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool ev_valid = false;
+    // "time_all" (rslf_ctx_set_debug): every scan launch sequence is bracketed by its own pair of events from this pool --
+    // rslf_scan_time_total_ms sums them -- so that a sweep's or a pyramid's SUMMED K2 time can be reported (bench.py's
+    // roofline on the sweep2d / f2c lines).  Off by default: an event is a packet of its own in the queue (~5.6 us each).
+    int time_all = 0;
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
     int last_spad = 0;   // register-scan slot count of the last K2 launch, 0 = none
     int last_kernel = 0; // RSLF_SCAN_* of the last K2 launch
     int num_cus = 0;           // compute units of the device (how many workgroups a launch needs to fill it)

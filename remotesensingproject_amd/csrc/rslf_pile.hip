@@ -379,16 +379,34 @@ extern "C" int rslf_depth_epi_scan(rslf_ctx* ctx, const rslf_volume* vol, const 
                                     (int)ctx->stream_lds_bytes));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k2_scan_stream<3>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)ctx->stream_lds_bytes));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k2_scan_stream_px<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)ctx->stream_lds_bytes));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k2_scan_stream_px<3>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)ctx->stream_lds_bytes));
         ctx->stream_attr_set = true;
     }
 
     HIP_TRY(hipGetLastError());   // anything an earlier enqueue left behind is not this launch's fault
     ctx->last_spad = spad;
-    ctx->last_kernel = spad ? (sp.px_waves ? RSLF_SCAN_REG_PX : RSLF_SCAN_REG) : use_chip ? RSLF_SCAN_CHIP : (stream_ok ? RSLF_SCAN_STREAM : RSLF_SCAN_GENERIC);
+    ctx->last_kernel = spad ? (sp.px_waves ? RSLF_SCAN_REG_PX : RSLF_SCAN_REG)
+                       : use_chip ? RSLF_SCAN_CHIP
+                       : stream_ok ? (sp.px_waves ? RSLF_SCAN_STREAM_PX : RSLF_SCAN_STREAM) : RSLF_SCAN_GENERIC;
     // The events that time K2 are marker packets of their own: ~5.6 us each before the next kernel starts (measured,
     // tools/probe_gaps.py) -- nothing beside a 66 ms scan, a tenth of a sweep's sparse visit.  A sweep times its first
     // (dense) visit only.
     const bool timed = !ctx->sweep_open || ctx->sweep_first;
+    hipEvent_t pool0 = nullptr, pool1 = nullptr;
+    if (ctx->time_all) {   // every launch sequence gets a pair of its own (rslf_scan_time_total_ms)
+        while (ctx->ev_pool.size() < ctx->ev_used + 2) {
+            hipEvent_t e = nullptr;
+            HIP_TRY(hipEventCreate(&e));
+            ctx->ev_pool.push_back(e);
+        }
+        pool0 = ctx->ev_pool[ctx->ev_used];
+        pool1 = ctx->ev_pool[ctx->ev_used + 1];
+        ctx->ev_used += 2;
+        HIP_TRY(hipEventRecord(pool0, st));
+    }
     if (timed)
         HIP_TRY(hipEventRecord(ctx->ev0, st));
     for (int v0 = 0; v0 < vol->V; v0 += rows_per_launch) {
@@ -415,6 +433,11 @@ extern "C" int rslf_depth_epi_scan(rslf_ctx* ctx, const rslf_volume* vol, const 
                 hipLaunchKernelGGL(k2_scan_chip<false>, grid, dim3(64 * kScanWaves), lds, st, a);
             else
                 hipLaunchKernelGGL(k2_scan_chip<true>, grid, dim3(64 * kScanWaves), lds, st, a);
+        } else if (use_stream && sp.px_waves) {
+            if (vol->C == 1)
+                hipLaunchKernelGGL(k2_scan_stream_px<1>, grid, dim3(64 * kScanWaves), lds, st, a);
+            else
+                hipLaunchKernelGGL(k2_scan_stream_px<3>, grid, dim3(64 * kScanWaves), lds, st, a);
         } else if (use_stream) {
             if (vol->C == 1)
                 hipLaunchKernelGGL(k2_scan_stream<1>, grid, dim3(64 * kScanWaves), lds, st, a);
@@ -433,6 +456,8 @@ extern "C" int rslf_depth_epi_scan(rslf_ctx* ctx, const rslf_volume* vol, const 
         HIP_TRY(hipEventRecord(ctx->ev1, st));
         ctx->ev_valid = true;
     }
+    if (pool1)
+        HIP_TRY(hipEventRecord(pool1, st));
 
     if (stats) {
         unsigned long long tot = 0;
@@ -660,6 +685,26 @@ extern "C" int rslf_depth1d_pile_run_host(rslf_ctx* ctx, const rslf_volume* vol,
     }
     (void)hipFree(blk);
     return rc;
+}
+RSLF_API_CATCH
+
+extern "C" int rslf_scan_time_total_ms(rslf_ctx* ctx, float* ms, int* launches) RSLF_API_TRY
+{
+    if (!ctx || !ms)
+        return fail(RSLF_ERR_INVALID_ARG, "NULL argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    double sum = 0.0;
+    for (size_t i = 0; i + 1 < ctx->ev_used; i += 2) {
+        float t = 0.0f;
+        HIP_TRY(hipEventSynchronize(ctx->ev_pool[i + 1]));
+        HIP_TRY(hipEventElapsedTime(&t, ctx->ev_pool[i], ctx->ev_pool[i + 1]));
+        sum += (double)t;
+    }
+    *ms = (float)sum;
+    if (launches)
+        *launches = (int)(ctx->ev_used / 2);
+    ctx->ev_used = 0;
+    return RSLF_OK;
 }
 RSLF_API_CATCH
 

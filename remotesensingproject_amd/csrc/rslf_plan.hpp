@@ -535,10 +535,10 @@ inline ScanPlan plan_scan(const ScanRequest& r, int nres)
     if (packed && (r.use_stream || r.use_chip))
         while (groups > 1 && ((n + 63) / 64) * groups * 64 * kPartialRecordBytes > kPartialBudget)
             groups /= 2;
-    // Packed launches of a register kernel: lanes own hypotheses, a wave owns a pixel (the gather of a sparse list is then
-    // 64 neighbouring taps of one scanline instead of 64 scanlines) -- no hypothesis groups, no records
+    // Packed launches of a register or streaming kernel: lanes own hypotheses, a wave owns a pixel (the gather of a sparse
+    // list is then 64 neighbouring taps of one scanline instead of 64 scanlines) -- no hypothesis groups, no records
     p.px_waves = 0;
-    if (packed && r.spad && !r.use_stream && !r.use_chip && r.px_mode != 0) {
+    if (packed && (r.spad || r.use_stream) && !r.use_chip && r.px_mode != 0) {
         int w = px_waves(r.dim_d);
         if (w == 0 && r.px_mode == 1)
             w = 1;

@@ -101,7 +101,7 @@ class Context:
         check(_lib.lib().rslf_ctx_synchronize(self._h), "rslf_ctx_synchronize")
 
     _DEBUG_DEFAULTS = dict(force_scan=0, force_groups=0, force_packed=-1, px=-1, stream_share=1, stream_groups=0, stream_lds_kib=80,
-                           claim_skip=1)   # = the library's own defaults (rslf_internal.hpp, plan::kStreamLdsBytes)
+                           claim_skip=1, time_all=0)   # = the library's own defaults (rslf_internal.hpp, plan::kStreamLdsBytes)
     _FORCE_SCAN = {None: 0, "auto": 0, "generic": 1, "stream": 2}
 
     def set_debug(self, **hooks) -> None:
@@ -119,6 +119,12 @@ class Context:
         ms = C.c_float()
         check(_lib.lib().rslf_last_scan_kernel_ms(self._h, C.byref(ms)), "rslf_last_scan_kernel_ms")
         return float(ms.value)
+
+    def scan_time_total_ms(self) -> tuple[float, int]:
+        """With set_debug(time_all=1): (summed K2 milliseconds, scan launches) since the last call; resets the sum."""
+        ms, n = C.c_float(), C.c_int()
+        check(_lib.lib().rslf_scan_time_total_ms(self._h, C.byref(ms), C.byref(n)), "rslf_scan_time_total_ms")
+        return float(ms.value), int(n.value)
 
     def close(self) -> None:
         # at interpreter shutdown the HIP runtime may already be gone: leave the handle to the OS

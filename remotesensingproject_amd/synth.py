@@ -16,6 +16,10 @@ CONFIGS = {
     "c2": dict(U=512, V=512, S=33, C=1, D=128, dmin=-1.0, dmax=2.96875, seed=20260001),
     "c3": dict(U=1920, V=1080, S=101, C=1, D=256, dmin=-2.0, dmax=5.96875, seed=20260003),
     "c5": dict(U=4096, V=2160, S=201, C=3, D=512, dmin=-2.0, dmax=5.984375, seed=20260005),
+    # the shapes of the reference's own published runs (report/rs_report.tex:427-437), synthetic fields: context lines of
+    # the fine-to-coarse / 2-D sweep rows, not BASELINE configs
+    "skysat_lr": dict(U=960, V=540, S=100, C=1, D=120, dmin=-1.0, dmax=4.0, seed=20260099),     # SkysatLR18, report:430
+    "mansion_lr": dict(U=1146, V=720, S=100, C=3, D=120, dmin=0.0, dmax=4.0, seed=20260099),    # MansionLR, report:406,427
 }
 
 

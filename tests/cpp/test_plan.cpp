@@ -304,11 +304,22 @@ static void test_scan_plans()
     sparse.dim_d = 128;
     CHECK(px_waves(256) == 4 && px_waves(128) == 2 && px_waves(120) == 2 && px_waves(64) == 1 && px_waves(40) == 1 && px_waves(512) == 4);
     CHECK(px_waves(32) == 0 && px_waves(16) == 0 && px_waves(2) == 0 && px_waves(300) == 1 && px_waves(200) == 4 && px_waves(100) == 2);
-    {   // the streaming kernel's packed launches keep their groups
+    {   // the streaming kernel's packed launches take the pixel-per-wave form too (k2_scan_stream_px, round 4): no groups, no
+        // records, the same LDS split as the row kernel; switched off, they keep their groups
         ScanRequest many = request(64, 512, 250, 1, 128);
         many.ctx_packed = true;
         many.ctx_groups = 8;
-        CHECK(many.use_stream && plan_scan(many, 192).px_waves == 0 && plan_scan(many, 192).groups == 8);
+        ScanPlan q = plan_scan(many, 192);
+        CHECK(many.use_stream && q.px_waves == 2 && q.groups == 1 && q.records == 0 && !q.packed_adapt && q.lds_bytes > 0);
+        many.px_mode = 0;
+        q = plan_scan(many, 192);
+        CHECK(q.px_waves == 0 && q.groups == 8 && q.records > 0);
+        ScanRequest mansion = request(720, 1146, 100, 3, 120);   // the sparse visits of the MansionLR shape: two waves per pixel
+        mansion.ctx_packed = true;
+        mansion.ctx_groups = kSweepGroups;
+        mansion.precompacted = 2;
+        q = plan_scan(mansion, 68);
+        CHECK(mansion.use_stream && q.packed && q.px_waves == 2 && q.groups == 1 && q.stream_park == 24);
     }
     // K1 left row lists: never packed, whatever the caller asked for
     sparse.precompacted = 1;

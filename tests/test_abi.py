@@ -34,7 +34,7 @@ def test_every_declared_symbol_is_exported(L):
 
 def test_abi_version_and_strings(L):
     from remotesensingproject_amd import _lib
-    assert L.rslf_abi_version() == _lib.ABI_VERSION == 5
+    assert L.rslf_abi_version() == _lib.ABI_VERSION == 6
     assert L.rslf_status_string(0) == b"ok"
     assert b"invalid" in L.rslf_status_string(-1)
 

@@ -151,7 +151,7 @@ def test_stream_kernel_per_pixel_ranges(rs, oracle_mod, hooks):
     assert np.array_equal(trbar.cpu().numpy(), ref.rbar)
 
 
-@pytest.mark.parametrize("packed", [0, 1, 2])   # 2 = packed, lanes own hypotheses (k2_scan_reg_px) wherever a register kernel runs
+@pytest.mark.parametrize("packed", [0, 1, 2])   # 2 = packed, lanes own hypotheses (k2_scan_reg_px / k2_scan_stream_px) wherever such a kernel runs
 @pytest.mark.parametrize("groups,force,C_,S,U,D", [
     (1, None, 1, 17, 130, 12),       # packed tiles alone
     (2, None, 1, 17, 130, 16),       # the smallest D a pair of groups accepts
@@ -179,7 +179,7 @@ def test_sparse_launch_shapes(rs, oracle_mod, hooks, packed, groups, force, C_, 
     vol = _vol("noise" if C_ == 1 else "struct", U, 5, S, C_, 900 + D, -1.5, 2.5)
     ref = oracle_mod.depth1d_pile_run(vol, -1.5, 2.5, D)
     comp, got = _run(rs, vol, -1.5, 2.5, D)
-    assert comp.stats.scan_kernel == {None: 4 if packed == 2 else 1, "stream": 2, "generic": 0}[force]
+    assert comp.stats.scan_kernel == {None: 4 if packed == 2 else 1, "stream": 5 if packed == 2 else 2, "generic": 0}[force]
     assert_pile_parity(got, ref, label="groups%d_packed%d_%s_C%d_D%d" % (groups, packed, force, C_, D))
 
 
@@ -709,3 +709,70 @@ def test_pixel_per_wave_kernel_against_the_oracle(rs, oracle_mod, hooks, C_, S, 
     for k in got:
         assert np.array_equal(got[k], other[k]), k
         assert np.array_equal(got[k], rows[k]), k
+
+
+@pytest.mark.parametrize("C_,S,U,V,D,dmin,dmax", [
+    (3, 56, 120, 3, 120, 0.0, 4.0),         # RGB just past the register kernels: 48 resident, the rest parked, two waves per pixel
+    (3, 100, 150, 2, 120, 0.0, 4.0),        # the MansionLR shape (report:406,427): resident + parked + a re-gathered tail
+    (3, 201, 90, 2, 64, -0.5, 0.5),         # c5's view count: one wave per pixel, a long tail; every pixel a border pixel
+    (3, 100, 400, 2, 40, -1.0, 1.0),        # interior pixels (no validity test), 24 idle lanes
+    (1, 224, 100, 2, 128, -0.25, 0.25),     # one channel past 192 views: 192 resident, 32 parked
+    (1, 300, 80, 2, 70, -0.2, 0.2),         # ... with a tail; two waves per pixel, 58 idle lanes
+    (1, 200, 64, 2, 9, -0.3, 0.3),          # forced where the plan would not choose it: 9 of 64 lanes busy
+])
+def test_stream_pixel_per_wave_kernel_against_the_oracle(rs, oracle_mod, hooks, C_, S, U, V, D, dmin, dmax):
+    """k2_scan_stream_px: the stream-class units (RGB > 48 views, one channel > 192) with a wave per pixel and the
+    hypotheses in its lanes -- the kernel of the sparse visits of a 100-view RGB sweep (core.hpp:993-1028).  Every plane
+    bit-identical to the oracle and to the pixel-per-lane streaming kernel (packed tiles with groups, and row tiles)."""
+    hooks(force_packed=1)
+    hooks(px=1)
+    vol = _vol("struct" if U >= 100 else "noise", U, V, S, C_, 5000 + S + D, dmin, dmax)
+    vol[:, :, U // 2: U // 2 + 3] *= np.float32(0.03)      # a dark band: gaps in the pixel list
+    ref = oracle_mod.depth1d_pile_run(vol, dmin, dmax, D)
+    comp, got = _run(rs, vol, dmin, dmax, D)
+    assert comp.stats.scan_kernel == 5
+    assert_pile_parity(got, ref, label="stream_px_C%d_S%d_D%d" % (C_, S, D))
+    hooks(px=0)
+    hooks(force_groups=2 if D >= 16 else 1)
+    comp2, other = _run(rs, vol, dmin, dmax, D)
+    assert comp2.stats.scan_kernel == 2
+    hooks(force_packed=0)
+    hooks(force_groups=0)
+    hooks(force_scan="stream")
+    comp3, rows = _run(rs, vol, dmin, dmax, D)
+    assert comp3.stats.scan_kernel == 2
+    for k in got:
+        if k == "disp_confidence":          # the double score sum's order differs between launch shapes (rslf_hip.h)
+            assert np.abs(got[k] - other[k]).max() <= 1e-5 and np.abs(got[k] - rows[k]).max() <= 1e-5
+            continue
+        assert np.array_equal(got[k], other[k]), k
+        assert np.array_equal(got[k], rows[k]), k
+
+
+def test_stream_pixel_per_wave_kernel_with_per_pixel_ranges(rs, oracle_mod, hooks):
+    """... under per-pixel [dmin, dmax] planes and a scan mask, as a fine-to-coarse level hands them in (dc.hpp:201-203)."""
+    import torch
+    rng = np.random.default_rng(99)
+    V, S, U, D, C_ = 3, 60, 140, 70, 3
+    vol = _vol("struct", U, V, S, C_, 77, -1.0, 2.0)
+    Ce, cm = oracle_mod.edge_confidence_pile(vol, S // 2)
+    dmin = rng.uniform(-1.0, 0.0, size=(V, U)).astype(np.float32)
+    dmax = (dmin + rng.uniform(0.5, 2.0, size=(V, U))).astype(np.float32)
+    mask = ((rng.uniform(size=(V, U)) < 0.2) * 255).astype(np.uint8) & cm
+    ref = oracle_mod.depth_epi_pile(vol, dmin, dmax, D, S // 2, Ce, cm, mask_vu=mask)
+    v = rs.Volume.from_dense(vol)
+    hooks(force_packed=1)
+    hooks(px=1)
+    t = lambda a: torch.from_numpy(a.copy()).cuda()
+    tCe, tcm, tmask = t(Ce), t(cm), t(mask)
+    tCd = torch.zeros((V, U), device="cuda"); td = torch.zeros((V, U), device="cuda"); trb = torch.zeros((V, U, C_), device="cuda")
+    tidx = torch.empty((V, U), dtype=torch.int32, device="cuda"); tsc = torch.empty((V, U), device="cuda")
+    st = rs.compute_1D_depth_epi_pile(v, t(dmin), t(dmax), D, S // 2, tCe, tcm, tCd, td, trb, None, tmask, idx_v_u=tidx, score_v_u=tsc,
+                                      want_stats=True)
+    torch.cuda.synchronize()
+    assert st.scan_kernel == 5 and st.pixels_scanned == int((mask > 0).sum())
+    assert np.array_equal(tidx.cpu().numpy(), ref.depth_idx)
+    assert np.array_equal(tsc.cpu().numpy(), ref.score)
+    assert np.array_equal(trb.cpu().numpy(), ref.rbar)
+    assert np.array_equal(td.cpu().numpy(), ref.depth)
+    assert np.abs(tCd.cpu().numpy() - ref.disp_confidence).max() <= 1e-5

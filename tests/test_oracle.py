@@ -13,20 +13,40 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 KEYS = ("edge_confidence", "edge_mask", "disp_confidence", "depth", "rbar", "depth_idx", "score", "depth_raw")
 
 
+# Noise fields at the BASELINE shapes (view count, hypothesis count and grid of configs[2] / configs[4]), a few scanlines
+# each: name -> (V, S, U, C, D, dmin, dmax, seed).  Inputs come from the seed; the oracle's planes are committed.
+NOISE_CASES = {
+    "c3noise": (16, 101, 1920, 1, 256, -2.0, 5.96875, 20260403),
+    "c5noise": (2, 201, 4096, 3, 512, -2.0, 5.984375, 20260405),
+}
+
+
+def noise_volume(name):
+    V, S, U, C, _, _, _, seed = NOISE_CASES[name]
+    return np.random.default_rng(seed).uniform(0.0, 1.0, size=(V, S, U, C)).astype(np.float32)
+
+
 def load_case(name):
     z = np.load(os.path.join(GOLD, name + ".npz"))
     meta = json.loads(str(z["meta"]))
-    if name == "c1crop":
+    if name in NOISE_CASES:
+        vol = noise_volume(name)
+    elif name == "c1crop":
         import oracle
         crop = np.load(os.path.join(GOLD, "c1_crop_000tif_rows400_424.npy"))
         norm, _ = oracle.normalize_f32(crop, meta["tif_max"])
+        vol = np.ascontiguousarray(np.repeat(norm[:, None, :, None], meta["views"], axis=1))
+    elif name == "c1full":   # BASELINE.json configs[0]: the whole 960 x 540 frame of data/000.tif in 9 identical views
+        import oracle
+        img = np.load(os.path.join(GOLD, "c1_000tif_960x540_f32.npz"))["image"]
+        norm, _ = oracle.normalize_f32(np.ascontiguousarray(img), meta["tif_max"])
         vol = np.ascontiguousarray(np.repeat(norm[:, None, :, None], meta["views"], axis=1))
     else:
         vol = np.load(os.path.join(GOLD, name + "_input.npy"))
     return vol, meta, {k: z[k] for k in KEYS}
 
 
-@pytest.mark.parametrize("name", ["c1crop", "rand1", "rgb", "edge"])
+@pytest.mark.parametrize("name", ["c1crop", "rand1", "rgb", "edge", "c1full", "c3noise", "c5noise"])
 def test_oracle_reproduces_golden(oracle_mod, name):
     vol, meta, want = load_case(name)
     r = oracle_mod.depth1d_pile_run(vol, meta["dmin"], meta["dmax"], meta["D"], meta["s_hat"])

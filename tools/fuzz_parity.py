@@ -38,7 +38,7 @@ def draw_case(rng):
     budget = 600000 if C == 1 else 250000          # oracle work ~ V*U*D*S
     U = int(rng.choice([1, 2, 7, 33, 63, 64, 65, 100, 129, 200, 260, 513, 700]))
     V = int(rng.integers(1, 13))
-    D = int(rng.choice([2, 3, 5, 8, 13, 16, 17, 31, 32, 40, 64]))
+    D = int(rng.choice([2, 3, 5, 8, 13, 16, 17, 31, 32, 40, 64, 70, 120]))
     while V * U * D * S > budget * 64 and D > 2:
         D = max(2, D // 2)
     while V * U * D * S > budget * 64 and U > 8:
@@ -52,7 +52,7 @@ def draw_case(rng):
                     planes=False, mask=bool(rng.uniform() < 0.3), force="", packed=0, groups=int(rng.choice([1, 1, 2, 4, 8])),
                     iters=float(rng.choice([10.0, 10.0, 1.0, 3.5, 12.0])), h=float(rng.choice([0.2, 0.2, 0.1, 0.5])),
                     thr=float(rng.choice([0.02, 0.02, 0.0, 0.2])), raw_thr=float(rng.choice([0.0, 0.0, 0.3])),
-                    median=int(rng.choice([5, 5, 3, 7, 1])), shadows=bool(rng.uniform() < 0.8), negative=False, interp=0,
+                    median=int(rng.choice([5, 5, 3, 7, 1, 0, 2, 4, 6, 9, 11, 13, 15, 21, 33])), shadows=bool(rng.uniform() < 0.8), negative=False, interp=0,
                     opening=(2, 1), form=str(rng.choice(["dense", "dense", "epis_f32", "epis_u8"])))
     return dict(C=C, S=S, U=U, V=V, D=D, dmin=lo, dmax=hi, kind=kind,
                 slope=float(rng.choice([1.0, 1.0, 0.5, 0.25, 1.5])),
@@ -62,13 +62,13 @@ def draw_case(rng):
                 packed=int(rng.uniform() < 0.4), groups=int(rng.choice([1, 1, 2, 4, 8])),
                 iters=float(rng.choice([10.0, 10.0, 1.0, 3.5, 12.0])), h=float(rng.choice([0.2, 0.2, 0.1, 0.5])),
                 thr=float(rng.choice([0.02, 0.02, 0.0, 0.2])), raw_thr=float(rng.choice([0.0, 0.0, 0.3])),
-                median=int(rng.choice([5, 5, 3, 7, 1])), shadows=bool(rng.uniform() < 0.8),
+                median=int(rng.choice([5, 5, 3, 7, 1, 0, 2, 4, 6, 9, 11, 13, 15, 21, 33])), shadows=bool(rng.uniform() < 0.8),
                 negative=bool(rng.uniform() < 0.1), interp=int(rng.choice([0, 0, 0, 0, 1, 2])),
                 opening=(int(rng.choice([0, 1, 2])), int(rng.choice([2, 3, 4, 5, 7]))) if rng.uniform() < 0.15 else (2, 1),
                 # how the light field reaches the device: dense device tensor, host EPIs (f32, scale 1), host EPIs
                 # normalised by their max (dc.hpp:442-460), uint8 EPIs (x/255, dc.hpp:470), uint8 image stack (io.cpp:194-227)
                 form=str(rng.choice(["dense", "dense", "epis_f32", "epis_max", "epis_u8", "images_u8"])),
-                # packed launches of a register kernel: lanes own hypotheses (k2_scan_reg_px) -- automatic / never / whenever it can run
+                # packed launches of a register / streaming kernel: lanes own hypotheses (k2_scan_reg_px, k2_scan_stream_px) -- automatic / never / whenever it can run
                 px=int(rng.choice([-1, -1, 0, 1])))
 
 

@@ -58,7 +58,7 @@ def sweep_case(i, rng):
     pr = rs.Depth1DParameters()
     if rng.uniform() < 0.4:
         for name, val in (("edge_score_threshold", float(rng.choice([0.02, 0.0, 0.1]))),
-                          ("median_filter_size", int(rng.choice([5, 3, 7, 1]))),
+                          ("median_filter_size", int(rng.choice([5, 5, 3, 7, 1, 0, 4, 6, 9, 11, 15, 33]))),
                           ("kernel_bandwidth", float(rng.choice([0.2, 0.1, 0.4]))),
                           ("mean_shift_max_iter", float(rng.choice([10.0, 3.0]))),
                           ("cut_shadows", int(rng.uniform() < 0.8)),
