@@ -137,7 +137,8 @@ int rslf_ctx_synchronize(rslf_ctx* ctx);
  *   "px"             -1 automatic | 0 never | 1 whenever it can run: packed launches of a register or streaming kernel put a pixel's
  *                    HYPOTHESES in the lanes of a wave (k2_scan_reg_px, k2_scan_stream_px) instead of 64 pixels
  *   "claim_skip"     1 (default) the 2-D sweep's claims skip views with nothing left to paint within reach | 0 off
- *   "stream_share"   1 (default) 63-pixel tiles sharing taps between lanes in the streaming kernel | 0 off
+ *   "stream_share"   63-pixel tiles sharing taps between lanes in the streaming kernel: 1 (default) where the samples gathered
+ *                    again on every pass are at least a quarter of the views | 0 never | 2 always
  *   "stream_groups"  0 automatic | hypothesis groups per tile of the streaming kernel's dense launches
  *   "stream_lds_kib" dynamic LDS of one streaming workgroup, KiB (default 80)
  *   "time_all"       0 (default) | 1: every scan launch is bracketed by its own pair of HIP events, summed and reset by

@@ -42,6 +42,13 @@ __host__ __device__ constexpr int stream_resident_for(int S, int C)
 {
     return S >= stream_resident_hi(C) ? stream_resident_hi(C) : (stream_resident_lo(C) > 0 && S >= stream_resident_lo(C)) ? stream_resident_lo(C) : 0;
 }
+// ... of the pixel-per-wave form: its gathers have no neighbour wave to share L1 lines with, and the residents past what
+// the registers hold -- compiler scratch -- cost it more than they save: RGB 48 instead of 68 is 13 % faster (67.4 vs 77.9 ms
+// on a dense 100-view list, profiles/r04_k2_variants.md)
+__host__ __device__ constexpr int stream_px_resident_for(int S, int C)
+{
+    return C == 3 ? (S >= stream_resident_lo(3) ? stream_resident_lo(3) : 0) : stream_resident_for(S, C);
+}
 
 // DENSE: the tile is 63 consecutive pixels of one scanline in lanes 0..62 and lane 63 stands on the pixel after them
 // (scan_stream_rows): a lane's right tap is then its neighbour's left tap, so the re-gathered tail loads ONE texel
@@ -559,7 +566,10 @@ __device__ __forceinline__ void scan_stream_rows(const ScanArgs& a, int v, int u
     }
 }
 
-template <int C>
+// One kernel per resident-prefix length and launch form (round 4): a single kernel holding all three prefix lengths and both
+// forms was allocated for the worst of its six paths and carried that path's scratch everywhere (544 B/lane for RGB).
+// NRES = stream_resident_for(S, C); PACKED = one packed pixel list (lanes on different scanlines: per-lane offsets).
+template <int C, int NRES, bool PACKED>
 __global__ __launch_bounds__(64 * kScanWaves) __attribute__((amdgpu_waves_per_eu(RSLF_STREAM_WAVES, 8))) void k2_scan_stream(ScanArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float s_stream_otab[];   // [kScanWaves][stream_wave_floats]
@@ -568,17 +578,28 @@ __global__ __launch_bounds__(64 * kScanWaves) __attribute__((amdgpu_waves_per_eu
     constexpr bool kEpiDyn = true;
     float* const epi_lds = otab;
     const int epi_stride = a.stream_wave_floats;
-    // packed tiles: lanes sit on different scanlines, offsets are per lane (the <true, false> body)
-    if (a.vol.S >= stream_resident_hi(C)) {
-        RSLF_SCAN_KERNEL_BODY((scan_stream_rows<C, stream_resident_hi(C)>(a, v, u, active, d0, d1, best, otab)),
-                              (scan_stream_body<C, true, false, stream_resident_hi(C)>(a, v, u, d0, d1, best, otab)))
-    } else if (stream_resident_lo(C) > 0 && a.vol.S >= stream_resident_lo(C)) {
-        RSLF_SCAN_KERNEL_BODY((scan_stream_rows<C, stream_resident_lo(C)>(a, v, u, active, d0, d1, best, otab)),
-                              (scan_stream_body<C, true, false, stream_resident_lo(C)>(a, v, u, d0, d1, best, otab)))
+    if constexpr (PACKED) {
+        RSLF_SCAN_PACKED_LOOP((scan_stream_body<C, true, false, NRES>(a, v, u, d0, d1, best, otab)))
     } else {
-        RSLF_SCAN_KERNEL_BODY((scan_stream_rows<C, 0>(a, v, u, active, d0, d1, best, otab)),
-                              (scan_stream_body<C, true, false, 0>(a, v, u, d0, d1, best, otab)))
+        RSLF_SCAN_ROW_TILE((scan_stream_rows<C, NRES>(a, v, u, active, d0, d1, best, otab)))
     }
+}
+
+// host side: f(kernel) for the instantiation with resident prefix `nres` (one of 0, stream_resident_lo(C), stream_resident_hi(C))
+template <int C, bool PACKED, class F>
+inline void stream_kernel_for(int nres, F f)
+{
+    if (nres == stream_resident_hi(C)) {
+        f(k2_scan_stream<C, stream_resident_hi(C), PACKED>);
+        return;
+    }
+    if constexpr (stream_resident_lo(C) > 0 && stream_resident_lo(C) != stream_resident_hi(C)) {
+        if (nres == stream_resident_lo(C)) {
+            f(k2_scan_stream<C, stream_resident_lo(C), PACKED>);
+            return;
+        }
+    }
+    f(k2_scan_stream<C, 0, PACKED>);
 }
 
 // Sparse launches of the stream-class units (RGB above 48 views, one channel above 192), lanes own HYPOTHESES
@@ -592,7 +613,7 @@ __global__ __launch_bounds__(64 * kScanWaves) __attribute__((amdgpu_waves_per_eu
 // reduction over hypotheses is scan_px_finish (k2_scan.hpp).  The fine-to-coarse run of the report's MansionLR shape
 // (1146 x 720, 100 views RGB, report/rs_report.tex:406,427; core.hpp:993-1028 is the caller) spends nine tenths of its time
 // in these launches.
-template <int C>
+template <int C, int NRES>
 __global__ __launch_bounds__(64 * kScanWaves) __attribute__((amdgpu_waves_per_eu(RSLF_STREAM_WAVES, 8))) void k2_scan_stream_px(ScanArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float s_stream_otab[];   // [kScanWaves][stream_wave_floats]
@@ -618,21 +639,28 @@ __global__ __launch_bounds__(64 * kScanWaves) __attribute__((amdgpu_waves_per_eu
         const float dlo = a.dmin_vu ? a.dmin_vu[o] : a.dmin, dhi = a.dmax_vu ? a.dmax_vu[o] : a.dmax;
         const float reach = (float)max(a.s_hat, a.vol.S - 1 - a.s_hat) * fmaxf(fabsf(dlo), fabsf(dhi)) * fabsf(a.k.slope) + 2.0f;
         const bool interior = (float)u - reach >= 0.0f && (float)u + reach <= (float)(a.vol.U - 1);   // wave-uniform
-        auto run = [&](auto nres_tag) {
-            constexpr int NRES = decltype(nres_tag)::value;
-            if (interior)
-                scan_stream_body<C, false, false, NRES, false, true>(a, v, u, 0, a.dim_d, best, otab, dlane, dstep);
-            else
-                scan_stream_body<C, true, false, NRES, false, true>(a, v, u, 0, a.dim_d, best, otab, dlane, dstep);
-        };
-        if (a.vol.S >= stream_resident_hi(C))
-            run(std::integral_constant<int, stream_resident_hi(C)>{});
-        else if (stream_resident_lo(C) > 0 && a.vol.S >= stream_resident_lo(C))
-            run(std::integral_constant<int, stream_resident_lo(C)>{});
+        if (interior)
+            scan_stream_body<C, false, false, NRES, false, true>(a, v, u, 0, a.dim_d, best, otab, dlane, dstep);
         else
-            run(std::integral_constant<int, 0>{});
+            scan_stream_body<C, true, false, NRES, false, true>(a, v, u, 0, a.dim_d, best, otab, dlane, dstep);
         scan_px_finish<C>(a, o, have, best, wave, lane, wpp, s_rec, s_sum);
     }
+}
+
+template <int C, class F>
+inline void stream_px_kernel_for(int nres, F f)
+{
+    if (nres == stream_resident_hi(C)) {
+        f(k2_scan_stream_px<C, stream_resident_hi(C)>);
+        return;
+    }
+    if constexpr (stream_resident_lo(C) > 0 && stream_resident_lo(C) != stream_resident_hi(C)) {
+        if (nres == stream_resident_lo(C)) {
+            f(k2_scan_stream_px<C, stream_resident_lo(C)>);
+            return;
+        }
+    }
+    f(k2_scan_stream_px<C, 0>);
 }
 
 }  // namespace rslf

@@ -281,8 +281,8 @@ extern "C" int rslf_ctx_set_debug(rslf_ctx* ctx, const char* key, int value) RSL
         ctx->force_packed = value;
     else if (strcmp(key, "px") == 0 && value >= -1 && value <= 1)
         ctx->px_mode = value;
-    else if (strcmp(key, "stream_share") == 0 && (value == 0 || value == 1))
-        ctx->stream_share = value != 0;
+    else if (strcmp(key, "stream_share") == 0 && value >= 0 && value <= 2)
+        ctx->stream_share = value;
     else if (strcmp(key, "claim_skip") == 0 && (value == 0 || value == 1))
         ctx->claim_skip = value;
     else if (strcmp(key, "time_all") == 0 && (value == 0 || value == 1)) {
@@ -292,7 +292,6 @@ extern "C" int rslf_ctx_set_debug(rslf_ctx* ctx, const char* key, int value) RSL
         ctx->stream_groups = value;
     else if (strcmp(key, "stream_lds_kib") == 0 && value >= 16 && value <= 152) {
         ctx->stream_lds_bytes = (size_t)value << 10;
-        ctx->stream_attr_set = false;
     } else
         return fail(RSLF_ERR_INVALID_ARG, "rslf_ctx_set_debug: unknown key or value out of range: %s = %d", key, value);
     return RSLF_OK;

@@ -189,9 +189,8 @@ struct rslf_ctx {
     int force_packed = -1;     // 0 / 1
     int px_mode = -1;          // pixel-per-wave kernel on packed launches: -1 automatic, 0 never, 1 whenever it can run
     int stream_groups = 0;     // streaming kernel, dense launches: hypothesis groups per tile (0 = kStreamGroups)
-    bool stream_share = true;  // streaming kernel: 63-pixel row tiles whose tail shares taps between neighbouring lanes
+    int stream_share = 1;      // streaming kernel: 63-pixel row tiles whose tail shares taps between neighbouring lanes: 0 never, 1 where the tail is long (plan::stream_shares_taps), 2 always
     size_t stream_lds_bytes = rslf::plan::kStreamLdsBytes;   // dynamic LDS of one streaming workgroup
-    bool stream_attr_set = false;
     bool chip_attr_set = false;
     int claim_skip = 1;        // 2-D sweep: the claims skip views with nothing left to paint within reach (0: off, A/B and tests)
     rslf::Partial* scan_partial = nullptr;   // [tile][group][64] records of grouped scan launches

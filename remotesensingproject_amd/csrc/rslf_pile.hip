@@ -241,7 +241,7 @@ int rslf::scan_presize(rslf_ctx* ctx, int S, int U, int C, int dim_d, const rslf
     for (int i = 0; i < n_rows; i++) {
         max_rows = std::max(max_rows, rows[i]);
         const plan::ScanPlan sp = plan::plan_scan(scan_request(ctx, rows[i], U, S, C, dim_d, ch, fused ? 1 : 0),
-                                                  ch.use_stream ? stream_resident_for(S, C) : 0);
+                                                  ch.use_stream ? stream_resident_for(S, C) : 0, ch.use_stream ? stream_px_resident_for(S, C) : -1);
         recs = std::max(recs, sp.records);
         tickets = std::max(tickets, sp.tickets);
     }
@@ -308,7 +308,8 @@ extern "C" int rslf_depth_epi_scan(rslf_ctx* ctx, const rslf_volume* vol, const 
     // Launch shape (rslf_plan.hpp, plan_scan): hypothesis groups per tile, packed or row tiles, 63- or 64-entry tiles, row
     // blocks and records of grouped launches, the streaming kernel's LDS split -- pure host logic, unit-tested on the CPU.
     const plan::ScanRequest rq = scan_request(ctx, vol->V, vol->U, vol->S, vol->C, dim_d, ch, precompacted);
-    const plan::ScanPlan sp = plan::plan_scan(rq, use_stream ? stream_resident_for(vol->S, vol->C) : 0);
+    const plan::ScanPlan sp = plan::plan_scan(rq, use_stream ? stream_resident_for(vol->S, vol->C) : 0,
+                                              use_stream ? stream_px_resident_for(vol->S, vol->C) : -1);
     const int groups = sp.groups;
     const bool packed = sp.packed;
 
@@ -374,18 +375,7 @@ extern "C" int rslf_depth_epi_scan(rslf_ctx* ctx, const rslf_volume* vol, const 
                                     (int)kChipLdsBytes));
         ctx->chip_attr_set = true;
     }
-    if (use_stream && !ctx->stream_attr_set) {   // more than the 64 KiB a kernel gets without asking
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k2_scan_stream<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)ctx->stream_lds_bytes));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k2_scan_stream<3>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)ctx->stream_lds_bytes));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k2_scan_stream_px<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)ctx->stream_lds_bytes));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k2_scan_stream_px<3>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)ctx->stream_lds_bytes));
-        ctx->stream_attr_set = true;
-    }
-
+    // (more than the 64 KiB a kernel gets without asking: set on the instantiation about to be launched, below)
     HIP_TRY(hipGetLastError());   // anything an earlier enqueue left behind is not this launch's fault
     ctx->last_spad = spad;
     ctx->last_kernel = spad ? (sp.px_waves ? RSLF_SCAN_REG_PX : RSLF_SCAN_REG)
@@ -433,16 +423,32 @@ extern "C" int rslf_depth_epi_scan(rslf_ctx* ctx, const rslf_volume* vol, const 
                 hipLaunchKernelGGL(k2_scan_chip<false>, grid, dim3(64 * kScanWaves), lds, st, a);
             else
                 hipLaunchKernelGGL(k2_scan_chip<true>, grid, dim3(64 * kScanWaves), lds, st, a);
-        } else if (use_stream && sp.px_waves) {
-            if (vol->C == 1)
-                hipLaunchKernelGGL(k2_scan_stream_px<1>, grid, dim3(64 * kScanWaves), lds, st, a);
-            else
-                hipLaunchKernelGGL(k2_scan_stream_px<3>, grid, dim3(64 * kScanWaves), lds, st, a);
         } else if (use_stream) {
-            if (vol->C == 1)
-                hipLaunchKernelGGL(k2_scan_stream<1>, grid, dim3(64 * kScanWaves), lds, st, a);
-            else
-                hipLaunchKernelGGL(k2_scan_stream<3>, grid, dim3(64 * kScanWaves), lds, st, a);
+            // one instantiation per channel count, resident-prefix length and launch form (k2_stream.hpp)
+            hipError_t attr = hipSuccess;
+            auto launch = [&](auto kernel) {
+                attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)ctx->stream_lds_bytes);   // (more than the 64 KiB a kernel gets without asking)
+                if (attr == hipSuccess)
+                    hipLaunchKernelGGL(kernel, grid, dim3(64 * kScanWaves), lds, st, a);
+            };
+            if (sp.px_waves) {
+                if (vol->C == 1)
+                    stream_px_kernel_for<1>(sp.stream_nres, launch);
+                else
+                    stream_px_kernel_for<3>(sp.stream_nres, launch);
+            } else if (packed) {
+                if (vol->C == 1)
+                    stream_kernel_for<1, true>(sp.stream_nres, launch);
+                else
+                    stream_kernel_for<3, true>(sp.stream_nres, launch);
+            } else {
+                if (vol->C == 1)
+                    stream_kernel_for<1, false>(sp.stream_nres, launch);
+                else
+                    stream_kernel_for<3, false>(sp.stream_nres, launch);
+            }
+            HIP_TRY(attr);
         } else if (vol->C == 1) {
             hipLaunchKernelGGL(k2_scan_generic<1>, grid, dim3(64 * kScanWaves), 0, st, a);
         } else {

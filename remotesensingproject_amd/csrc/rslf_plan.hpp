@@ -461,7 +461,7 @@ struct ScanRequest {
     int force_packed;
     int px_mode;           // pixel-per-wave kernel for packed launches of a register kernel: -1 automatic, 0 never, 1 whenever it can run
     int stream_groups;     // 0 = kStreamGroups
-    bool stream_share;     // 63-pixel row tiles (shared taps)
+    int stream_share;      // 63-pixel row tiles (shared taps): 0 never, 1 where the re-gathered tail is long enough to pay for them, 2 always
     size_t stream_lds_bytes;
 };
 
@@ -476,6 +476,7 @@ struct ScanPlan {
     size_t records;        // 32-byte records the launches need (0 when groups == 1)
     size_t tickets;        // one int per tile of a launch
     // streaming kernel
+    int stream_nres;       // resident prefix of the instantiation that runs (k2_stream.hpp)
     int stream_park;       // samples per lane parked in LDS
     int stream_wave_floats;
     size_t lds_bytes;
@@ -483,8 +484,31 @@ struct ScanPlan {
 
 inline int stream_resident_hi(int C, int nres_1ch, int nres_rgb) { return C == 1 ? nres_1ch : nres_rgb; }
 
-// `nres` = the streaming kernel's resident prefix for this volume (stream_resident_for), needed only with use_stream.
-inline ScanPlan plan_scan(const ScanRequest& r, int nres)
+// The streaming kernel's LDS per wave: the S view offsets (rounded up to 4) and as many batches of parked samples as the
+// workgroup's share leaves room for (never past the end of the views).  Returns the parked samples per lane.
+inline int stream_park_for(int S, int C, int nres, size_t stream_lds_bytes)
+{
+    if (nres <= 0)
+        return 0;
+    const int batch = C == 1 ? 8 : 4;
+    const size_t s4 = ((size_t)S + 3) & ~(size_t)3;
+    size_t room = stream_lds_bytes / kScanWavesPerTile / sizeof(float);   // floats per wave
+    room -= std::min(room, s4);
+    int park = (int)(room / ((size_t)C * 64));
+    park = std::min(park, S - nres);
+    park = std::max(park, 0);
+    return park - park % batch;
+}
+
+// Shared taps (63-pixel row tiles, one texel load per sample, the right tap from lane + 1) halve the loads of the samples
+// that are gathered again on EVERY pass -- and cost a lane per tile.  They pay where that tail is long: 109 of 201 views at
+// c5 (+9 %); at 100 views RGB the tail is 8 samples and plain 64-pixel tiles are 6 % faster (47.5 vs 44.7 ms,
+// profiles/r04_k2_variants.md).  Rule: the tail is at least a quarter of the views.
+inline bool stream_shares_taps(int S, int nres, int park) { return 4 * (S - nres - park) >= S; }
+
+// `nres` = the streaming kernel's resident prefix for this volume (stream_resident_for), needed only with use_stream;
+// `nres_px` = the prefix of its pixel-per-wave form (stream_px_resident_for; -1: the same).
+inline ScanPlan plan_scan(const ScanRequest& r, int nres, int nres_px = -1)
 {
     ScanPlan p;
     const size_t n = (size_t)r.V * r.U;
@@ -523,7 +547,21 @@ inline ScanPlan plan_scan(const ScanRequest& r, int nres)
     while (groups > 1 && r.dim_d < 2 * kScanWavesPerTile * groups)
         groups /= 2;
 
-    p.tile_w = ((r.use_stream || r.use_chip) && !packed && r.stream_share) ? 63 : 64;
+    // Packed launches of a register or streaming kernel: lanes own hypotheses, a wave owns a pixel (the gather of a sparse
+    // list is then 64 neighbouring taps of one scanline instead of 64 scanlines) -- no hypothesis groups, no records
+    int px_w = 0;
+    if (packed && (r.spad || r.use_stream) && !r.use_chip && r.px_mode != 0) {
+        px_w = px_waves(r.dim_d);
+        if (px_w == 0 && r.px_mode == 1)
+            px_w = 1;
+    }
+    if (px_w && r.use_stream && nres_px >= 0)
+        nres = nres_px;
+    p.stream_nres = r.use_stream ? nres : 0;
+    const int park_early = r.use_stream ? stream_park_for(r.S, r.C, nres, r.stream_lds_bytes) : 0;
+    const bool share = r.use_chip ? r.stream_share != 0
+                                  : r.use_stream && (r.stream_share == 2 || (r.stream_share == 1 && stream_shares_taps(r.S, nres, park_early)));
+    p.tile_w = (share && !packed) ? 63 : 64;
     // 63-entry tiles: a row's last tile takes up to 64 entries (scan_tile)
     p.tiles_per_row = p.tile_w == 63 ? std::max(1, (r.U + 61) / 63) : (r.U + p.tile_w - 1) / p.tile_w;
     p.packed_adapt = packed && !r.use_stream && !r.use_chip;
@@ -535,18 +573,10 @@ inline ScanPlan plan_scan(const ScanRequest& r, int nres)
     if (packed && (r.use_stream || r.use_chip))
         while (groups > 1 && ((n + 63) / 64) * groups * 64 * kPartialRecordBytes > kPartialBudget)
             groups /= 2;
-    // Packed launches of a register or streaming kernel: lanes own hypotheses, a wave owns a pixel (the gather of a sparse
-    // list is then 64 neighbouring taps of one scanline instead of 64 scanlines) -- no hypothesis groups, no records
-    p.px_waves = 0;
-    if (packed && (r.spad || r.use_stream) && !r.use_chip && r.px_mode != 0) {
-        int w = px_waves(r.dim_d);
-        if (w == 0 && r.px_mode == 1)
-            w = 1;
-        p.px_waves = w;
-        if (w) {
-            groups = 1;
-            p.packed_adapt = false;
-        }
+    p.px_waves = px_w;
+    if (px_w) {
+        groups = 1;
+        p.packed_adapt = false;
     }
     p.groups = groups;
     p.packed = packed;
@@ -565,17 +595,8 @@ inline ScanPlan plan_scan(const ScanRequest& r, int nres)
     if (r.use_stream) {
         // LDS per wave: the S view offsets (rounded up to 4) and as many batches of parked samples as the workgroup's
         // share leaves room for (never past the end of the views)
-        const int batch = r.C == 1 ? 8 : 4;
         const size_t s4 = ((size_t)r.S + 3) & ~(size_t)3;
-        int park = 0;
-        if (nres > 0) {
-            size_t room = r.stream_lds_bytes / kScanWavesPerTile / sizeof(float);   // floats per wave
-            room -= std::min(room, s4);
-            park = (int)(room / ((size_t)r.C * 64));
-            park = std::min(park, r.S - nres);
-            park = std::max(park, 0);
-            park -= park % batch;
-        }
+        const int park = park_early;
         p.stream_park = park;
         p.stream_wave_floats = (int)(s4 + (size_t)park * r.C * 64);
         p.stream_wave_floats = std::max(p.stream_wave_floats, 2 * (64 + (3 + r.C) * 32));   // room for the wave's EpilogueBlock

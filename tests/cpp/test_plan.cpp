@@ -216,7 +216,7 @@ static ScanRequest request(int V, int U, int S, int C, int D)
     r.force_packed = -1;
     r.px_mode = -1;
     r.stream_groups = 0;
-    r.stream_share = true;
+    r.stream_share = 1;
     r.stream_lds_bytes = kStreamLdsBytes;
     return r;
 }
@@ -320,6 +320,17 @@ static void test_scan_plans()
         mansion.precompacted = 2;
         q = plan_scan(mansion, 68);
         CHECK(mansion.use_stream && q.packed && q.px_waves == 2 && q.groups == 1 && q.stream_park == 24);
+        // shared taps only where the re-gathered tail is long: 8 of 100 views here (64-pixel tiles), 109 of 201 at c5 (63)
+        ScanRequest dense = request(720, 1146, 100, 3, 120);
+        CHECK(dense.use_stream && plan_scan(dense, 68).tile_w == 64 && !stream_shares_taps(100, 68, 24));
+        dense.stream_share = 2;
+        CHECK(plan_scan(dense, 68).tile_w == 63);
+        ScanRequest c5s = request(2160, 4096, 201, 3, 512);
+        c5s.use_chip = false;
+        c5s.use_stream = true;
+        CHECK(plan_scan(c5s, 68).tile_w == 63 && stream_shares_taps(201, 68, 24));
+        c5s.stream_share = 0;
+        CHECK(plan_scan(c5s, 68).tile_w == 64);
     }
     // K1 left row lists: never packed, whatever the caller asked for
     sparse.precompacted = 1;
@@ -342,7 +353,7 @@ static void test_scan_plans()
         r.force_groups = (rng() % 5 == 0) ? (int)(rng() % 70) : 0;
         r.force_packed = (int)(rng() % 3) - 1;
         r.stream_groups = (rng() % 6 == 0) ? (int)(rng() % 40) : 0;
-        r.stream_share = rng() & 1;
+        r.stream_share = (int)(rng() % 3);
         r.stream_lds_bytes = (size_t)(16 + rng() % 137) << 10;
         if (rng() % 7 == 0) {   // forced streaming kernel on a shape the register kernel would take
             r.spad = 0;

@@ -51,3 +51,23 @@ def test_bench_path_e2e_one_process_two_workers():
     assert j["e2e"]["value"] > 0 and len(j["e2e"]["calls_ms"]) == 3
     one = _run(["--path", "e2e", "--config", "c2", "--steps", "2"])
     assert one["n_gpus"] == 1 and one["e2e"]["value"] > 0
+
+
+@pytest.mark.parametrize("path", ["sweep2d", "f2c"])
+def test_rows_around_the_path_carry_roofline_and_cpu_baseline(path):
+    """`--path sweep2d` / `--path f2c`: the line carries `roofline` -- units x algorithmic flops over the
+    SUMMED K2 time of one run (every scan launch timed by its own pair of HIP events, a separate instrumented pass) and the
+    share of a step's wall time that is K2 -- and a `cpu_baseline` from the oracle's restatement of the same row."""
+    j = _run(["--path", path, "--config", "c2", "--rows", "96", "--steps", "2", "--warmup", "1"], env={"RSLF_CPU_THREADS": "8"})
+    assert j["config"]["path"] == path and j["value"] > 0
+    rf = j["roofline"]
+    assert 0 < rf["frac"] < 1 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
+    assert rf["kernel_ms"] > 0 and 0 < rf["k2_share"] <= 1.05 and rf["scan_launches"] >= 33
+    cb = j["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] == 8 and "scanlines" in cb["sample"]
+
+
+def test_c1_config_is_the_real_frame():
+    j = _run(["--config", "c1", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-e2e"])
+    assert j["config"]["pixels_scanned"] == 223271 and "000.tif" in j["data"]
+    assert j["config"]["scan_kernel"].startswith("k2_scan_reg<16,1>")

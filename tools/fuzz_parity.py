@@ -69,7 +69,9 @@ def draw_case(rng):
                 # normalised by their max (dc.hpp:442-460), uint8 EPIs (x/255, dc.hpp:470), uint8 image stack (io.cpp:194-227)
                 form=str(rng.choice(["dense", "dense", "epis_f32", "epis_max", "epis_u8", "images_u8"])),
                 # packed launches of a register / streaming kernel: lanes own hypotheses (k2_scan_reg_px, k2_scan_stream_px) -- automatic / never / whenever it can run
-                px=int(rng.choice([-1, -1, 0, 1])))
+                px=int(rng.choice([-1, -1, 0, 1])),
+                # the streaming kernel's shared-tap tiles: automatic (by the tail's length) / never / always
+                share=int(rng.choice([1, 1, 0, 2])))
 
 
 def make_volume(c, rng):
@@ -94,7 +96,8 @@ def make_volume(c, rng):
 
 def run_case(i, c, rng):
     # per-context hooks (rslf_ctx_set_debug)
-    rs.default_context(0).set_debug(force_scan=c["force"], force_packed=c["packed"], force_groups=c["groups"], px=c.get("px", -1))
+    rs.default_context(0).set_debug(force_scan=c["force"], force_packed=c["packed"], force_groups=c["groups"], px=c.get("px", -1),
+                                    stream_share=c.get("share", 1))
     vol = make_volume(c, rng)
     V, S, U, C = vol.shape
     po = oracle.default_params()

@@ -18,6 +18,9 @@ if os.environ.get("FORCE_SCAN"):
     v.ctx.set_debug(force_scan=int(os.environ["FORCE_SCAN"]))
 if os.environ.get("STREAM_SHARE"):   # 0: 64-pixel tiles, every hypothesis in the general two-tap form
     v.ctx.set_debug(stream_share=int(os.environ["STREAM_SHARE"]))
+for env, key in (("PACKED", "force_packed"), ("PX", "px")):   # launch shape of the sparse visits, on a dense list
+    if os.environ.get(env):
+        v.ctx.set_debug(**{key: int(os.environ[env])})
 if os.environ.get("FORCE_GROUPS"):
     v.ctx.set_debug(force_groups=int(os.environ["FORCE_GROUPS"]))
 comp = rs.Depth1DComputer_pile(v, dmin, dmax, D, parameters=params)

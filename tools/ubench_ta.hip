@@ -8,9 +8,12 @@
 #define LDS_PTR(p) ((void __attribute__((address_space(3)))*)(p))
 #define GLB_PTR(p) ((const void __attribute__((address_space(1)))*)(p))
 typedef float f3 __attribute__((ext_vector_type(3)));
-enum Mode { G_X4, G_X2, G_X4X2, C_X3, C_X4, C_X1, DMA_X4, DMA_X1, NMODES };
+enum Mode { G_X4, G_X2, G_X4X2, C_X3, C_X4, C_X1, DMA_X4, DMA_X1, PX_X4X2, PX_X3X3, PX_X1X6, NMODES };
 static const char* kNames[NMODES] = {"gather x4 (12-B stride)", "gather x2 (12-B stride)", "gather x4 + x2", "coalesced x3",
-                                     "coalesced x4", "coalesced x1", "LDS-DMA x4 coalesced", "LDS-DMA x1 coalesced"};
+                                     "coalesced x4", "coalesced x1", "LDS-DMA x4 coalesced", "LDS-DMA x1 coalesced",
+                                     // round 4: the pixel-per-wave kernels' pattern -- lanes = hypotheses of ONE pixel, lane l reads the
+                                     // texel pair at floor(l * f), f = |s_hat - s| * (hypothesis step) in [0, 1.7]: non-decreasing, irregular
+                                     "px x4 + x2 (f = j/4)", "px x3 + x3 (f = j/4)", "px 6 x x1 (f = j/4)"};
 constexpr int ROWB = 4160 * 12;
 
 template <int MODE>
@@ -45,6 +48,20 @@ __global__ __launch_bounds__(256) void k(const char* __restrict__ vol, float* ou
                 v[j] = *(const float4*)(row + lane * 16);
             if (MODE == C_X1)
                 v[j].x = *(const float*)(row + lane * 4);
+            if (MODE == PX_X4X2 || MODE == PX_X3X3 || MODE == PX_X1X6) {
+                const char* p = row + (int)((float)lane * (0.25f * (float)j)) * 12;
+                if (MODE == PX_X4X2) {
+                    v[j] = *(const float4*)p;
+                    const float2 b = *(const float2*)(p + 16);
+                    v[j].x += b.x, v[j].y += b.y;
+                } else if (MODE == PX_X3X3) {
+                    const f3 a = *(const f3*)p, b = *(const f3*)(p + 12);
+                    v[j].x = a.x + b.x, v[j].y = a.y + b.y, v[j].z = a.z + b.z;
+                } else {
+                    const float* q = (const float*)p;
+                    v[j].x = q[0] + q[3], v[j].y = q[1] + q[4], v[j].z = q[2] + q[5];
+                }
+            }
             if (MODE == DMA_X4)
                 __builtin_amdgcn_global_load_lds(GLB_PTR(row + lane * 16), LDS_PTR(stage + j * 256), 16, 0, 0);
             if (MODE == DMA_X1)
@@ -97,7 +114,10 @@ int main()
     run<C_X4>(d_vol, d_out, rows, stride, where);                  \
     run<C_X1>(d_vol, d_out, rows, stride, where);                  \
     run<DMA_X4>(d_vol, d_out, rows, stride, where);                \
-    run<DMA_X1>(d_vol, d_out, rows, stride, where);
+    run<DMA_X1>(d_vol, d_out, rows, stride, where);                \
+    run<PX_X4X2>(d_vol, d_out, rows, stride, where);               \
+    run<PX_X3X3>(d_vol, d_out, rows, stride, where);               \
+    run<PX_X1X6>(d_vol, d_out, rows, stride, where);
     ALL(2, ROWB, "L1")
     ALL(64, ROWB, "L2")
     return 0;
