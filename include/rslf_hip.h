@@ -253,7 +253,9 @@ int rslf_kernel_columns_pile(rslf_ctx* ctx, const rslf_volume* vol, const float*
                              const int32_t* d_idx_vu, float* d_K_vsu);
 
 /* rslf::selective_median_filter -- core.hpp:366-375, impl :663-718.
- * d_dst_vu must not alias d_src_vu; it is fully written (0 where mask is 0). */
+ * d_dst_vu must not alias d_src_vu; it is fully written (0 where mask is 0).
+ * `size` = a_size: the window is width = (size - 1) / 2 pixels either side (:686), so an even size is the next smaller
+ * odd window and 0 the 1 x 1 window; any size >= 0 runs (the report documents 11, report/rs_report.tex:388). */
 int rslf_selective_median(rslf_ctx* ctx, const rslf_volume* vol, const float* d_src_vu, float* d_dst_vu,
                           int s_hat, int size, const uint8_t* d_mask_vu, float epsilon);
 

@@ -37,7 +37,10 @@ namespace rslf {
 #define RSLF_STREAM_NRES_1CH 192
 #endif
 __host__ __device__ constexpr int stream_resident_hi(int C) { return C == 1 ? RSLF_STREAM_NRES_1CH : RSLF_STREAM_NRES_RGB; }
-__host__ __device__ constexpr int stream_resident_lo(int C) { return C == 1 ? 0 : 48; }
+#ifndef RSLF_STREAM_NRES_RGB_LO
+#define RSLF_STREAM_NRES_RGB_LO 48
+#endif
+__host__ __device__ constexpr int stream_resident_lo(int C) { return C == 1 ? 0 : RSLF_STREAM_NRES_RGB_LO; }
 __host__ __device__ constexpr int stream_resident_for(int S, int C)
 {
     return S >= stream_resident_hi(C) ? stream_resident_hi(C) : (stream_resident_lo(C) > 0 && S >= stream_resident_lo(C)) ? stream_resident_lo(C) : 0;
