@@ -1,4 +1,4 @@
-"""The committed measurements of this round hang together: every `profiles/r03_*_pmc.json`, every
+"""The committed measurements of the latest round hang together: every `profiles/r04_*_pmc.json`, every
 entry of `profiles/k2_traffic.json` and the resource table were taken on ONE source tree (the hash of csrc/ + the C-ABI
 header, remotesensingproject_amd.build.source_hash), each config's rocprofv3 average reproduces its un-profiled bench
 line's roofline fraction within 2 %, and the on-chip kernel's row of the resource table shows no scratch.  Whether that
@@ -11,34 +11,35 @@ import warnings
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PROF = os.path.join(ROOT, "profiles")
-TAGS = ("c3_n1", "c2_n1", "c1_n1", "c5_slice16", "c5_n1")
+RND = "r04"
+TAGS = ("c3_n1", "c2_n1", "c1_n1", "c5_slice16", "c5_n1", "mansion_lr_n1")
 
 
 def _load(name):
     return json.load(open(os.path.join(PROF, name)))
 
 
-def test_round3_profiles_come_from_one_source_tree():
+def test_the_rounds_profiles_come_from_one_source_tree():
     traffic = _load("k2_traffic.json")
-    hashes = {t: _load("r03_%s_pmc.json" % t)["source_hash"] for t in TAGS}
+    hashes = {t: _load("%s_%s_pmc.json" % (RND, t))["source_hash"] for t in TAGS}
     assert len(set(hashes.values())) == 1, hashes
     h = next(iter(hashes.values()))
     assert all(traffic[t]["source_hash"] == h for t in TAGS), {t: traffic[t]["source_hash"] for t in TAGS}
-    table = open(os.path.join(PROF, "r03_resource_table.txt")).read()
+    table = open(os.path.join(PROF, RND + "_resource_table.txt")).read()
     assert table.splitlines()[0].strip() == "# source hash %s" % h
     from remotesensingproject_amd import build
     if build.source_hash() != h:
-        warnings.warn("profiles/r03_* were measured on sources %s; this tree is %s" % (h, build.source_hash()))
+        warnings.warn("profiles/%s_* were measured on sources %s; this tree is %s" % (RND, h, build.source_hash()))
 
 
 def test_rocprof_average_reproduces_each_bench_line():
     for t in TAGS:
-        j = _load("r03_%s_pmc.json" % t)
+        j = _load("%s_%s_pmc.json" % (RND, t))
         rc = j["roofline_check"]
         # (the 16-scanline slice of c5 is a developer aid: its 32-ms launches run 2-2.6 % slower under the profiler than
         # un-profiled on every lease; the config's line of record is the full-size one, which agrees to 0.1 %)
         assert abs(rc["ratio"] - 1.0) <= (0.03 if t == "c5_slice16" else 0.02), (t, rc)
-        line = _load("r03_bench_%s.json" % t)
+        line = _load("%s_bench_%s.json" % (RND, t))
         assert abs(line["roofline"]["frac"] - rc["frac_of_the_unprofiled_line"]) < 1e-9, t
         assert abs(line["roofline"]["frac"] - line["roofline"]["achieved"] / line["roofline"]["peak"]) < 1e-9
         # the kernel cannot take longer than the step that contains it (same lease, un-profiled)
@@ -54,7 +55,7 @@ def test_c5_traffic_is_within_twice_the_algorithmic_bytes():
 
 
 def test_on_chip_kernel_has_no_scratch_in_the_resource_table():
-    rows = [ln for ln in open(os.path.join(PROF, "r03_resource_table.txt")) if re.match(r"^(rslf::)?k2_scan_chip\b", ln)]
+    rows = [ln for ln in open(os.path.join(PROF, RND + "_resource_table.txt")) if re.match(r"^(rslf::)?k2_scan_chip\b", ln)]
     assert len(rows) == 2, rows      # <false>: exactly 201 views (c5); <true>: 202 .. 220, the rest fetched per pass
     for row in rows:
         vgpr, sgpr, scratch, occ, lds = [int(x) for x in row.split()[-5:]]
@@ -74,10 +75,11 @@ def test_shipped_library_carries_the_scratch_figures_of_the_table():
         build.build()
     ks = {k.replace("rslf::", ""): v for k, v in kernel_metadata.kernels(lib).items()}
     assert len(ks) > 100
-    for name in ("k2_scan_chip<false>", "k2_scan_chip<true>", "k2_scan_reg<40, 1>", "k2_scan_reg<16, 1>", "k2_scan_reg_px<40, 1>"):
+    for name in ("k2_scan_chip<false>", "k2_scan_chip<true>", "k2_scan_reg<40, 1>", "k2_scan_reg<16, 1>", "k2_scan_reg_px<40, 1>",
+                 "k2_scan_reg<104, 1>", "k2_scan_reg_px<104, 1>", "k2_scan_stream<3, 0, false>", "k2_scan_stream_px<3, 0>"):
         assert ks[name]["private_segment_fixed_size"] == 0, (name, ks[name])
     assert ks["k2_scan_chip<false>"]["agpr_count"] == 256
-    table = open(os.path.join(PROF, "r03_resource_table.txt")).read().splitlines()
+    table = open(os.path.join(PROF, RND + "_resource_table.txt")).read().splitlines()
     if table[0].strip() != "# source hash %s" % build.source_hash():
         warnings.warn("the resource table is of another tree: not compared with this binary")
         return

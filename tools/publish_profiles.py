@@ -13,7 +13,8 @@ def stats(src_glob, dst):
     rows = list(csv.reader(open(f)))
     keep = [rows[0]] + [r for r in rows[1:] if "rslf::" in r[0]]
     csv.writer(open(dst, "w", newline=""), quoting=csv.QUOTE_ALL).writerows(keep)
-TAGS = {"r03f_c3": "c3_n1", "r03f_c2": "c2_n1", "r03f_c1": "c1_n1", "r03f_c5s16": "c5_slice16", "r03f_c5": "c5_n1"}
+TAGS = {rnd + "f_c3": "c3_n1", rnd + "f_c2": "c2_n1", rnd + "f_c1": "c1_n1", rnd + "f_c5s16": "c5_slice16", rnd + "f_c5": "c5_n1",
+        rnd + "f_mansion": "mansion_lr_n1"}   # (the last: the dense pile step of the report's MansionLR shape, 100 views RGB)
 for d, t in TAGS.items():
     if os.path.isdir(os.path.join("gpurun_out", d)):
         subprocess.run([sys.executable, "tools/summarize_profiles.py", rnd, t], env=dict(os.environ, PROF_DIR=d), stdout=subprocess.DEVNULL, check=True)
@@ -32,11 +33,17 @@ for src, dst in (("gpurun_out/bench_default.json", "bench_default"), ("gpurun_ou
         open("profiles/%s_%s.json" % (rnd, dst), "w").write(lastline(src))
 k = json.load(open("profiles/k2_traffic.json"))
 for t in TAGS.values():
+    if not os.path.exists("profiles/%s_%s_pmc.json" % (rnd, t)):
+        continue
     j = json.load(open("profiles/%s_%s_pmc.json" % (rnd, t))); rc = j["roofline_check"]; b = json.load(open("profiles/%s_bench_%s.json" % (rnd, t))); e = k[t]
     print("%-11s K2 %.3f ms frac %.4f csv %.4f ratio %.3f | step %.3f ms value %.0f | read %.3f write %.3f total %.3f GB clock %.2f hash %s" % (
         t, rc["kernel_ms_hip_events"], rc["frac_of_the_unprofiled_line"], rc["frac_from_the_rocprof_average"], rc["ratio"], b["ms_per_step"], b["value"],
         e["read_bytes"] / 1e9, e["write_bytes"] / 1e9, e["hbm_bytes_per_launch"] / 1e9, j.get("effective_clock_ghz_under_profiling"), j["source_hash"]))
 for f in ("bench_sweep2d_c2", "bench_f2c_c2", "context_f2c_skysat_lr", "context_f2c_mansion_lr", "context_sweep2d_c3"):
-    j = json.load(open("profiles/%s_%s.json" % (rnd, f))); print("%-28s %6d M units/s  %.3f ms" % (f, round(j["value"]), j["ms_per_step"]))
+    if not os.path.exists("profiles/%s_%s.json" % (rnd, f)):
+        continue
+    j = json.load(open("profiles/%s_%s.json" % (rnd, f))); r = j.get("roofline", {})
+    print("%-28s %6d M units/s  %.3f ms  frac %.4f k2_share %.3f  cpu %.1f" % (f, round(j["value"]), j["ms_per_step"], r.get("frac", float("nan")),
+                                                                            r.get("k2_share", float("nan")), j.get("cpu_baseline", {}).get("value", float("nan"))))
 j = json.load(open("profiles/%s_bench_default.json" % rnd)); print("default: value %.0f step %.2f ms frac %.4f e2e %.1f ms cpu %.1f" % (j["value"], j["ms_per_step"], j["roofline"]["frac"], j["e2e"]["ms"], j["cpu_baseline"]["value"]))
 j = json.load(open("profiles/%s_bench_c5_e2e.json" % rnd)); print("c5:      value %.0f step %.1f ms frac %.4f e2e %.1f ms" % (j["value"], j["ms_per_step"], j["roofline"]["frac"], j["e2e"]["ms"]))
