@@ -136,6 +136,8 @@ int rslf_ctx_synchronize(rslf_ctx* ctx);
  *   "force_packed"   -1 automatic | 0 row tiles | 1 one packed pixel list
  *   "px"             -1 automatic | 0 never | 1 whenever it can run: packed launches of a register or streaming kernel put a pixel's
  *                    HYPOTHESES in the lanes of a wave (k2_scan_reg_px, k2_scan_stream_px) instead of 64 pixels
+ *   "row_split"      1 (default) packed launches of stream-class volumes scan the rows that hold >= 64 pixels as row tiles of
+ *                    the packed list and leave the pixel-per-wave launch the rest | 0 the pixel-per-wave launch takes all
  *   "claim_skip"     1 (default) the 2-D sweep's claims skip views with nothing left to paint within reach | 0 off
  *   "stream_share"   63-pixel tiles sharing taps between lanes in the streaming kernel: 1 (default) where the samples gathered
  *                    again on every pass are at least a quarter of the views | 0 never | 2 always

@@ -211,9 +211,10 @@ __global__ __launch_bounds__(256) void k_compact_mask(const uint8_t* __restrict_
 // (compact_row_packed: k_compact.hpp -- the 2-D sweep's apply pass lists the next visit's pixels with it too)
 __global__ __launch_bounds__(256) void k_compact_mask_packed(const uint8_t* __restrict__ edge_mask, uint8_t* __restrict__ scan_mask,
                                                             int U, int* __restrict__ list, int* __restrict__ count,
-                                                            unsigned long long* __restrict__ total, int* __restrict__ packed_n)
+                                                            unsigned long long* __restrict__ total, int* __restrict__ packed_n,
+                                                            int* __restrict__ rowbase)
 {
-    compact_row_packed(blockIdx.x, edge_mask, scan_mask, U, list, count, total, packed_n);
+    compact_row_packed(blockIdx.x, edge_mask, scan_mask, U, list, count, total, packed_n, rowbase);
 }
 
 }  // namespace rslf

@@ -705,7 +705,7 @@ __global__ __launch_bounds__(64 * kScanWaves) __attribute__((amdgpu_waves_per_eu
     // through it (ChipTile): `lb` is made opaque in between, so the second derivation is not merged with the first
     Best<C> best;
     int v, d0, d1, e0, width, n;
-    int lb = xcd_logical_block(blockIdx.x, a.per_xcd);
+    int lb = RSLF_XCD_ROW_INTERLEAVE ? xcd_logical_block_rows(blockIdx.x, a.tiles_per_row * a.groups) : xcd_logical_block(blockIdx.x, a.per_xcd);
     if (!scan_tile_span(a, lb, v, e0, width, n))
         return;
     chip_chunk(a, lb % a.groups, wave, d0, d1);

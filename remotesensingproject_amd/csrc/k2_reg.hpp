@@ -467,10 +467,11 @@ void k2_scan_reg_px(ScanArgs a)
     const int dlane = sub * 64 + lane, dstep = 64 * wpp;
     for (int item = blockIdx.x; item < items; item += gridDim.x) {
         const int e = item * ppw + wave / wpp;
-        const bool have = e < n;   // (a workgroup's last pixels may be missing: those waves shadow the list's last entry and write nothing)
-        const unsigned o = (unsigned)__builtin_amdgcn_readfirstlane(a.list[have ? e : n - 1]);
+        const bool listed = e < n;   // (a workgroup's last pixels may be missing: those waves shadow the list's last entry and write nothing)
+        const unsigned o = (unsigned)__builtin_amdgcn_readfirstlane(a.list[listed ? e : n - 1]);
         const int v = (int)(o / (unsigned)a.vol.U);
         const int u = (int)(o - (unsigned)v * (unsigned)a.vol.U);
+        const bool have = listed && scan_px_owns(a, v);   // (wave-uniform; a row with many pixels is the row-tile launch's)
         Best<C> best;
         best.init();
         // the validity test (interp.hpp:182) can go where every sample line of every hypothesis stays inside the row
@@ -478,7 +479,9 @@ void k2_scan_reg_px(ScanArgs a)
         const float reach = (float)max(a.s_hat, a.vol.S - 1 - a.s_hat) * fmaxf(fabsf(dlo), fabsf(dhi)) * fabsf(a.k.slope) + 2.0f;
         const bool interior = (float)u - reach >= 0.0f && (float)u + reach <= (float)(a.vol.U - 1);   // wave-uniform
         constexpr int kGB = RSLF_PX_ROWLIKE ? 0 : packed_gather_batch(SPAD, C);
-        if (interior)
+        if (!have) {
+            // nothing to scan: the finish below still runs (its barriers are the workgroup's)
+        } else if (interior)
             scan_reg_body<SPAD, C, false, false, false, kGB, Best<C>, true>(a, v, u, 0, a.dim_d, best, nullptr, dlane, dstep);
         else
             scan_reg_body<SPAD, C, true, false, false, kGB, Best<C>, true>(a, v, u, 0, a.dim_d, best, nullptr, dlane, dstep);

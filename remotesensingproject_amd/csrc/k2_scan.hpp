@@ -35,6 +35,9 @@
 namespace rslf {
 
 constexpr int kScanWaves = 4;   // waves per workgroup = hypothesis chunks per tile
+#ifndef RSLF_XCD_ROW_INTERLEAVE
+#define RSLF_XCD_ROW_INTERLEAVE 1   // row-tile launches: scanlines dealt to the XCDs in turn (rslf_device.hpp); 0: contiguous eighths
+#endif
 
 struct ScanArgs {
     VolView vol;
@@ -82,6 +85,14 @@ struct ScanArgs {
     float stream_frac_max;
     // pixel-per-wave kernel (k2_scan_reg_px, sparse launches): waves that share one pixel's hypotheses, 1 / 2 / 4; 0 = not that kernel
     int px_waves;
+    // Row split of a packed list (sparse visits of stream-class volumes).  A row's entries are contiguous in the packed
+    // list (compact_row_packed), rowbase[v] = where they start.  Rows that hold at least `row_min` pixels are scanned as
+    // ROW tiles straight from the packed list -- 64 lanes on one scanline, a scalar EPI base, the tile's waves sharing
+    // their L1 lines: 11.6 ms for 180 k pixels of a banded 28 % mask where a pixel per wave takes 15.1
+    // (tools/probe_density.py) -- and the pixel-per-wave launch of the same list leaves those rows out (it wins below
+    // ~8 % density).  rowbase == nullptr: per-row lists at list[v * U] (dense launches); row_min == 0: no split.
+    const int* rowbase;
+    int row_min;
 };
 
 // Laid out WORD-major in memory ([item][word][lane], record_word): a wave's store of one word is then 256 contiguous bytes.
@@ -187,7 +198,7 @@ __device__ __forceinline__ bool scan_tile_span(const ScanArgs& a, int lb, int& v
     const int j = tile - vr * a.tiles_per_row;
     v = vr + a.v0;
     n = a.count[v];
-    if (j * a.tile_w >= n)
+    if (j * a.tile_w >= n || n < a.row_min)   // (row_min: a row with few pixels belongs to the pixel-per-wave launch)
         return false;
     // 63-entry tiles (streaming kernel, lane 63 left to the shared taps): the row's LAST tile takes up to 64 entries, so
     // that a row of 63 k + 1 pixels (4096 = 65 * 63 + 1) does not end in a tile of one
@@ -211,7 +222,11 @@ __device__ __forceinline__ bool scan_tile(const ScanArgs& a, int lb, int& v, int
     const int e = e0 + lane;
     active = lane < width && e < n;
     // idle lanes shadow the tile's last pixel so their addresses stay valid
-    u = a.list[(long long)v * a.vol.U + (active ? e : min(e0 + width, n) - 1)];
+    const int idx = active ? e : min(e0 + width, n) - 1;
+    if (a.rowbase)   // the row's stretch of a packed list: entries are pixel indices v * U + u
+        u = a.list[a.rowbase[v] + idx] - v * a.vol.U;
+    else
+        u = a.list[(long long)v * a.vol.U + idx];
     return true;
 }
 
@@ -274,6 +289,12 @@ __device__ __forceinline__ void write_pixel(const ScanArgs& a, long long o, floa
 // unless a score is below 2^-21, so in practice the same bits in any order).  Then across the waves that share the pixel
 // through `rec` / `wsum` (LDS, one row per wave of the workgroup), and the pixel is written by the first of them.
 constexpr int kPxRecFloats = 3 + 3;   // score, hypothesis (bits), disparity, rbar[<= 3]
+// Does this pixel-per-wave launch scan the pixels of scanline v?  Not where the row split hands the row to the row-tile launch.
+__device__ __forceinline__ bool scan_px_owns(const ScanArgs& a, int v)
+{
+    return a.row_min == 0 || a.count[v] < a.row_min;
+}
+
 template <int C>
 __device__ __forceinline__ void scan_px_finish(const ScanArgs& a, unsigned o, bool have, const Best<C>& best, int wave, int lane, int wpp,
                                                float (*rec)[kPxRecFloats], double* wsum)
@@ -660,7 +681,8 @@ __device__ __forceinline__ int packed_groups(int groups, int tiles, int adapt)
         Best<C> best;                                                                   \
         int v, u, d0, d1;                                                               \
         bool active;                                                                    \
-        const int lb = xcd_logical_block(blockIdx.x, a.per_xcd);                        \
+        const int lb = RSLF_XCD_ROW_INTERLEAVE ? xcd_logical_block_rows(blockIdx.x, a.tiles_per_row * a.groups) \
+                                               : xcd_logical_block(blockIdx.x, a.per_xcd); \
         if (!scan_tile(a, lb, v, u, active))                                            \
             return;                                                                     \
         CHUNK(a, lb % a.groups, d0, d1);                                                \

@@ -632,17 +632,20 @@ __global__ __launch_bounds__(64 * kScanWaves) __attribute__((amdgpu_waves_per_eu
     const int dlane = sub * 64 + lane, dstep = 64 * wpp;
     for (int item = blockIdx.x; item < items; item += gridDim.x) {
         const int e = item * ppw + wave / wpp;
-        const bool have = e < n;   // (a workgroup's last pixels may be missing: those waves shadow the list's last entry and write nothing)
-        const unsigned o = (unsigned)__builtin_amdgcn_readfirstlane(a.list[have ? e : n - 1]);
+        const bool listed = e < n;   // (a workgroup's last pixels may be missing: those waves shadow the list's last entry and write nothing)
+        const unsigned o = (unsigned)__builtin_amdgcn_readfirstlane(a.list[listed ? e : n - 1]);
         const int v = (int)(o / (unsigned)a.vol.U);
         const int u = (int)(o - (unsigned)v * (unsigned)a.vol.U);
+        const bool have = listed && scan_px_owns(a, v);   // (wave-uniform; a row with many pixels is the row-tile launch's)
         Best<C> best;
         best.init();
         // the validity test (interp.hpp:182) can go where every sample line of every hypothesis stays inside the row
         const float dlo = a.dmin_vu ? a.dmin_vu[o] : a.dmin, dhi = a.dmax_vu ? a.dmax_vu[o] : a.dmax;
         const float reach = (float)max(a.s_hat, a.vol.S - 1 - a.s_hat) * fmaxf(fabsf(dlo), fabsf(dhi)) * fabsf(a.k.slope) + 2.0f;
         const bool interior = (float)u - reach >= 0.0f && (float)u + reach <= (float)(a.vol.U - 1);   // wave-uniform
-        if (interior)
+        if (!have) {
+            // nothing to scan: the finish below still runs (its barriers are the workgroup's)
+        } else if (interior)
             scan_stream_body<C, false, false, NRES, false, true>(a, v, u, 0, a.dim_d, best, otab, dlane, dstep);
         else
             scan_stream_body<C, true, false, NRES, false, true>(a, v, u, 0, a.dim_d, best, otab, dlane, dstep);

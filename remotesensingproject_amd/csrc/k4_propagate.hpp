@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256) void k4_propagate_apply(int S, int V, int U, i
                                                          uint8_t* __restrict__ dirty, int s_next, const uint8_t* __restrict__ edge_mask_next_vu,
                                                          int* __restrict__ list, int* __restrict__ count,
                                                          unsigned long long* __restrict__ total, int* __restrict__ packed_n,
-                                                         int* __restrict__ remain)
+                                                         int* __restrict__ remain, int* __restrict__ rowbase)
 {
     __shared__ uint8_t s_flags[kApplyFlagSlots];
     const int nseg = (U + 255) >> 8;
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256) void k4_propagate_apply(int S, int V, int U, i
         __syncthreads();      // every thread has read the flags, and this row's mask writes are the workgroup's own
         if ((int)threadIdx.x < nseg)
             flags[threadIdx.x] = 0;
-        compact_row_packed(v, edge_mask_next_vu, mask_svu + (long long)s_next * V * U, U, list, count, total, packed_n);
+        compact_row_packed(v, edge_mask_next_vu, mask_svu + (long long)s_next * V * U, U, list, count, total, packed_n, rowbase);
         return;
     }
     // every other row, kApplyRowsPerBlock at a time: one coalesced load of their flags, then only the segments that hold

@@ -10,9 +10,12 @@ namespace rslf {
 // scan wavefront is full even when a scanline holds two or three pixels.  A block counts its row, claims
 // a range of the list with one atomic (rows land in arrival order; a pixel's result does not depend on
 // where in the list it sits), then writes the row's ascending u.  *packed_n must be 0 on entry.
+// `rowbase` (nullable): where the row's entries start in the list -- a row's entries are contiguous, so a scan can also
+// take the rows that hold many pixels as ROW tiles straight from the packed list (k2_scan.hpp, ScanArgs::rowbase).
 __device__ __forceinline__ void compact_row_packed(int v, const uint8_t* __restrict__ edge_mask, uint8_t* scan_mask, int U,
                                                    int* __restrict__ list, int* __restrict__ count,
-                                                   unsigned long long* __restrict__ total, int* __restrict__ packed_n)
+                                                   unsigned long long* __restrict__ total, int* __restrict__ packed_n,
+                                                   int* __restrict__ rowbase = nullptr)
 {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     __shared__ int wave_tot[4];
@@ -33,6 +36,8 @@ __device__ __forceinline__ void compact_row_packed(int v, const uint8_t* __restr
         const int row = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
         count[v] = row;
         base_s = row ? atomicAdd(packed_n, row) : 0;
+        if (rowbase)
+            rowbase[v] = base_s;
         if (row)
             atomicAdd(total, (unsigned long long)row);
     }

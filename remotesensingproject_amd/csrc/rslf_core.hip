@@ -67,7 +67,7 @@ int rslf::ensure_plane_scratch(rslf_ctx* ctx, int V, int U)
             HIP_TRY(hipFree(ctx->count));
         ctx->count = nullptr;
         ctx->count_cap = 0;
-        HIP_TRY(hipMalloc(&ctx->count, (size_t)V * sizeof(int)));
+        HIP_TRY(hipMalloc(&ctx->count, (size_t)2 * V * sizeof(int)));   // [count_cap] entries per row, then [count_cap] row bases of packed lists
         ctx->count_cap = V;
     }
     return RSLF_OK;
@@ -283,6 +283,8 @@ extern "C" int rslf_ctx_set_debug(rslf_ctx* ctx, const char* key, int value) RSL
         ctx->px_mode = value;
     else if (strcmp(key, "stream_share") == 0 && value >= 0 && value <= 2)
         ctx->stream_share = value;
+    else if (strcmp(key, "row_split") == 0 && value >= 0 && value <= 65536)
+        ctx->row_split = value;
     else if (strcmp(key, "claim_skip") == 0 && (value == 0 || value == 1))
         ctx->claim_skip = value;
     else if (strcmp(key, "time_all") == 0 && (value == 0 || value == 1)) {

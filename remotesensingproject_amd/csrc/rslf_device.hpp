@@ -266,4 +266,18 @@ __device__ __forceinline__ int xcd_logical_block(int b, int per_xcd)
     return (b & 7) * per_xcd + (b >> 3);
 }
 
+// The same for ROW tiles, balanced (round 4): XCD x takes the scanlines x, x + 8, x + 16, ... of the launch -- every scanline's
+// `row_blocks` logical blocks (tiles x hypothesis groups) in a row, so a scanline's tiles still share one L2 -- instead of
+// one contiguous eighth of the scanlines.  A contiguous eighth is as good while every scanline holds the same work; an
+// edge mask does not (textured and flat regions of an image; the bands of a sweep's later visits), and the launch then
+// lasts as long as its busiest XCD: 15.4 ms against 12.3 for the same pixel count spread evenly
+// (profiles/r04_k2_variants.md section 7).  Scanlines do not share EPI rows, so nothing is lost by interleaving them.
+// Returns a logical block >= rows * row_blocks for the surplus blocks of a launch (they return at once).
+__device__ __forceinline__ int xcd_logical_block_rows(int b, int row_blocks)
+{
+    const int slot = b >> 3;
+    const int k = slot / row_blocks;
+    return ((b & 7) + 8 * k) * row_blocks + (slot - k * row_blocks);
+}
+
 }  // namespace rslf

@@ -192,6 +192,7 @@ struct rslf_ctx {
     int stream_share = 1;      // streaming kernel: 63-pixel row tiles whose tail shares taps between neighbouring lanes: 0 never, 1 where the tail is long (plan::stream_shares_taps), 2 always
     size_t stream_lds_bytes = rslf::plan::kStreamLdsBytes;   // dynamic LDS of one streaming workgroup
     bool chip_attr_set = false;
+    int row_split = 1;         // packed launches of stream-class volumes: rows with many pixels as row tiles of the list (0: off; A/B and tests)
     int claim_skip = 1;        // 2-D sweep: the claims skip views with nothing left to paint within reach (0: off, A/B and tests)
     rslf::Partial* scan_partial = nullptr;   // [tile][group][64] records of grouped scan launches
     size_t partial_rec_cap = 0;

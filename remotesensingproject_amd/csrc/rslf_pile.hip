@@ -320,7 +320,7 @@ extern "C" int rslf_depth_epi_scan(rslf_ctx* ctx, const rslf_volume* vol, const 
         if (!ctx->packed_n_clean)
             HIP_TRY(hipMemsetAsync(packed_n, 0, sizeof(int), st));
         hipLaunchKernelGGL(k_compact_mask_packed, dim3(vol->V), dim3(256), 0, st, d_Ce_mask_vu, d_mask_vu, vol->U, ctx->list,
-                           ctx->count, ctx->total, packed_n);
+                           ctx->count, ctx->total, packed_n, ctx->count + ctx->count_cap);
     } else {
         hipLaunchKernelGGL(k_compact_mask, dim3(vol->V), dim3(256), 0, st, d_Ce_mask_vu, d_mask_vu, vol->U, ctx->list,
                            ctx->count, ctx->total);
@@ -358,6 +358,22 @@ extern "C" int rslf_depth_epi_scan(rslf_ctx* ctx, const rslf_volume* vol, const 
     a.ticket = nullptr;
     a.v0 = 0;
     a.groups = groups;
+    a.rowbase = nullptr;
+    a.row_min = 0;
+    // Row split (sparse visits of stream-class volumes): the rows of the packed list that hold many pixels go as ROW tiles --
+    // the streaming kernel's dense form, reading its tiles straight from the packed list -- and the pixel-per-wave launch
+    // takes the rest.  Both are queued; which rows each scans is settled on the device, from the rows' counts.
+    const bool row_split = packed && use_stream && sp.px_waves > 0 && ctx->row_split != 0 && precompacted != 1;
+    plan::ScanPlan spr = sp;
+    if (row_split) {
+        plan::ScanRequest rr = rq;
+        rr.ctx_packed = false;
+        rr.ctx_groups = 1;
+        rr.precompacted = 1;      // the lists are in place
+        rr.force_packed = 0;
+        spr = plan::plan_scan(rr, stream_resident_for(vol->S, vol->C));
+        a.row_min = ctx->row_split > 1 ? ctx->row_split : plan::kRowSplitMin;   // (hook: 1 = the default threshold, larger = that many pixels)
+    }
     // Grouped launches leave one 32-byte record per (tile, group, lane) for the tile's last group to merge (k2_scan.hpp)
     const int rows_per_launch = sp.rows_per_launch;
     if (groups > 1) {
@@ -366,6 +382,11 @@ extern "C" int rslf_depth_epi_scan(rslf_ctx* ctx, const rslf_volume* vol, const 
             return rc;
         a.partial = ctx->scan_partial;
         a.ticket = ctx->scan_ticket;
+    }
+    if (row_split && spr.groups > 1) {
+        rc = ensure_group_scratch(ctx, spr.records, spr.tickets);
+        if (rc)
+            return rc;
     }
     const size_t lds = sp.lds_bytes;
     if (use_chip && !ctx->chip_attr_set) {
@@ -386,7 +407,8 @@ extern "C" int rslf_depth_epi_scan(rslf_ctx* ctx, const rslf_volume* vol, const 
     // (dense) visit only.
     const bool timed = !ctx->sweep_open || ctx->sweep_first;
     hipEvent_t pool0 = nullptr, pool1 = nullptr;
-    if (ctx->time_all) {   // every launch sequence gets a pair of its own (rslf_scan_time_total_ms)
+    if (ctx->time_all && ctx->ev_used + 2 <= ((size_t)1 << 16)) {   // every launch sequence gets a pair of its own (rslf_scan_time_total_ms;
+                                                                      // 32 768 untimed-for launches are the pool's end: later ones go untimed)
         while (ctx->ev_pool.size() < ctx->ev_used + 2) {
             hipEvent_t e = nullptr;
             HIP_TRY(hipEventCreate(&e));
@@ -399,6 +421,43 @@ extern "C" int rslf_depth_epi_scan(rslf_ctx* ctx, const rslf_volume* vol, const 
     }
     if (timed)
         HIP_TRY(hipEventRecord(ctx->ev0, st));
+    if (row_split) {   // the rows with many pixels, as row tiles of the packed list
+        ScanArgs ar = a;
+        ar.packed = 0;
+        ar.px_waves = 0;
+        ar.packed_adapt = 0;
+        ar.rowbase = ctx->count + ctx->count_cap;
+        ar.groups = spr.groups;
+        ar.tile_w = spr.tile_w;
+        ar.tiles_per_row = spr.tiles_per_row;
+        ar.stream_park = spr.stream_park;
+        ar.stream_wave_floats = spr.stream_wave_floats;
+        ar.partial = spr.groups > 1 ? ctx->scan_partial : nullptr;
+        ar.ticket = spr.groups > 1 ? ctx->scan_ticket : nullptr;
+        for (int v0 = 0; v0 < vol->V; v0 += spr.rows_per_launch) {
+            const int rows = std::min(spr.rows_per_launch, vol->V - v0);
+            const long long tiles = (long long)rows * ar.tiles_per_row;
+            if (tiles * ar.groups > (long long)1 << 30)
+                return fail(RSLF_ERR_UNSUPPORTED, "%lld tiles x %d groups exceeds the grid limit", tiles, ar.groups);
+            ar.v0 = v0;
+            ar.logical_blocks = (int)(tiles * ar.groups);
+            ar.per_xcd = ((rows + 7) / 8) * ar.tiles_per_row * ar.groups;
+            const dim3 rgrid((unsigned)(ar.per_xcd * 8));
+            hipError_t rattr = hipSuccess;
+            auto launch_rows = [&](auto kernel) {
+                rattr = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int)ctx->stream_lds_bytes);
+                if (rattr == hipSuccess)
+                    hipLaunchKernelGGL(kernel, rgrid, dim3(64 * kScanWaves), spr.lds_bytes, st, ar);
+            };
+            if (vol->C == 1)
+                stream_kernel_for<1, false>(spr.stream_nres, launch_rows);
+            else
+                stream_kernel_for<3, false>(spr.stream_nres, launch_rows);
+            HIP_TRY(rattr);
+            HIP_TRY(hipGetLastError());
+        }
+    }
     for (int v0 = 0; v0 < vol->V; v0 += rows_per_launch) {
         const int rows = std::min(rows_per_launch, vol->V - v0);
         // row tiles: ceil(U/64) per scanline; packed tiles: at most ceil(V*U/64), the device knows how many
@@ -407,7 +466,8 @@ extern "C" int rslf_depth_epi_scan(rslf_ctx* ctx, const rslf_volume* vol, const 
             return fail(RSLF_ERR_UNSUPPORTED, "%lld tiles x %d groups exceeds the grid limit", tiles, groups);
         a.v0 = v0;
         a.logical_blocks = (int)(tiles * groups);   // `groups` workgroups per tile, their waves split the hypotheses
-        a.per_xcd = (a.logical_blocks + 7) / 8;
+        // (row tiles: the scanlines are dealt to the XCDs in turn, every XCD ceil(rows / 8) of them: xcd_logical_block_rows)
+        a.per_xcd = packed ? (a.logical_blocks + 7) / 8 : ((rows + 7) / 8) * a.tiles_per_row * groups;
         // packed: a fixed grid strides over the items (k2_scan.hpp); ~4 workgroups per CU cover any occupancy
         // (the pixel-per-wave kernel's items are 4 / px_waves pixels each)
         const long long px_items = sp.px_waves ? ((long long)n * sp.px_waves + kScanWaves - 1) / kScanWaves : 0;

@@ -37,6 +37,7 @@ constexpr size_t kAutoGroupBudget = (size_t)96 << 20;              // ... of whi
 constexpr int kPackedItemTarget = 2048;                            // packed launches: (tile, group) items the device aims for
 constexpr int kSweepGroups = 32;                                   // workgroups sharing a packed tile on a sweep's sparse visits
 constexpr int kStreamGroups = 16;                                  // dense launches of the streaming kernel: workgroups per tile
+constexpr int kRowSplitMin = 64;                                   // packed launches of stream-class volumes: rows with at least this many pixels go as row tiles
 constexpr int kChipGroups = 8;                                     // ... of the on-chip kernel: half the records, same speed (profiles/r03_k2_variants.md)
 constexpr size_t kStreamLdsBytes = (size_t)80 << 10;               // dynamic LDS of one streaming workgroup (two per CU)
 constexpr size_t kStagingBudget = (size_t)256 << 20;               // device staging buffer of the chunked host upload

@@ -110,6 +110,13 @@ extern "C" int rslf_sweep_begin(rslf_ctx* ctx, const rslf_volume* vol, const uin
         // differ, that call sizes the records itself.)
         size_t recs = 0, tickets = 0;
         plan::sweep_record_plan(n, dim_d, scan_takes_stream(vol), &recs, &tickets);
+        if (scan_takes_stream(vol)) {   // the row split of the sparse visits: row tiles of the streaming kernel's dense form, in row blocks
+            const size_t tiles_per_row = (size_t)std::max(1, (U + 61) / 63);
+            const size_t per_row = tiles_per_row * plan::kStreamGroups * 64;
+            const size_t rows = std::min<size_t>((size_t)V, std::max<size_t>(1, plan::kPartialBudget / (per_row * plan::kPartialRecordBytes)));
+            recs = std::max(recs, rows * per_row);
+            tickets = std::max(tickets, rows * tiles_per_row);
+        }
         if (recs) {
             rc = ensure_group_scratch(ctx, recs, tickets);
             if (rc)
@@ -213,7 +220,7 @@ extern "C" int rslf_sweep_visit_finish(rslf_ctx* ctx, const rslf_volume* vol, in
     const unsigned apply_blocks = (unsigned)((s_next >= 0 ? V : 0) + ((long long)S * V + kApplyRowsPerBlock - 1) / kApplyRowsPerBlock);
     hipLaunchKernelGGL(k4_propagate_apply, dim3(apply_blocks), dim3(256), 0, st, S, V, U, s_hat, ctx->filtered, Cd, d_depth_svu,
                        d_Cd_svu, mask_svu, ctx->winner, ctx->dirty, s_next, s_next >= 0 ? d_Ce_mask_svu + (size_t)s_next * n : nullptr, ctx->list,
-                       ctx->count, ctx->total, packed_n, ctx->remain);
+                       ctx->count, ctx->total, packed_n, ctx->remain, ctx->count + ctx->count_cap);
     HIP_TRY(hipGetLastError());
     ctx->packed_n_clean = s_next < 0;       // k34_median_claim zeroed the packed list's length; a listing apply pass set it again
     ctx->precompacted = s_next >= 0 ? 2 : 0;

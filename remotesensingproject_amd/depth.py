@@ -101,7 +101,7 @@ class Context:
         check(_lib.lib().rslf_ctx_synchronize(self._h), "rslf_ctx_synchronize")
 
     _DEBUG_DEFAULTS = dict(force_scan=0, force_groups=0, force_packed=-1, px=-1, stream_share=1, stream_groups=0, stream_lds_kib=80,
-                           claim_skip=1, time_all=0)   # = the library's own defaults (rslf_internal.hpp, plan::kStreamLdsBytes)
+                           claim_skip=1, time_all=0, row_split=1)   # = the library's own defaults (rslf_internal.hpp, plan::kStreamLdsBytes)
     _FORCE_SCAN = {None: 0, "auto": 0, "generic": 1, "stream": 2}
 
     def set_debug(self, **hooks) -> None:

@@ -726,6 +726,7 @@ def test_stream_pixel_per_wave_kernel_against_the_oracle(rs, oracle_mod, hooks, 
     bit-identical to the oracle and to the pixel-per-lane streaming kernel (packed tiles with groups, and row tiles)."""
     hooks(force_packed=1)
     hooks(px=1)
+    hooks(row_split=0)          # every pixel to the pixel-per-wave kernel (the row split of the list has a test of its own)
     vol = _vol("struct" if U >= 100 else "noise", U, V, S, C_, 5000 + S + D, dmin, dmax)
     vol[:, :, U // 2: U // 2 + 3] *= np.float32(0.03)      # a dark band: gaps in the pixel list
     ref = oracle_mod.depth1d_pile_run(vol, dmin, dmax, D)
@@ -763,6 +764,7 @@ def test_stream_pixel_per_wave_kernel_with_per_pixel_ranges(rs, oracle_mod, hook
     v = rs.Volume.from_dense(vol)
     hooks(force_packed=1)
     hooks(px=1)
+    hooks(row_split=0)
     t = lambda a: torch.from_numpy(a.copy()).cuda()
     tCe, tcm, tmask = t(Ce), t(cm), t(mask)
     tCd = torch.zeros((V, U), device="cuda"); td = torch.zeros((V, U), device="cuda"); trb = torch.zeros((V, U, C_), device="cuda")
@@ -776,3 +778,61 @@ def test_stream_pixel_per_wave_kernel_with_per_pixel_ranges(rs, oracle_mod, hook
     assert np.array_equal(trb.cpu().numpy(), ref.rbar)
     assert np.array_equal(td.cpu().numpy(), ref.depth)
     assert np.abs(tCd.cpu().numpy() - ref.disp_confidence).max() <= 1e-5
+
+
+@pytest.mark.parametrize("C_,S,U,D,planes", [(3, 60, 300, 70, False), (3, 100, 260, 40, True), (1, 224, 200, 64, False)])
+def test_row_split_of_a_packed_list(rs, oracle_mod, hooks, C_, S, U, D, planes):
+    """Sparse visits of stream-class volumes (round 4): the rows of the packed list that hold >= 64 pixels are scanned as ROW
+    tiles straight from the list (row bases from the compaction, k2_scan_stream's dense form), the pixel-per-wave launch takes
+    the rows with fewer -- settled on the device from the rows' counts.  A scan mask with full rows, rows of 70 / 63 / 64 / 40
+    / 1 / 0 pixels: every plane equals the oracle's, and the un-split launch's, bit for bit."""
+    import torch
+    rng = np.random.default_rng(7 + S)
+    V = 9
+    vol = _vol("noise", U, V, S, C_, 6100 + S, -0.5, 0.5)
+    Ce, cm = oracle_mod.edge_confidence_pile(vol, S // 2)
+    assert (cm > 0).mean() > 0.9
+    mask = np.zeros((V, U), np.uint8)
+    pick = lambda r, k: rng.choice(np.flatnonzero(cm[r]), k, replace=False)   # k pixels of row r's edge mask
+    mask[0] = 255                                                   # a full row: several row tiles
+    mask[1, pick(1, 70)] = 255                                      # 70 scattered pixels: two row tiles
+    mask[2, pick(2, 63)] = 255                                      # 63: one short of the threshold -> pixel per wave
+    mask[3, pick(3, 64)] = 255                                      # 64: exactly the threshold -> one row tile
+    mask[4, 5:45] = 255                                             # 40 consecutive pixels -> pixel per wave
+    mask[5, U - 1] = 255                                            # one pixel at the border
+    mask[7] = 255                                                   # (row 6: nothing)
+    mask[8, ::2] = 255                                              # every other pixel of a row
+    mask &= cm
+    assert (mask[2] > 0).sum() == 63 and (mask[3] > 0).sum() == 64
+    if planes:
+        dmin = rng.uniform(-0.5, 0.0, size=(V, U)).astype(np.float32)
+        dmax = (dmin + rng.uniform(0.3, 1.0, size=(V, U))).astype(np.float32)
+    else:
+        dmin = np.full((V, U), -0.5, np.float32)
+        dmax = np.full((V, U), 0.5, np.float32)
+    ref = oracle_mod.depth_epi_pile(vol, dmin, dmax, D, S // 2, Ce, cm, mask_vu=mask)
+    v = rs.Volume.from_dense(vol)
+    t = lambda a: torch.from_numpy(a.copy()).cuda()
+    out = {}
+    for split in (1, 0):
+        hooks(force_packed=1)
+        hooks(px=1)
+        hooks(row_split=split)
+        tCe, tcm, tmask = t(Ce), t(cm), t(mask)
+        tCd = torch.zeros((V, U), device="cuda"); td = torch.zeros((V, U), device="cuda"); trb = torch.zeros((V, U, C_), device="cuda")
+        tidx = torch.empty((V, U), dtype=torch.int32, device="cuda"); tsc = torch.empty((V, U), device="cuda")
+        args = (t(dmin), t(dmax)) if planes else (-0.5, 0.5)
+        st = rs.compute_1D_depth_epi_pile(v, args[0], args[1], D, S // 2, tCe, tcm, tCd, td, trb, None, tmask, idx_v_u=tidx, score_v_u=tsc,
+                                          want_stats=True)
+        torch.cuda.synchronize()
+        assert st.scan_kernel == 5 and st.pixels_scanned == int((mask > 0).sum())
+        out[split] = dict(idx=tidx.cpu().numpy(), score=tsc.cpu().numpy(), rbar=trb.cpu().numpy(), depth=td.cpu().numpy(),
+                          Cd=tCd.cpu().numpy(), Ce=tCe.cpu().numpy(), cm=tcm.cpu().numpy())
+        assert np.array_equal(out[split]["idx"], ref.depth_idx), split
+        assert np.array_equal(out[split]["score"], ref.score), split
+        assert np.array_equal(out[split]["rbar"], ref.rbar), split
+        assert np.array_equal(out[split]["depth"], ref.depth), split
+        assert np.array_equal(out[split]["cm"], ref.edge_mask) and np.array_equal(out[split]["Ce"], ref.edge_confidence), split
+        assert np.abs(out[split]["Cd"] - ref.disp_confidence).max() <= 1e-5
+    for k in ("idx", "score", "rbar", "depth", "cm", "Ce"):
+        assert np.array_equal(out[1][k], out[0][k]), k

@@ -71,7 +71,9 @@ def draw_case(rng):
                 # packed launches of a register / streaming kernel: lanes own hypotheses (k2_scan_reg_px, k2_scan_stream_px) -- automatic / never / whenever it can run
                 px=int(rng.choice([-1, -1, 0, 1])),
                 # the streaming kernel's shared-tap tiles: automatic (by the tail's length) / never / always
-                share=int(rng.choice([1, 1, 0, 2])))
+                share=int(rng.choice([1, 1, 0, 2])),
+                # packed launches of stream-class volumes: rows with >= N pixels as row tiles of the list (1: the default 64; 0: off)
+                row_split=int(rng.choice([1, 1, 0, 4, 20])))
 
 
 def make_volume(c, rng):
@@ -97,7 +99,7 @@ def make_volume(c, rng):
 def run_case(i, c, rng):
     # per-context hooks (rslf_ctx_set_debug)
     rs.default_context(0).set_debug(force_scan=c["force"], force_packed=c["packed"], force_groups=c["groups"], px=c.get("px", -1),
-                                    stream_share=c.get("share", 1))
+                                    stream_share=c.get("share", 1), row_split=c.get("row_split", 1))
     vol = make_volume(c, rng)
     V, S, U, C = vol.shape
     po = oracle.default_params()

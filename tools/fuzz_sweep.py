@@ -148,7 +148,10 @@ def main():
         which = "f2c" if i % 3 == 2 else "sweep"
         # the sparse visits' kernel: lanes own hypotheses where the plan says so / never / whenever it can run (a generator of
         # its own, so the cases themselves are the ones earlier campaigns drew)
-        rs.default_context(0).set_debug(px=int(np.random.default_rng([seed, i, 77]).choice([-1, 0, 1])))
+        r77 = np.random.default_rng([seed, i, 77])
+        # ... and now and then the streaming kernels on these small shapes (prefix 0), whose sparse visits split their lists by row
+        rs.default_context(0).set_debug(px=int(r77.choice([-1, 0, 1])), row_split=int(r77.choice([1, 1, 0, 4, 20])),
+                                        force_scan=str(r77.choice(["auto", "auto", "stream"])))
         try:
             pixels += (f2c_case if which == "f2c" else sweep_case)(i, rng)
             n[which] += 1

@@ -10,6 +10,9 @@ from remotesensingproject_amd import depth as rs
 from remotesensingproject_amd.synth import CONFIGS, make_lightfield
 
 cfg = CONFIGS[sys.argv[1] if len(sys.argv) > 1 else "mansion_lr"]
+if os.environ.get("SHAPE"):   # U,V,S,C,D,dmin,dmax instead of a named config
+    f = os.environ["SHAPE"].split(",")
+    cfg = dict(U=int(f[0]), V=int(f[1]), S=int(f[2]), C=int(f[3]), D=int(f[4]), dmin=float(f[5]), dmax=float(f[6]), seed=20260099)
 dens = [float(x) for x in sys.argv[2:]] or [1.0, 0.5, 0.2, 0.05, 0.01]
 U, V, S, C, D = cfg["U"], cfg["V"], cfg["S"], cfg["C"], cfg["D"]
 V = int(os.environ.get("ROWS", V))
@@ -21,7 +24,16 @@ rng = np.random.default_rng(5)
 forms = [("rows", dict(force_packed=0)), ("rows noshare", dict(force_packed=0, stream_share=0)), ("packed", dict(force_packed=1, px=0)),
          ("px", dict(force_packed=1, px=1))]
 for dn in dens:
-    mask = torch.from_numpy(((rng.uniform(size=(V, U)) < dn) * 255).astype(np.uint8)).cuda()
+    m_np = rng.uniform(size=(V, U)) < dn
+    zone = os.environ.get("ZONE", "")          # "border": only the columns a sample line can leave the row from; "interior": the rest
+    if zone:
+        reach = int(max(S // 2, S - 1 - S // 2) * max(abs(cfg["dmin"]), abs(cfg["dmax"]))) + 2
+        cols = np.arange(U)
+        edge = (cols < reach) | (cols > U - 1 - reach)
+        m_np &= (edge if zone == "border" else ~edge)[None, :]
+    if os.environ.get("BANDS"):                # as the synthetic sweeps' lists: bands of 32 scanlines, every fifth band empty, the others denser
+        m_np &= (((np.arange(V) // 32) % 5) != 0)[:, None]
+    mask = torch.from_numpy((m_np * 255).astype(np.uint8)).cuda()
     out = []
     for name, hooks in forms:
         ctx.reset_debug()
