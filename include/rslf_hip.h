@@ -113,8 +113,9 @@ typedef struct rslf_stats {
 #define RSLF_SCAN_GENERIC   0  /* any S, C in {1,3}, any sign: re-gathers every mean-shift pass */
 #define RSLF_SCAN_STREAM    2  /* volume >= 0, any S: a resident prefix of the samples (registers + LDS), the rest re-gathered every pass */
 #define RSLF_SCAN_REG       1  /* volume >= 0 and C=1, S<=192 or C=3, S<=48: every sample held in registers */
-#define RSLF_SCAN_CHIP      3  /* volume >= 0, C=3, S in [201, 220], dense launch with one hypothesis grid: one wave per SIMD, 198 samples
-                                  of a unit on chip (VGPRs + AGPRs + LDS), packed-fp32 passes */
+#define RSLF_SCAN_CHIP      3  /* volume >= 0, C=3, S in [123, 220], dense launch with one hypothesis grid: one wave per SIMD, all but
+                                  three samples of a unit on chip (VGPRs + AGPRs + LDS, a ladder of instantiations 8 views apart;
+                                  201 views = BASELINE.json's c5 is the top rung), packed-fp32 passes */
 #define RSLF_SCAN_REG_PX    4  /* RSLF_SCAN_REG's shapes on a packed (sparse) launch: a wave owns one pixel, its lanes the hypotheses */
 #define RSLF_SCAN_STREAM_PX 5  /* RSLF_SCAN_STREAM's shapes on a packed (sparse) launch, the same way */
 

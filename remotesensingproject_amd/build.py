@@ -22,7 +22,10 @@ COMMON = ["rslf_internal.hpp", "rslf_plan.hpp", "rslf_device.hpp", os.path.join(
 # translation unit -> the kernel headers it alone includes (device code is per unit; rslf_internal.hpp lists the units)
 UNITS = {
     "rslf_core.hip": ["k0_pack.hpp"],
-    "rslf_pile.hip": ["k1_edge.hpp", "k_compact.hpp", "k2_scan.hpp", "k2_reg.hpp", "k2_stream.hpp", "k2_chip.hpp", "k3_median.hpp"],
+    "rslf_pile.hip": ["k1_edge.hpp", "k_compact.hpp", "k2_scan.hpp", "k2_reg.hpp", "k2_stream.hpp", "k3_median.hpp"],
+    "rslf_chip_a.hip": ["k2_scan.hpp", "k2_chip.hpp"],
+    "rslf_chip_b.hip": ["k2_scan.hpp", "k2_chip.hpp"],
+    "rslf_chip_c.hip": ["k2_scan.hpp", "k2_chip.hpp"],
     "rslf_sweep.hip": ["k3_median.hpp", "k4_propagate.hpp", "k_compact.hpp"],
     "rslf_f2c.hip": ["k5_f2c.hpp"],
     "rslf_multi.hip": [],
@@ -128,7 +131,7 @@ def build(force: bool = False, report: bool = False) -> str:
         logs[u] = r.stderr
 
     from concurrent.futures import ThreadPoolExecutor
-    with ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 1)) as ex:
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
         list(ex.map(compile_unit, todo))
     r = subprocess.run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO] + [_obj(u) for u in SOURCES],
                        cwd=CSRC, capture_output=True, text=True)

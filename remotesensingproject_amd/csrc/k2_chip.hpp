@@ -1,23 +1,28 @@
-// K2, on-chip variant (k2_scan_chip): RGB light fields with more views than two waves per SIMD can hold on chip --
-// BASELINE.json's 201-view RGB config (c5).
+// K2, on-chip variant (k2_scan_chip): RGB light fields with more views than two waves per SIMD can hold on chip -- 123 to
+// 220 views; BASELINE.json's 201-view RGB config (c5) is the top rung of its ladder.
 //
 // The streaming variant (k2_stream.hpp) runs two waves per SIMD: 256 registers and 20 KiB of LDS per wave hold 92 of a
-// unit's 201 RGB samples, and the other 109 are re-gathered on each of the ten mean-shift passes -- 34 vector
-// instructions and a 12-byte L1 read per sample and pass against 19 for a sample that is at hand; three quarters of
-// its time.  Here a wave has its SIMD to itself: 512 registers (the unified file: 256 VGPRs + 256 AGPRs) and a quarter
-// of the CU's 160 KiB of LDS hold all but three samples of a unit -- in the order a pass walks them,
+// unit's RGB samples, and the others are re-gathered on each of the ten mean-shift passes -- 34 vector instructions and
+// a 12-byte L1 read per sample and pass against 19 for a sample that is at hand; three quarters of its time at 201 views.
+// Here a wave has its SIMD to itself: 512 registers (the unified file: 256 VGPRs + 256 AGPRs) and a quarter of the CU's
+// 160 KiB of LDS hold all but three samples of a unit -- in the order a pass walks them,
 //     views [0, NV)               in VGPRs, as register pairs (s, s+1) per channel
 //     [NV, NV + NA)               in AGPRs, laid out by hand: one v_accvgpr_read_b32 per value and pass (VALU operands cannot name an AGPR)
 //     the next three              fetched AGAIN on every pass (L1 / L2 hits), their loads issued a tier ahead of their use
 //     [NV + NA + 3, .. + NL)      in LDS, [pair][channel][lane] as 8-byte pairs: one conflict-free ds_read_b64 per pair and channel
-//     the rest (none at c5: 64 + 84 + 3 + 50 = 201) fetched again per pass too, in pairs, one pair ahead (up to 220 views)
-// -- the 198 gathered ONCE per hypothesis.  (The chip is full to the word: 201 x 3 samples + the wave's running result
+//     the rest (beyond the top rung only: 202 .. 220 views) fetched again per pass too, in pairs, one pair ahead
+// -- NV = 64; NA and NL are template parameters, one instantiation per RUNG of plan::kChipLadder (rslf_plan.hpp): the tiers
+// fill in the order VGPRs, AGPRs, LDS as the view count grows (127 views = <60, 0> ... 151 = <84, 0> ... 201 = <84, 50>,
+// 8 views apart), and a volume runs on the smallest rung that holds all its views, the missing ones PADDED with samples
+// that contribute nothing (PAD, below).  At c5 the chip is full to the word: 201 x 3 samples + the wave's running result
 // -- a double sum and the best score in three AGPRs, the best index and rbar in LDS -- is what 192 + 256 registers and
-// 157 words of LDS per lane hold, less two samples.)  A wave alone on its SIMD issues one instruction every ~5 clocks
+// 157 words of LDS per lane hold, less two samples.  A wave alone on its SIMD issues one instruction every ~5 clocks
 // whatever it is (tools/ubench_valu.hip), so the pass runs in packed fp32 on sample pairs: v_pk_add / v_pk_mul do two
 // samples' work per issue slot, each half the scalar instruction's IEEE operation (tools/ubench_pk.hip).  The two running
-// sums still take one sample at a time in ascending s (core.hpp:602-603).  No scratch, and nothing written but the
-// workgroup's record: the kernel's HBM traffic is the slab read once plus 2 KB per (tile, group).
+// sums still take one sample at a time in ascending s (core.hpp:602-603).  No scratch in the kernels of record, and nothing
+// written but the workgroup's record: the kernel's HBM traffic is the slab read once plus 2 KB per (tile, group).
+// Against the streaming kernel on a 1146 x 720 x 120-hypothesis dense step: 127 views 69.6 vs 71.9 ms, 151 82.9 vs 93.5,
+// 201 109.6 vs 143.1; below 123 views two waves per SIMD win (100 views: 54.2 vs 45.5) -- profiles/r04_k2_variants.md section 9.
 //
 // Dense row-tile launches with one hypothesis grid for all pixels only (no per-pixel [dmin, dmax] planes, no packed
 // lists): everything else stays with the streaming kernel.
@@ -30,35 +35,23 @@ namespace rslf {
 // samples per tier (all even: the pass works on pairs).  NV: 3 * NV VGPRs beside ~60 of working state (60 left four more
 // samples of c5 to per-pass fetches and ran 7.6 % slower, profiles/r03_k2_variants.md); NA: 3 * NA + 3 <= 256 AGPRs;
 // NL: what a quarter of the CU's LDS holds behind the wave's offset table and before its running best.
+// NV is fixed; NA and NL are TEMPLATE PARAMETERS of the kernel (round 4): the tiers fill in the order VGPRs, AGPRs, LDS as
+// the view count grows, one instantiation per rung of plan::kChipLadder (rslf_plan.hpp), and a volume runs on the largest
+// rung it fills -- what it has beyond the rung's views is fetched again per pass (TAIL).  c5's 201 views are the top rung
+// exactly: <84, 50>.
 #ifndef RSLF_CHIP_NV
 #define RSLF_CHIP_NV 64
-#endif
-#ifndef RSLF_CHIP_NA
-#define RSLF_CHIP_NA 84
-#endif
-#ifndef RSLF_CHIP_NL
-#define RSLF_CHIP_NL 50
 #endif
 #ifndef RSLF_CHIP_PD
 #define RSLF_CHIP_PD 3
 #endif
-constexpr int kChipNV = RSLF_CHIP_NV, kChipNA = RSLF_CHIP_NA, kChipNL = RSLF_CHIP_NL;
-constexpr int kChipOnChip = kChipNV + kChipNA + kChipNL;   // samples that stay on the chip for a hypothesis
-constexpr int kChipAhead = 3;                              // samples fetched again on every pass, ahead of their use
-constexpr int kChipMinS = kChipOnChip + kChipAhead;
-constexpr int kChipMaxS = 220;                             // beyond, the per-pass fetches cost more than the streaming kernel's tail
-constexpr int kChipBestFloats = 4 * 64;                    // a wave's running index and rbar (ChipBest)
-constexpr size_t kChipLdsBytes = (size_t)160 << 10;        // one workgroup per CU takes all of it
-static_assert(kChipNV % 4 == 0 && kChipNA % 4 == 0 && kChipNL % 2 == 0, "gather batches of four samples, pairs in the pass");
-static_assert(3 * kChipNA + 3 <= 256, "AGPR tier and the three named registers");
-
-// floats of dynamic LDS per wave: [view offsets, S rounded up to 4][NL samples x 3 channels x 64 lanes][running best, 4 x 64]
-__host__ __device__ constexpr int chip_wave_floats(int S) { return ((S + 3) & ~3) + kChipNL * 3 * 64 + kChipBestFloats; }
-// the kernel takes volumes whose on-chip tiers and fetched-ahead slots are all in use and whose per-wave LDS share fits
-__host__ __device__ constexpr bool chip_takes(int S, int C)
-{
-    return C == 3 && S >= kChipMinS && S <= kChipMaxS && (size_t)chip_wave_floats(S) * 4 * kScanWaves <= kChipLdsBytes;
-}
+constexpr int kChipNV = RSLF_CHIP_NV;
+constexpr int kChipNAMax = plan::kChipNAMax, kChipNLMax = plan::kChipNLMax;
+constexpr int kChipAhead = plan::kChipAhead;               // samples fetched again on every pass, ahead of their use
+constexpr int kChipBestFloats = plan::kChipBestFloats;     // a wave's running index and rbar (ChipBest)
+constexpr size_t kChipLdsBytes = plan::kChipLdsBytes;      // one workgroup per CU may take all of it
+static_assert(kChipNV == plan::kChipNV && kChipNV % 4 == 0, "gather batches of four samples, pairs in the pass");
+static_assert(3 * kChipNAMax + 3 <= 256, "AGPR tier and the three named registers");
 
 // f(integral_constant<int, G>) for G = 0 .. N-1, in order: a loop unrolled by the type system -- `#pragma unroll` leaves the
 // 49-batch gather rolled, and a rolled loop cannot index registers
@@ -106,7 +99,7 @@ struct ChipUnroll<N, N> {
 template <int R>
 __device__ __forceinline__ void agpr_put(float v)
 {
-    static_assert(R >= 0 && R < 3 * kChipNA, "an AGPR-tier register");
+    static_assert(R >= 0 && R < 3 * kChipNAMax, "an AGPR-tier register");
     asm volatile("v_accvgpr_write_b32 a%c1, %0" : : "v"(v), "n"(R) : RSLF_CHIP_AGPRS);
 }
 
@@ -171,7 +164,7 @@ __device__ __forceinline__ ChipPK chip_pair(f2 r0, f2 r1, f2 r2, f2 m01, f2 m2x,
 template <int P>
 __device__ __forceinline__ ChipPK chip_pair_agpr(f2 m01, f2 m2x, unsigned long long kq, const ChipPK& prev, float (&A)[3], float& B)
 {
-    static_assert(P >= 0 && 2 * P + 1 < kChipNA, "a pair of the AGPR tier");
+    static_assert(P >= 0 && 2 * P + 1 < kChipNAMax, "a pair of the AGPR tier");
     ChipPK n;
     f2 d0, d1, d2;
     asm volatile("v_accvgpr_read_b32 v250, a%c[a0x]\n\t"
@@ -297,19 +290,50 @@ struct ChipBest {
     }
 };
 
+// r = (view W of S is missing) ? sentinel : r, for the padded rungs.  By hand: left to hipcc, the thirteen wave-uniform
+// answers were hoisted out of the hypothesis loop as lane masks (26 scalar registers: the scalar file overflowed into vector
+// registers and those into scratch) and the sentinel sat in a vector register of its own; here the answer is made where it
+// is used and the constant lives for four instructions (v_cndmask_b32_e32: D = VCC ? src1 : src0).
+template <int W>
+__device__ __forceinline__ void chip_pad_select(float (&r)[3], int S)
+{
+    static_assert(kSentinel == 1e30f, "the literal below");
+    float sent;
+    asm volatile("s_cmp_gt_i32 %4, %5\n\t"            // SCC = S > W: the view exists
+                 "s_cselect_b64 vcc, -1, 0\n\t"
+                 "v_mov_b32_e32 %3, 0x7149f2ca\n\t"   // (VCC and a literal in one instruction are two reads of the constant bus)
+                 "v_cndmask_b32_e32 %0, %3, %0, vcc\n\t"
+                 "v_cndmask_b32_e32 %1, %3, %1, vcc\n\t"
+                 "v_cndmask_b32_e32 %2, %3, %2, vcc"
+                 : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "=&v"(sent)
+                 : "s"(S), "n"(W)
+                 : "vcc", "scc");
+}
+
 // SHARED = false: the general form -- every lane loads both taps of a sample (16 + 8 bytes) and tests the sample's validity
 // (interp.hpp:182).  SHARED = true: lanes 0..62 hold 63 consecutive pixels, lane 63 stands on the pixel after them, every
 // sample line of every lane stays inside the row and all lanes floor alike (scan_chip_rows): a lane's right tap is its
 // neighbour's left tap, so a sample costs ONE 12-byte load, the right tap comes from lane + 1 (v_mul_f32_dpp wave_shl:1),
 // and with 4 registers per sample in flight instead of 7 the gather runs TWO batches ahead of its blends -- a wave alone on
 // its SIMD has nobody to hide an L2 round trip behind (the general form, one batch ahead, waits a third of its gather).
-// TAIL = false: exactly kChipMinS views (c5's 201): the per-pass fetches of further views are not compiled in (their
+// TAIL = false: exactly the rung's views (c5's 201 on the top rung): the per-pass fetches of further views are not compiled in (their
 // registers cost the 201-view kernel 0.5 %).
-template <bool SHARED, bool TAIL>
+// PAD = true: the volume has FEWER views than the rung holds (at most kChipPadMax fewer: plan::chip_rung_for): the missing
+// ones are samples that contribute nothing -- the sentinel, K = 0 and R K = 0 exactly, added to the sums as +0 -- read from
+// the last view's row at offset 0 (in bounds), not counted in the cardinal.  A view of padding costs a quarter of what a
+// view fetched again per pass does, which is why a volume runs on the rung ABOVE its view count, not the one below.
+template <bool SHARED, bool TAIL, int NA, int NL, bool PAD>
 __device__ __forceinline__ void scan_chip_body(const ScanArgs& a, int v, const ChipTile& t, int d0, int d1, ChipBest& best, float* __restrict__ otab)
 {
-    constexpr int C = 3, NV = kChipNV, NA = kChipNA, NL = kChipNL, GB = 4;
+    constexpr int C = 3, NV = kChipNV, GB = 4;
+    static_assert(NA % 4 == 0 && NA <= kChipNAMax && NL % 2 == 0 && NL <= kChipNLMax, "a rung of the ladder");
     constexpr int NO = NV + NA + NL, NB = (NO + GB - 1) / GB;   // on-chip samples; gather batches (the last may be half full)
+    constexpr int T = NO + kChipAhead;                          // the rung's views
+    static_assert(!(PAD && TAIL), "a volume is padded up to a rung or has views beyond the top one");
+    // gather index -> view (the gather walks the LDS tier, then the AGPR tier, then the VGPR tier)
+    auto view_of = [](int i) constexpr { return i < NL ? NV + NA + kChipAhead + i : i < NL + NA ? NV + (i - NL) : i - NL - NA; };
+    // can view w be padding?  (compile-time: only the rung's last kChipPadMax views)
+    auto may_pad = [](int w) constexpr { return PAD && w >= T - plan::kChipPadMax; };
     constexpr bool BORDER = !SHARED;
     constexpr int PD = SHARED ? RSLF_CHIP_PD : 2;   // batches of loads in flight + 1
     const VolView& vol = a.vol;
@@ -330,7 +354,12 @@ __device__ __forceinline__ void scan_chip_body(const ScanArgs& a, int v, const C
     const float uf = (float)u;
     const unsigned centre_off = ((unsigned)(a.s_hat * (int)vol.stride_s) + (unsigned)(u * C)) << 2;   // 32-bit: one EPI is < 2 GiB
     // LDS tier: [pair][channel][lane] as f2 behind the offset table
-    f2* park = reinterpret_cast<f2*>(otab + ((S + 3) & ~3)) + lane;
+    f2* park = reinterpret_cast<f2*>(otab + plan::chip_table_floats(S, T)) + lane;
+    unsigned row_last = 0;   // PAD: the row every missing view reads
+    if constexpr (PAD) {
+        row_last = (unsigned)(S - 1) * stride_b;
+        asm volatile("" : "+s"(row_last));
+    }
 
     // one sample's two taps and its blend (interp.hpp:179-190); `rowb` = byte offset of view s's row in the EPI
     // `xoff` = fl(fl(float(s_hat - s) * D[d]) * slope), from the wave's offset table (one broadcast read serves four samples)
@@ -376,9 +405,11 @@ __device__ __forceinline__ void scan_chip_body(const ScanArgs& a, int v, const C
         const float range = dmax_s - dmin_s;
         const float denom = (float)(dim_s - 1);
         const float Dd = hypothesis(dmin_s, range, denom, d);
-        for (int s = lane; s < S; s += 64) {
+        for (int s = lane; s < (PAD ? T : S); s += 64) {
             float off = (float)(a.s_hat - s) * Dd;   // core.hpp:542,550
             off = off * slope;                       // core.hpp:551
+            if (PAD && s >= S)
+                off = 0.0f;                          // a missing view: any in-bounds address will do
             // the table is in the order of USE: the on-chip samples as the gather walks them (LDS tier, AGPR tier, VGPR
             // tier), then the three fetched ahead, then the ragged tail
             const int pos = s < NV                        ? NL + NA + s
@@ -400,13 +431,16 @@ __device__ __forceinline__ void scan_chip_body(const ScanArgs& a, int v, const C
         // full for two thirds of the gather and hipcc spilled four of its registers once per hypothesis.
         // (The AGPR tier stays in the middle: gathered first, hipcc spills five of ITS values.)
         // gather index i: [0, NL) LDS tier (views NV + NA + 3 ..), [NL, NL + NA) AGPR tier (views NV ..), then the VGPR tier
-        unsigned rowb = (unsigned)(NV + NA + kChipAhead) * stride_b;
+        // (a rung without an LDS tier starts in the AGPR tier)
+        unsigned rowb = (unsigned)(NL > 0 ? NV + NA + kChipAhead : NV) * stride_b;
+        if (may_pad(NL > 0 ? NV + NA + kChipAhead : NV))
+            rowb = min(rowb, row_last);
         asm volatile("" : "+s"(rowb));
         typedef float f4v __attribute__((ext_vector_type(4)));
         float e0[PD][GB][C], e1[PD][GB][C], tt[PD][GB];
         bool ok[PD][GB];
         f4v xo[PD];   // the offsets of a batch, read a batch before its loads are issued (the table is padded to a multiple of 4)
-        static_assert((RSLF_CHIP_PD - 1) * GB <= NL && NL % 2 == 0 && (NA + NL) % 2 == 0, "prologue inside the LDS tier; pairs do not straddle tiers");
+        static_assert((RSLF_CHIP_PD - 1) * GB <= (NL > 0 ? NL : NA) && (NA + NL) % 2 == 0, "prologue inside the first tier gathered; pairs do not straddle tiers");
 #pragma unroll
         for (int b = 0; b < PD; b++)
             xo[b] = *(const f4v*)(otab + b * GB);
@@ -416,6 +450,8 @@ __device__ __forceinline__ void scan_chip_body(const ScanArgs& a, int v, const C
             for (int j = 0; j < GB; j++) {
                 taps(xo[b][j], rowb, e0[b][j], e1[b][j], tt[b][j], ok[b][j]);
                 rowb += stride_b;
+                if (may_pad(view_of(b * GB + j) + 1))
+                    rowb = min(rowb, row_last);
             }
         auto batch = [&](auto gc) {
             constexpr int g = decltype(gc)::value;
@@ -431,6 +467,8 @@ __device__ __forceinline__ void scan_chip_body(const ScanArgs& a, int v, const C
                             rowb = 0;
                         taps(xo[nxt][j], rowb, e0[nxt][j], e1[nxt][j], tt[nxt][j], ok[nxt][j]);
                         rowb += stride_b;
+                        if (may_pad(view_of(i) + 1))
+                            rowb = min(rowb, row_last);
                     }
                 }
             }
@@ -442,9 +480,16 @@ __device__ __forceinline__ void scan_chip_body(const ScanArgs& a, int v, const C
                 if (g * GB + j < NO) {
                     blend(e0[cur][j], e1[cur][j], tt[cur][j], ok[cur][j], r[j]);
                     if (BORDER)
-                        card += ok[cur][j] ? 1 : 0;
+                        card += ok[cur][j] ? 1 : 0;   // (a missing view reads an in-bounds address: counted here, taken off below)
                 }
             }
+            auto pad = [&](auto jc) {
+                constexpr int j = decltype(jc)::value, i = g * GB + j;
+                if constexpr (i < NO && may_pad(view_of(i)))
+                    chip_pad_select<view_of(i)>(r[j], S);
+            };
+            if constexpr (PAD)
+                ChipUnroll<0, GB>::run(pad);
 #pragma unroll
             for (int j = 0; j < GB; j++) {
                 const int i = g * GB + j;
@@ -508,8 +553,12 @@ __device__ __forceinline__ void scan_chip_body(const ScanArgs& a, int v, const C
             bool xok[kChipAhead];
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int k = 0; k < kChipAhead; k++)
-                taps(otab[NO + k], (unsigned)(NV + NA + k) * stride_b, xe0[k], xe1[k], xtt[k], xok[k]);
+            for (int k = 0; k < kChipAhead; k++) {
+                unsigned rb = (unsigned)(NV + NA + k) * stride_b;
+                if (may_pad(NV + NA + k))
+                    rb = min(rb, row_last);
+                taps(otab[NO + k], rb, xe0[k], xe1[k], xtt[k], xok[k]);
+            }
             __builtin_amdgcn_sched_barrier(0);
             // AGPR tier
             auto agpr_pair = [&](auto pc) { pk = chip_pair_agpr<decltype(pc)::value>(m01, m2x, kq2, pk, A, B); };
@@ -518,17 +567,27 @@ __device__ __forceinline__ void scan_chip_body(const ScanArgs& a, int v, const C
             {
                 float rx[kChipAhead][C];
 #pragma unroll
-                for (int k = 0; k < kChipAhead; k++)
+                for (int k = 0; k < kChipAhead; k++) {
                     blend(xe0[k], xe1[k], xtt[k], xok[k], rx[k]);
+                }
+                auto pad_ahead = [&](auto kc) {
+                    constexpr int k = decltype(kc)::value;
+                    if constexpr (may_pad(NV + NA + k))
+                        chip_pad_select<NV + NA + k>(rx[k], S);
+                };
+                if constexpr (PAD)
+                    ChipUnroll<0, kChipAhead>::run(pad_ahead);
                 pk = chip_pair(f2{rx[0][0], rx[1][0]}, f2{rx[0][1], rx[1][1]}, f2{rx[0][2], rx[1][2]}, m01, m2x, kq2, pk, A, B);
                 pk = chip_pair(f2{rx[2][0], kSentinel}, f2{rx[2][1], kSentinel}, f2{rx[2][2], kSentinel}, m01, m2x, kq2, pk, A, B);
             }
             // LDS tier, fully unrolled (immediate offsets): the three ds_read_b64 of pair p + 1 are issued before pair p's
             // block, which then covers their latency
             f2 q[2][C];
+            if constexpr (NL > 0) {
 #pragma unroll
-            for (int c = 0; c < C; c++)
-                q[0][c] = park[c * 64];
+                for (int c = 0; c < C; c++)
+                    q[0][c] = park[c * 64];
+            }
 #pragma unroll
             for (int p = 0; p < NL / 2; p++) {
                 const int cur = p & 1, nxt = cur ^ 1;
@@ -547,13 +606,15 @@ __device__ __forceinline__ void scan_chip_body(const ScanArgs& a, int v, const C
 #pragma unroll
                 for (int k = 0; k < kChipAhead; k++)
                     ncard += xok[k] ? 1 : 0;
+                if (PAD)
+                    ncard -= T - S;   // the missing views' in-bounds stand-ins
             }
             // What is left (none at c5) is fetched again on every pass, two views at a time and one pair AHEAD: the loads of
             // views s + 2, s + 3 go out before the pair (s, s + 1) is blended and run through the same packed block as the
             // tiers.  One view at a time with each load waited for cost 2.6 % of a hypothesis per view and the streaming
             // kernel overtook this one at 215 views; a pipelined pair costs 2.0 % per view, the crossover is at 220, and
             // chip_takes leaves more views than that to the streaming kernel (profiles/r03_k2_variants.md section 7).
-            constexpr int T0 = NO + kChipAhead;
+            constexpr int T0 = T;
             if (TAIL && S > T0) {   // wave-uniform
                 float ae0[2][C], ae1[2][C], att[2], be0[2][C], be1[2][C], btt[2];
                 bool aok[2], bok[2];
@@ -621,11 +682,11 @@ __device__ __forceinline__ void scan_chip_body(const ScanArgs& a, int v, const C
 // inside the row for every lane (two pixels of margin, which covers lane 63's extra pixel), and view offsets none of whose
 // fractions is within an ulp of 1 (positions are offset + integer u: the lanes then all floor alike).  Runs of
 // hypotheses of one kind go to one body call, in ascending order: first maximum wins (core.hpp:636-645).
-template <bool TAIL>
+template <bool TAIL, int NA, int NL, bool PAD>
 __device__ __forceinline__ void scan_chip_rows(const ScanArgs& a, int v, int e0, int width, int n, int d0, int d1, Best<3>& result, float* otab)
 {
     ChipBest best;
-    best.init(otab + ((a.vol.S + 3) & ~3) + kChipNL * 3 * 64);
+    best.init(otab + plan::chip_table_floats(a.vol.S, kChipNV + NA + NL + kChipAhead) + NL * 3 * 64);
     const int S = a.vol.S;
     ChipTile t;
     t.row = a.list + (long long)v * a.vol.U;
@@ -644,10 +705,14 @@ __device__ __forceinline__ void scan_chip_rows(const ScanArgs& a, int v, int e0,
         const bool lane63_free = !__any(ln == 63 && active);
         dense = a.tile_w == 63 && consecutive && lane63_free;
     }
+    // (a scalar: as a bool hipcc carried it through the hypotheses as a 0 / 1 per lane, and with every vector register
+    // spoken for that was a dword of scratch on some rungs)
+    int gappy_s = __builtin_amdgcn_readfirstlane(dense ? 0 : 1);
+    asm volatile("" : "+s"(gappy_s));   // (opaque from here on: seen through, it is the per-lane bool again)
     // (uniform FLOATS are made in the vector ALU and would be carried in vector registers: they are made per call, from
     // scalars the optimiser cannot see through)
     auto shared_form = [&](int d) -> bool {
-        if (!dense)
+        if (gappy_s)
             return false;
         float dmin_s = a.dmin, dmax_s = a.dmax, slope_s = a.k.slope;
         int dim_s = a.dim_d, reach_s = max(a.s_hat, S - 1 - a.s_hat), last_s = a.vol.U - 1;
@@ -674,24 +739,28 @@ __device__ __forceinline__ void scan_chip_rows(const ScanArgs& a, int v, int e0,
         while (e < d1 && shared_form(e) == sh)
             e++;
         if (sh)
-            scan_chip_body<true, TAIL>(a, v, t, d, e, best, otab);
+            scan_chip_body<true, TAIL, NA, NL, PAD>(a, v, t, d, e, best, otab);
         else
-            scan_chip_body<false, TAIL>(a, v, t, d, e, best, otab);
+            scan_chip_body<false, TAIL, NA, NL, PAD>(a, v, t, d, e, best, otab);
         d = e;
     }
     best.finish(a, result);
 }
 
-// scan_chunk with the wave's number handed in
+// This wave's hypotheses: scan_chunk's contiguous slices in wave order, but differing by at most one hypothesis (the first
+// dim_d % slices take the extra one).  scan_chunk's ceil-sized chunks leave the last waves of a tile idle when the count
+// does not divide -- 120 hypotheses over 8 groups: 30 slices of 4 and two idle waves -- which costs the other kernels
+// nothing (the SIMD's other waves take up the slots, profiles/r04_k2_variants.md section 8) and this one, a wave per SIMD, the
+// idle SIMDs.
 __device__ __forceinline__ void chip_chunk(const ScanArgs& a, int group, int wave, int& d0, int& d1)
 {
-    const int slices = kScanWaves * a.groups;
-    const int chunk = (a.dim_d + slices - 1) / slices;
-    d0 = min((group * kScanWaves + wave) * chunk, a.dim_d);
-    d1 = min(d0 + chunk, a.dim_d);
+    const int slices = kScanWaves * a.groups, slice = group * kScanWaves + wave;
+    const int q = a.dim_d / slices, r = a.dim_d - q * slices;
+    d0 = slice * q + min(slice, r);
+    d1 = d0 + q + (slice < r ? 1 : 0);
 }
 
-template <bool TAIL>
+template <bool TAIL, int NA, int NL, bool PAD>
 __global__ __launch_bounds__(64 * kScanWaves) __attribute__((amdgpu_waves_per_eu(1, 1))) void k2_scan_chip(ScanArgs a)
 {
     constexpr int C = 3;
@@ -709,7 +778,7 @@ __global__ __launch_bounds__(64 * kScanWaves) __attribute__((amdgpu_waves_per_eu
     if (!scan_tile_span(a, lb, v, e0, width, n))
         return;
     chip_chunk(a, lb % a.groups, wave, d0, d1);
-    scan_chip_rows<TAIL>(a, v, e0, width, n, d0, d1, best, otab);
+    scan_chip_rows<TAIL, NA, NL, PAD>(a, v, e0, width, n, d0, d1, best, otab);
     asm volatile("" : "+s"(lb));
     int u;
     bool active;
@@ -717,5 +786,29 @@ __global__ __launch_bounds__(64 * kScanWaves) __attribute__((amdgpu_waves_per_eu
     scan_tile(a, lb, v, u, active, lane);
     scan_epilogue<C, kEpiDyn>(a, lb, v, u, active, best, epi_lds, epi_stride, lane, wave);
 }
+
+// ---- host side: one launcher per translation unit of instantiations (rslf_chip_a/b/c.hip) -------------------------------
+template <bool TAIL, int NA, int NL, bool PAD>
+int launch_chip_rung(const ScanArgs& a, dim3 grid, size_t lds_bytes, hipStream_t stream)
+{
+    // (more than the 64 KiB a kernel gets without asking)
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k2_scan_chip<TAIL, NA, NL, PAD>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)kChipLdsBytes));
+    hipLaunchKernelGGL((k2_scan_chip<TAIL, NA, NL, PAD>), grid, dim3(64 * kScanWaves), lds_bytes, stream, a);
+    return RSLF_OK;
+}
+// the padded form of one of this unit's rungs; RSLF_ERR_UNSUPPORTED = not one of this unit's
+#define RSLF_CHIP_PART_CASE_(NA, NL) \
+    if (na == NA && nl == NL)        \
+        return launch_chip_rung<false, NA, NL, true>(a, grid, lds_bytes, stream);
+#define RSLF_CHIP_PART_LAUNCHER(NAME, LIST)                                                                  \
+    int NAME(int na, int nl, const ScanArgs& a, dim3 grid, size_t lds_bytes, hipStream_t stream)             \
+    {                                                                                                        \
+        LIST(RSLF_CHIP_PART_CASE_)                                                                           \
+        return RSLF_ERR_UNSUPPORTED;                                                                         \
+    }
+int launch_chip_part_a(int na, int nl, const ScanArgs& a, dim3 grid, size_t lds_bytes, hipStream_t stream);
+int launch_chip_part_b(int na, int nl, const ScanArgs& a, dim3 grid, size_t lds_bytes, hipStream_t stream);
+int launch_chip_part_c(int na, int nl, const ScanArgs& a, dim3 grid, size_t lds_bytes, hipStream_t stream);
 
 }  // namespace rslf

@@ -727,4 +727,8 @@ __global__ __launch_bounds__(256) void k2_kernel_column(ScanArgs a, const int32_
     scan_generic_body<C>(a, v, u, d, d + 1, best, K_vsu + (long long)v * a.vol.S * a.vol.U + u, (long long)a.vol.U);
 }
 
+// The on-chip kernel's instantiations (k2_chip.hpp, one per rung of plan::kChipLadder) are translation units of their own
+// (rslf_chip_a/b/c.hip): the hot path's unit launches them through this.  Returns an rslf error code.
+int launch_scan_chip(const ScanArgs& a, dim3 grid, size_t lds_bytes, hipStream_t stream);
+
 }  // namespace rslf

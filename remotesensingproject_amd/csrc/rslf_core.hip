@@ -1,4 +1,4 @@
-// librslf_hip.so, unit 1 of 6: errors, contexts, volumes, host upload / device pack (K0).
+// librslf_hip.so, unit 1 of 9: errors, contexts, volumes, host upload / device pack (K0).
 // C-ABI: include/rslf_hip.h.  No OpenCV, no torch, no CPU compute path.
 #include "rslf_internal.hpp"
 

@@ -1,4 +1,4 @@
-// librslf_hip.so, unit 4 of 6: fine-to-coarse (rslf_fine_to_coarse.hpp:103-324, rslf_fine_to_coarse_core.cpp:14-135) --
+// librslf_hip.so, unit 7 of 9: fine-to-coarse (rslf_fine_to_coarse.hpp:103-324, rslf_fine_to_coarse_core.cpp:14-135) --
 // the pyramid (Gaussian blur + halving), the bound tightening, the fusion (K5), the host-pointer form of the 2-D sweep and
 // the native level loop.  C-ABI: include/rslf_hip.h.
 #include "rslf_internal.hpp"

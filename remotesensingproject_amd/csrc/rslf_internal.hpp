@@ -4,6 +4,7 @@
 //
 //   rslf_core.hip         errors, contexts, volumes, host upload / device pack (K0)
 //   rslf_pile.hip         the hot path: edge confidence (K1), scan (K2), selective median (K3), Depth1DComputer(_pile)
+//   rslf_chip_a/b/c.hip   the on-chip scan kernel's instantiations, one per rung of its ladder (launched by rslf_pile.hip)
 //   rslf_sweep.hip        the 2-D sweep and its propagation (K4)
 //   rslf_f2c.hip          fine-to-coarse: pyramid, bound tightening, fusion (K5) and the native level loop
 //   rslf_multi.hip        host pointers in / host planes out, pipelined over one or several devices (pile path)
@@ -191,7 +192,6 @@ struct rslf_ctx {
     int stream_groups = 0;     // streaming kernel, dense launches: hypothesis groups per tile (0 = kStreamGroups)
     int stream_share = 1;      // streaming kernel: 63-pixel row tiles whose tail shares taps between neighbouring lanes: 0 never, 1 where the tail is long (plan::stream_shares_taps), 2 always
     size_t stream_lds_bytes = rslf::plan::kStreamLdsBytes;   // dynamic LDS of one streaming workgroup
-    bool chip_attr_set = false;
     int row_split = 1;         // packed launches of stream-class volumes: rows with many pixels as row tiles of the list (0: off; A/B and tests)
     int claim_skip = 1;        // 2-D sweep: the claims skip views with nothing left to paint within reach (0: off, A/B and tests)
     rslf::Partial* scan_partial = nullptr;   // [tile][group][64] records of grouped scan launches

@@ -1,4 +1,4 @@
-// librslf_hip.so, unit 5 of 6: host pointers in, host planes out -- Depth1DComputer_pile over one or several devices, the
+// librslf_hip.so, unit 8 of 9: host pointers in, host planes out -- Depth1DComputer_pile over one or several devices, the
 // upload, the kernels and the download of successive scanline chunks overlapped.  C-ABI: include/rslf_hip.h.
 #include "rslf_internal.hpp"
 

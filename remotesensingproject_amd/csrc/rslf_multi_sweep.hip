@@ -1,4 +1,4 @@
-// librslf_hip.so, unit 6 of 6: the 2-D sweep and fine-to-coarse sharded by scanline over the devices of one process, behind
+// librslf_hip.so, unit 9 of 9: the 2-D sweep and fine-to-coarse sharded by scanline over the devices of one process, behind
 // the C-ABI -- one neighbour exchange of boundary rows per visit (the path's one real exchange step).  C-ABI: include/rslf_hip.h.
 #include "rslf_internal.hpp"
 

@@ -1,4 +1,4 @@
-// librslf_hip.so, unit 2 of 6: the hot path -- edge confidence (K1), the scan (K2), the selective median (K3) and the
+// librslf_hip.so, unit 2 of 9: the hot path -- edge confidence (K1), the scan (K2), the selective median (K3) and the
 // Depth1DComputer / Depth1DComputer_pile drivers over them.  C-ABI: include/rslf_hip.h.
 #include "rslf_internal.hpp"
 
@@ -9,7 +9,6 @@
 #include "k2_scan.hpp"
 #include "k2_reg.hpp"
 #include "k2_stream.hpp"
-#include "k2_chip.hpp"
 #include "k3_median.hpp"
 
 using namespace rslf;
@@ -199,8 +198,8 @@ static ScanChoice choose_scan(const rslf_ctx* ctx, int S, int C, bool in_range, 
         c.spad = 0;
     }
     c.use_stream = !c.spad && c.stream_ok;
-    // more views than two waves per SIMD hold on chip (RGB, 200 views and up): one wave per SIMD with every sample at hand
-    c.use_chip = c.use_stream && dense_uniform && chip_takes(S, C) && ctx->force_scan != 2;
+    // more views than two waves per SIMD hold on chip (RGB, 123 to 220 views: plan::chip_takes): one wave per SIMD with every sample at hand
+    c.use_chip = c.use_stream && dense_uniform && plan::chip_takes(S, C) && ctx->force_scan != 2;
     if (c.use_chip)
         c.use_stream = false;
     return c;
@@ -213,7 +212,7 @@ static plan::ScanRequest scan_request(const rslf_ctx* ctx, int V, int U, int S, 
     rq.spad = ch.spad;
     rq.use_stream = ch.use_stream;
     rq.use_chip = ch.use_chip;
-    rq.chip_wave_floats = ch.use_chip ? chip_wave_floats(S) : 0;
+    rq.chip_wave_floats = ch.use_chip ? plan::chip_wave_floats(S, plan::kChipLadder[plan::chip_rung_for(S)]) : 0;
     rq.reg_waves = ch.spad ? scan_reg_waves(ch.spad, C) : 0;
     rq.num_cus = ctx->num_cus;
     rq.ctx_groups = ctx->scan_groups;
@@ -389,13 +388,6 @@ extern "C" int rslf_depth_epi_scan(rslf_ctx* ctx, const rslf_volume* vol, const 
             return rc;
     }
     const size_t lds = sp.lds_bytes;
-    if (use_chip && !ctx->chip_attr_set) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k2_scan_chip<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)kChipLdsBytes));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k2_scan_chip<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)kChipLdsBytes));
-        ctx->chip_attr_set = true;
-    }
     // (more than the 64 KiB a kernel gets without asking: set on the instantiation about to be launched, below)
     HIP_TRY(hipGetLastError());   // anything an earlier enqueue left behind is not this launch's fault
     ctx->last_spad = spad;
@@ -479,10 +471,9 @@ extern "C" int rslf_depth_epi_scan(rslf_ctx* ctx, const rslf_volume* vol, const 
             if (rc)
                 return rc;
         } else if (use_chip) {
-            if (vol->S == kChipMinS)   // c5's view count: every view has a place (or a fetched-ahead slot), no ragged tail compiled in
-                hipLaunchKernelGGL(k2_scan_chip<false>, grid, dim3(64 * kScanWaves), lds, st, a);
-            else
-                hipLaunchKernelGGL(k2_scan_chip<true>, grid, dim3(64 * kScanWaves), lds, st, a);
+            rc = launch_scan_chip(a, grid, lds, st);   // rslf_chip_a.hip: the rung that holds this view count
+            if (rc)
+                return rc;
         } else if (use_stream) {
             // one instantiation per channel count, resident-prefix length and launch form (k2_stream.hpp)
             hipError_t attr = hipSuccess;

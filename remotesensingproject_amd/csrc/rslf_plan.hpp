@@ -43,6 +43,75 @@ constexpr size_t kStreamLdsBytes = (size_t)80 << 10;               // dynamic LD
 constexpr size_t kStagingBudget = (size_t)256 << 20;               // device staging buffer of the chunked host upload
 constexpr int kMinSpatialDim = 10;                                 // _MIN_SPATIAL_DIM, rslf_fine_to_coarse.hpp:8
 
+// ---- the on-chip kernel's ladder (k2_chip.hpp) -----------------------------------------------------------------------
+// A rung = how many views sit in the AGPR tier (NA) and the LDS tier (NL) behind the 64 of the VGPR tier; three more are
+// fetched ahead on every pass.  The tiers fill in that order as the view count grows.  A volume runs on the SMALLEST rung
+// that holds all its views, the missing ones padded with samples that contribute nothing (~1 % of a hypothesis each; a
+// view beyond a rung, fetched again on every pass, costs 3.5 %) -- so the rungs are 8 views apart.  The top rung is
+// BASELINE.json's c5 (201 views), which has its own unpadded instantiation, and one with a ragged tail for 202..220.
+// The lists are per translation unit (rslf_chip_a/b/c.hip: each instantiation is ~20 s of hipcc).
+constexpr int kChipNV = 64, kChipNAMax = 84, kChipNLMax = 50, kChipAhead = 3;
+constexpr int kChipPadMax = 10;                                    // a rung holds at most this many views more than the volume has
+constexpr int kChipBestFloats = 4 * 64;                            // a wave's running index and rbar (ChipBest)
+constexpr size_t kChipLdsBytes = (size_t)160 << 10;                // one workgroup per CU may take all of it
+constexpr int kChipMaxS = 220;                                     // beyond, the per-pass fetches cost more than the streaming kernel's tail
+#ifndef RSLF_CHIP_LADDER_A
+#define RSLF_CHIP_LADDER_A(X) X(84, 32) X(84, 40) X(84, 50)
+#define RSLF_CHIP_LADDER_B(X) X(84, 0) X(84, 8) X(84, 16) X(84, 24)
+#define RSLF_CHIP_LADDER_C(X) X(60, 0) X(68, 0) X(76, 0)
+#endif
+#define RSLF_CHIP_LADDER(X) RSLF_CHIP_LADDER_C(X) RSLF_CHIP_LADDER_B(X) RSLF_CHIP_LADDER_A(X)
+#ifndef RSLF_CHIP_FIRST_S
+#define RSLF_CHIP_FIRST_S 123   // fewer views: the streaming kernel's two waves per SIMD are faster (profiles/r04_k2_variants.md section 9)
+#endif
+struct ChipRung {
+    int na, nl;
+    constexpr int views() const { return kChipNV + na + kChipAhead + nl; }
+};
+#define RSLF_CHIP_RUNG_(NA, NL) ChipRung{NA, NL},
+constexpr ChipRung kChipLadder[] = {RSLF_CHIP_LADDER(RSLF_CHIP_RUNG_)};   // ascending
+#undef RSLF_CHIP_RUNG_
+constexpr int kChipRungs = (int)(sizeof(kChipLadder) / sizeof(kChipLadder[0]));
+constexpr int kChipTopS = kChipLadder[kChipRungs - 1].views();
+constexpr int kChipMinS = RSLF_CHIP_FIRST_S > kChipLadder[0].views() - kChipPadMax ? RSLF_CHIP_FIRST_S : kChipLadder[0].views() - kChipPadMax;
+constexpr bool chip_ladder_ok()
+{
+    for (int i = 1; i < kChipRungs; i++)
+        if (kChipLadder[i].views() <= kChipLadder[i - 1].views() || kChipLadder[i].views() - kChipLadder[i - 1].views() > kChipPadMax)
+            return false;
+    return true;
+}
+static_assert(chip_ladder_ok(), "rungs ascend, and a volume is never padded by more than kChipPadMax views");
+
+// the rung a volume of S views runs on: the smallest that holds them all; beyond the top rung, the top rung (-1: none)
+inline int chip_rung_for(int S)
+{
+    if (S < kChipMinS || S > kChipMaxS)
+        return -1;
+    for (int i = 0; i < kChipRungs; i++)
+        if (kChipLadder[i].views() >= S)
+            return i;
+    return kChipRungs - 1;
+}
+// the wave's table of view offsets: one entry per view of the volume or of the rung, whichever is more
+constexpr int chip_table_floats(int S, int rung_views) { return ((S > rung_views ? S : rung_views) + 3) & ~3; }
+// floats of dynamic LDS per wave: [view offsets][NL samples x 3 channels x 64 lanes][running best, 4 x 64] -- and no less
+// than the epilogue's block, which reuses the region's head
+constexpr int chip_wave_floats(int S, const ChipRung& r)
+{
+    return chip_table_floats(S, r.views()) + r.nl * 3 * 64 + kChipBestFloats < 2 * (64 + 6 * 32)
+               ? 2 * (64 + 6 * 32)
+               : chip_table_floats(S, r.views()) + r.nl * 3 * 64 + kChipBestFloats;
+}
+// the kernel takes RGB volumes that have a rung and whose per-wave LDS share fits
+inline bool chip_takes(int S, int C)
+{
+    if (C != 3)
+        return false;
+    const int r = chip_rung_for(S);
+    return r >= 0 && (size_t)chip_wave_floats(S, kChipLadder[r]) * 4 * kScanWavesPerTile <= kChipLdsBytes;
+}
+
 // Register-variant slot counts compiled into the library (multiples of 8), per channel count: those that run at two or
 // more waves per SIMD.  Beyond them the streaming / on-chip kernels take over (k2_scan.hpp).
 #ifndef RSLF_SPAD_LIST_1CH

@@ -1,4 +1,4 @@
-// librslf_hip.so, unit 3 of 6: the 2-D sweep (Depth2DComputer::run, core.hpp:901-1133) -- one visit per view, scan (unit 2),
+// librslf_hip.so, unit 6 of 9: the 2-D sweep (Depth2DComputer::run, core.hpp:901-1133) -- one visit per view, scan (unit 2),
 // selective median + claims, apply + the next visit's compaction (K4).  C-ABI: include/rslf_hip.h.
 #include "rslf_internal.hpp"
 

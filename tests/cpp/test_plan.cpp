@@ -275,7 +275,8 @@ static void test_scan_plans()
     ScanRequest chip = c5;                                  // the on-chip kernel: the streaming kernel's tiles, half its groups, all of the CU's LDS
     chip.use_stream = false;
     chip.use_chip = true;
-    chip.chip_wave_floats = 204 + 50 * 3 * 64 + 256;
+    chip.chip_wave_floats = chip_wave_floats(201, kChipLadder[chip_rung_for(201)]);
+    CHECK(chip.chip_wave_floats == 204 + 50 * 3 * 64 + 256);
     p = plan_scan(chip, 0);
     CHECK(p.groups == kChipGroups && !p.packed && p.tile_w == 63 && p.tiles_per_row == 65 && p.rows_per_launch == 252 && p.stream_park == 0);
     chip.V = 3;                                             // a few scanlines: 3 x 65 tiles x 8 groups would be three rounds of workgroups on 256 CUs
@@ -385,6 +386,41 @@ static void test_scan_plans()
         const float x = (float)(U + 1) + f;
         CHECK(x < (float)(U + 2) || (float)(U + 1) + 1.0f == (float)(U + 1));
     }
+}
+
+static void test_chip_ladder()
+{
+    // rungs ascend, at most kChipPadMax views apart, each within the tiers' capacity; the top one is c5's 201 views
+    for (int i = 0; i < kChipRungs; i++) {
+        const ChipRung r = kChipLadder[i];
+        CHECK(r.na % 4 == 0 && r.na <= kChipNAMax && r.nl % 2 == 0 && r.nl <= kChipNLMax && (r.nl == 0 || r.nl >= 8));
+        CHECK(r.nl == 0 || r.na == kChipNAMax);   // the LDS tier only behind a full AGPR tier
+        if (i > 0)
+            CHECK(r.views() > kChipLadder[i - 1].views() && r.views() - kChipLadder[i - 1].views() <= kChipPadMax);
+    }
+    CHECK(kChipTopS == 201 && kChipLadder[kChipRungs - 1].na == 84 && kChipLadder[kChipRungs - 1].nl == 50);
+    // every view count the kernel takes has a rung that holds it with at most kChipPadMax views of padding -- or is beyond
+    // the top rung, which then fetches the rest per pass -- and its LDS share fits; no other count is taken
+    for (int S = 1; S <= 300; S++) {
+        const int k = chip_rung_for(S);
+        CHECK((k >= 0) == (S >= kChipMinS && S <= kChipMaxS));
+        CHECK(chip_takes(S, 3) == (k >= 0) && !chip_takes(S, 1));
+        if (k < 0)
+            continue;
+        const ChipRung r = kChipLadder[k];
+        if (S <= kChipTopS) {
+            CHECK(r.views() >= S && r.views() - S <= kChipPadMax);
+            CHECK(k == 0 || kChipLadder[k - 1].views() < S);   // the smallest such rung
+            CHECK(chip_table_floats(S, r.views()) >= r.views());
+        } else {
+            CHECK(k == kChipRungs - 1 && chip_table_floats(S, r.views()) >= S);
+        }
+        CHECK((size_t)chip_wave_floats(S, r) * 4 * kScanWavesPerTile <= kChipLdsBytes);
+        CHECK(chip_wave_floats(S, r) >= 2 * (64 + 6 * 32));   // the epilogue's block reuses the region's head
+    }
+    CHECK(kChipMinS == 123 && chip_rung_for(123) == 0 && kChipLadder[0].views() == 127);
+    CHECK(chip_rung_for(201) == kChipRungs - 1 && chip_rung_for(220) == kChipRungs - 1 && chip_rung_for(200) == kChipRungs - 1);
+    CHECK(kChipLadder[chip_rung_for(150)].views() == 151 && kChipLadder[chip_rung_for(152)].views() == 159);
 }
 
 static void test_visit_schedule()
@@ -539,6 +575,7 @@ int main()
     test_host_copies();
     test_plane_layout();
     test_scan_plans();
+    test_chip_ladder();
     test_visit_schedule();
     std::printf("plan tests ok: %d checks\n", g_checks);
     return 0;

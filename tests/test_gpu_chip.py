@@ -1,6 +1,7 @@
-"""The on-chip scan kernel (k2_scan_chip, remotesensingproject_amd/csrc/k2_chip.hpp): RGB light fields of 201 to 220
-views -- BASELINE.json configs[4]'s 201 -- with 198 samples of a unit held in VGPRs + AGPRs + LDS at one wave per SIMD, three
-fetched ahead on every pass, and the mean-shift passes in packed fp32.  Bit-exact against the CPU oracle (core.hpp:480-661 restated) on small fields with
+"""The on-chip scan kernel (k2_scan_chip, remotesensingproject_amd/csrc/k2_chip.hpp): RGB light fields of 123 to 220
+views -- BASELINE.json configs[4]'s 201 is the top rung of its ladder -- with all but three samples of a unit held in VGPRs +
+AGPRs + LDS at one wave per SIMD, three fetched ahead on every pass, and the mean-shift passes in packed fp32; a volume
+runs on the smallest rung that holds its views, the missing ones padded (round 4).  Bit-exact against the CPU oracle (core.hpp:480-661 restated) on small fields with
 border and interior hypotheses, ragged rows, hypothesis groups and views beyond the tiers; bit-exact against the
 streaming kernel at c5's real row length and hypothesis count."""
 import numpy as np
@@ -42,6 +43,14 @@ def _run(rs, vol, dmin, dmax, D, **debug):
     (140, 2, 207, 10, -0.5, 0.25, 0),    # six of them: a pair, a pair ahead of it, and one more trip
     (260, 2, 201, 24, -0.2, 0.2, 4),     # hypothesis groups: four workgroups share a tile, the last one merges
     (65, 1, 203, 8, 0.0, 0.0, 0),        # dmin == dmax
+    # the ladder (round 4): rung = views in the AGPR tier / in the LDS tier; a volume is padded up to the next rung
+    (200, 2, 127, 12, -0.3, 0.3, 0),     # <60, 0> exactly: no LDS tier, nothing padded
+    (131, 2, 123, 10, -0.5, 0.6, 0),     # <60, 0>, four views missing (three of them the fetched-ahead slots... and one of the AGPR tier)
+    (140, 2, 150, 9, -0.4, 0.4, 3),      # <84, 0>, one view missing (a fetched-ahead slot); three hypothesis groups (uneven slices)
+    (200, 2, 152, 12, -0.3, 0.3, 0),     # <84, 8>: seven of the LDS tier's eight views missing
+    (90, 3, 175, 8, -0.6, 0.3, 0),       # <84, 24> exactly
+    (200, 2, 192, 10, -0.3, 0.3, 0),     # the top rung padded by nine views
+    (70, 2, 200, 7, -1.0, 1.0, 0),       # ... by one, all border
 ])
 def test_chip_kernel_against_the_oracle(rs, oracle_mod, U, V, S, D, dmin, dmax, groups):
     rng = np.random.default_rng(1000 + U + S)
@@ -83,8 +92,12 @@ def test_chip_kernel_leaves_other_launch_shapes_to_the_streaming_kernel(rs):
     vol = rng.uniform(0.0, 1.0, size=(V, S, U, 3)).astype(np.float32)
     _, st = _run(rs, vol, -0.3, 0.3, D, force_packed=1)
     assert st.scan_kernel == 2
-    _, st = _run(rs, vol[:, :200], -0.3, 0.3, D)          # fewer views than the tiers and the fetched-ahead slots hold
+    _, st = _run(rs, vol[:, :200], -0.3, 0.3, D)          # fewer views than the top rung holds: padded (round 4)
+    assert st.scan_kernel == 3
+    _, st = _run(rs, vol[:, :122], -0.3, 0.3, D)          # fewer than the lowest rung pays for: two waves per SIMD are faster
     assert st.scan_kernel == 2
+    _, st = _run(rs, vol[:, :123], -0.3, 0.3, D)
+    assert st.scan_kernel == 3
     more = np.concatenate([vol, vol[:, :20]], axis=1)       # 221 views: beyond, the streaming kernel's tail is the cheaper one
     _, st = _run(rs, more, -0.3, 0.3, D)
     assert st.scan_kernel == 2

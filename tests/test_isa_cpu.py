@@ -1,6 +1,7 @@
 """What the shipped gfx950 code must look like, checked by disassembling librslf_hip.so on the CPU (llvm-objdump).
 
-k2_scan_chip keeps 252 samples and its running result in hand-numbered AGPRs a0..a255 (k2_chip.hpp).  The clobber lists
+k2_scan_chip keeps up to 252 samples (every instantiation: the AGPR tier of its rung) and its running result in
+hand-numbered AGPRs a0..a255 (k2_chip.hpp).  The clobber lists
 on its asm statements constrain the register allocator only ACROSS each statement: between them hipcc could legally
 park a live range or a spill copy in an AGPR and corrupt a parked sample, and `agpr_count == 256`, `scratch == 0` would
 both still hold.  So the layout is verified per build: the kernel must contain exactly the accumulator
@@ -14,9 +15,14 @@ sys.path.insert(0, ROOT)
 CSRC = os.path.join(ROOT, "remotesensingproject_amd", "csrc")
 
 
-def _macro(name):
-    txt = open(os.path.join(CSRC, "k2_chip.hpp")).read()
-    return int(re.search(r"#define %s (\d+)" % name, txt).group(1))
+def _ladder():
+    """(NA, NL) of every rung, from the X-macro lists of rslf_plan.hpp."""
+    txt = open(os.path.join(CSRC, "rslf_plan.hpp")).read()
+    rungs = []
+    for part in "ABC":
+        body = re.search(r"#define RSLF_CHIP_LADDER_%s\(X\) (.*)" % part, txt).group(1)
+        rungs += [(int(a), int(b)) for a, b in re.findall(r"X\((\d+), (\d+)\)", body)]
+    return rungs
 
 
 def test_chip_kernel_touches_agprs_only_where_its_asm_says():
@@ -24,17 +30,23 @@ def test_chip_kernel_touches_agprs_only_where_its_asm_says():
     from tools import kernel_metadata as km
     so = build.build()
     dis = km.disassemble(so, "k2_scan_chip")
-    assert sorted(dis) == ["rslf::k2_scan_chip<false>", "rslf::k2_scan_chip<true>"], sorted(dis)
-    NA = _macro("RSLF_CHIP_NA")
-    tier = set(range(3 * NA))                 # sample i of the AGPR tier: a[3i .. 3i + 2]
+    # one padded instantiation per rung; the top rung (BASELINE.json's c5) also exact and with a ragged tail
+    rungs = _ladder()
+    top = max(rungs, key=lambda r: 64 + r[0] + r[1])
+    want = ["rslf::k2_scan_chip<false, %d, %d, true>" % r for r in rungs]
+    want += ["rslf::k2_scan_chip<false, %d, %d, false>" % top, "rslf::k2_scan_chip<true, %d, %d, false>" % top]
+    assert sorted(dis) == sorted(want), sorted(dis)
     named = {253, 254, 255}                   # running score sum (a double) and best score
-    assert not (tier & named)
-    # two forms of the hypothesis body (shared taps / general gather), each: the tier written once by the gather and read
-    # once by the (rolled) pass loop, the three named registers read and written once by the update; plus the three
-    # initial writes and the three final reads
-    bodies = 2
-    expect = bodies * (3 * NA + 3) + 3
     for name, ins in dis.items():
+        tail, NA, NL, pad = re.match(r"rslf::k2_scan_chip<(\w+), (\d+), (\d+), (\w+)>", name).groups()
+        NA = int(NA)
+        tier = set(range(3 * NA))             # sample i of the AGPR tier: a[3i .. 3i + 2]
+        assert not (tier & named)
+        # two forms of the hypothesis body (shared taps / general gather), each: the tier written once by the gather and
+        # read once by the (rolled) pass loop, the three named registers read and written once by the update; plus the
+        # three initial writes and the three final reads
+        bodies = 2
+        expect = bodies * (3 * NA + 3) + 3
         writes = [i for i in ins if i.startswith("v_accvgpr_write_b32")]
         reads = [i for i in ins if i.startswith("v_accvgpr_read_b32")]
         assert len(writes) == expect and len(reads) == expect, (name, len(writes), len(reads), expect)
@@ -48,4 +60,12 @@ def test_chip_kernel_touches_agprs_only_where_its_asm_says():
         others = [i for i in ins if re.search(r"\ba\[?\d", i) and i not in writes and i not in reads]
         assert not others, (name, others[:5])          # no MFMA, no AV-class load / store, no spill through an AGPR
         assert not [i for i in ins if i.startswith("v_accvgpr_mov")], name
-        assert not [i for i in ins if i.startswith(("scratch_", "buffer_store", "buffer_load"))], name   # and no scratch at all
+        assert not [i for i in ins if i.startswith(("buffer_store", "buffer_load"))], name
+        # scratch: none in the kernels of record (c5's), none on the rungs without an LDS tier; the padded rungs WITH one carry
+        # a single dword per lane -- the tile's dense / gappy flag, which hipcc keeps per lane -- stored once per workgroup
+        # and read once per run of hypotheses
+        scratch = [i for i in ins if i.startswith("scratch_")]
+        if pad == "false" or int(NL) == 0:
+            assert not scratch, (name, scratch[:4])
+        else:
+            assert len(scratch) <= 2, (name, scratch[:6])

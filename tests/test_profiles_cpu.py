@@ -57,10 +57,15 @@ def test_c5_traffic_is_within_twice_the_algorithmic_bytes():
 
 def test_on_chip_kernel_has_no_scratch_in_the_resource_table():
     rows = [ln for ln in open(os.path.join(PROF, RND + "_resource_table.txt")) if re.match(r"^(rslf::)?k2_scan_chip\b", ln)]
-    assert len(rows) == 2, rows      # <false>: exactly 201 views (c5); <true>: 202 .. 220, the rest fetched per pass
+    # <TAIL, NA, NL, PAD>: the top rung exactly (c5's 201 views) and with a ragged tail (202 .. 220), and one padded
+    # instantiation per rung of the ladder
+    assert len(rows) >= 2, rows
     for row in rows:
         vgpr, sgpr, scratch, occ, lds = [int(x) for x in row.split()[-5:]]
-        assert scratch == 0 and vgpr == 256 and occ == 1, row
+        assert vgpr == 256 and occ == 1, row
+        # (padded rungs with an LDS tier: one dword per lane, the tile's dense flag -- tests/test_isa_cpu.py)
+        assert scratch == 0 or ("true>" in row and scratch <= 8), row
+    assert sum("84, 50, false>" in row for row in rows) == 2, rows
 
 
 def test_shipped_library_carries_the_scratch_figures_of_the_table():
@@ -76,10 +81,10 @@ def test_shipped_library_carries_the_scratch_figures_of_the_table():
         build.build()
     ks = {k.replace("rslf::", ""): v for k, v in kernel_metadata.kernels(lib).items()}
     assert len(ks) > 100
-    for name in ("k2_scan_chip<false>", "k2_scan_chip<true>", "k2_scan_reg<40, 1>", "k2_scan_reg<16, 1>", "k2_scan_reg_px<40, 1>",
+    for name in ("k2_scan_chip<false, 84, 50, false>", "k2_scan_chip<true, 84, 50, false>", "k2_scan_chip<false, 84, 0, true>", "k2_scan_reg<40, 1>", "k2_scan_reg<16, 1>", "k2_scan_reg_px<40, 1>",
                  "k2_scan_reg<104, 1>", "k2_scan_reg_px<104, 1>", "k2_scan_stream<3, 0, false>", "k2_scan_stream_px<3, 0>"):
         assert ks[name]["private_segment_fixed_size"] == 0, (name, ks[name])
-    assert ks["k2_scan_chip<false>"]["agpr_count"] == 256
+    assert ks["k2_scan_chip<false, 84, 50, false>"]["agpr_count"] == 256
     table = open(os.path.join(PROF, RND + "_resource_table.txt")).read().splitlines()
     if table[0].strip() != "# source hash %s" % build.source_hash():
         warnings.warn("the resource table is of another tree: not compared with this binary")

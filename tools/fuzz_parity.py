@@ -27,14 +27,14 @@ S_CHOICES_3 = [1, 2, 3, 5, 8, 9, 16, 17, 24, 31, 40, 48, 49, 56, 57, 64, 70, 88,
                199, 200, 201, 201, 202, 203, 209, 220, 230, 256]   # 201 .. 220 views, dense launch: the on-chip kernel (k2_chip.hpp)
 
 
-ONLY_CHIP = os.environ.get("FUZZ_ONLY_CHIP") == "1"   # RGB, 201..220 views, dense launches: what k2_scan_chip takes
+ONLY_CHIP = os.environ.get("FUZZ_ONLY_CHIP") == "1"   # RGB, 123..220 views, dense launches: what k2_scan_chip takes (every rung, padded and exact)
 
 
 def draw_case(rng):
     C = int(rng.choice([1, 1, 3]))
     S = int(rng.choice(S_CHOICES_1 if C == 1 else S_CHOICES_3))
     if ONLY_CHIP:
-        C, S = 3, int(rng.choice([201, 201, 202, 203, 204, 205, 206, 211, 217, 220]))
+        C, S = 3, int(rng.choice([201, 201, 202, 203, 204, 205, 206, 211, 217, 220]) if rng.uniform() < 0.4 else rng.integers(123, 202))
     budget = 600000 if C == 1 else 250000          # oracle work ~ V*U*D*S
     U = int(rng.choice([1, 2, 7, 33, 63, 64, 65, 100, 129, 200, 260, 513, 700]))
     V = int(rng.integers(1, 13))
