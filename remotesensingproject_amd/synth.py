@@ -20,6 +20,8 @@ CONFIGS = {
     # the fine-to-coarse / 2-D sweep rows, not BASELINE configs
     "skysat_lr": dict(U=960, V=540, S=100, C=1, D=120, dmin=-1.0, dmax=4.0, seed=20260099),     # SkysatLR18, report:430
     "mansion_lr": dict(U=1146, V=720, S=100, C=3, D=120, dmin=0.0, dmax=4.0, seed=20260099),    # MansionLR, report:406,427
+    # MansionLR's frame with 151 views: a rung of the on-chip kernel's ladder other than c5's (k2_scan_chip<false, 84, 0, true>)
+    "mansion_151": dict(U=1146, V=720, S=151, C=3, D=120, dmin=0.0, dmax=4.0, seed=20260099),
 }
 
 

@@ -12,7 +12,7 @@ import warnings
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PROF = os.path.join(ROOT, "profiles")
 RND = "r04"
-TAGS = ("c3_n1", "c2_n1", "c1_n1", "c5_slice16", "c5_n1", "mansion_lr_n1")
+TAGS = ("c3_n1", "c2_n1", "c1_n1", "c5_slice16", "c5_n1", "mansion_lr_n1", "mansion_151_n1")
 
 
 def _load(name):
@@ -36,10 +36,10 @@ def test_rocprof_average_reproduces_each_bench_line():
     for t in TAGS:
         j = _load("%s_%s_pmc.json" % (RND, t))
         rc = j["roofline_check"]
-        # (the 16-scanline slice of c5 and the MansionLR-shaped dense step are developer aids: their 32- and 45-ms launches
+        # (the 16-scanline slice of c5 and the MansionLR-shaped dense steps are developer aids: their 32- to 80-ms launches
         # run 2-2.6 % slower under the profiler than un-profiled on every lease; c5's line of record is the full-size one,
         # which agrees to 0.1 %)
-        assert abs(rc["ratio"] - 1.0) <= (0.03 if t in ("c5_slice16", "mansion_lr_n1") else 0.02), (t, rc)
+        assert abs(rc["ratio"] - 1.0) <= (0.03 if t in ("c5_slice16", "mansion_lr_n1", "mansion_151_n1") else 0.02), (t, rc)
         line = _load("%s_bench_%s.json" % (RND, t))
         assert abs(line["roofline"]["frac"] - rc["frac_of_the_unprofiled_line"]) < 1e-9, t
         assert abs(line["roofline"]["frac"] - line["roofline"]["achieved"] / line["roofline"]["peak"]) < 1e-9

@@ -14,7 +14,8 @@ def stats(src_glob, dst):
     keep = [rows[0]] + [r for r in rows[1:] if "rslf::" in r[0]]
     csv.writer(open(dst, "w", newline=""), quoting=csv.QUOTE_ALL).writerows(keep)
 TAGS = {rnd + "f_c3": "c3_n1", rnd + "f_c2": "c2_n1", rnd + "f_c1": "c1_n1", rnd + "f_c5s16": "c5_slice16", rnd + "f_c5": "c5_n1",
-        rnd + "f_mansion": "mansion_lr_n1"}   # (the last: the dense pile step of the report's MansionLR shape, 100 views RGB)
+        rnd + "f_mansion": "mansion_lr_n1",   # (the dense pile step of the report's MansionLR shape, 100 views RGB)
+        rnd + "f_mansion151": "mansion_151_n1"}   # (the same frame with 151 views: a rung of the on-chip ladder other than c5's)
 for d, t in TAGS.items():
     if os.path.isdir(os.path.join("gpurun_out", d)):
         subprocess.run([sys.executable, "tools/summarize_profiles.py", rnd, t], env=dict(os.environ, PROF_DIR=d), stdout=subprocess.DEVNULL, check=True)
