@@ -9,7 +9,7 @@ rnd = sys.argv[1] if len(sys.argv) > 1 else "r03"
 def lastline(f):
     return [l for l in open(f) if l.startswith("{")][-1]
 def stats(src_glob, dst):
-    f = sorted(glob.glob(src_glob))[-1]
+    f = sorted(glob.glob(src_glob), key=os.path.getmtime)[-1]   # (the newest: the directories keep every earlier run)
     rows = list(csv.reader(open(f)))
     keep = [rows[0]] + [r for r in rows[1:] if "rslf::" in r[0]]
     csv.writer(open(dst, "w", newline=""), quoting=csv.QUOTE_ALL).writerows(keep)
