@@ -690,25 +690,6 @@ __device__ __forceinline__ int packed_groups(int groups, int tiles, int adapt)
         ROWS_CALL;                                                                      \
         scan_epilogue<C, kEpiDyn>(a, lb, v, u, active, best, epi_lds, epi_stride);      \
     }
-// The streaming kernel's form: a grid smaller than the launch's blocks strides over them (plan::stream_row_grid).  Not the
-// register kernels': what the loop keeps alive across its trips cost them registers they do not have (c1 / c2 / c3: 20-60
-// bytes of scratch per lane, which reached HBM) and the dispatcher balances their short workgroups better than a stride.
-#define RSLF_SCAN_ROW_TILES_STRIDED(ROWS_CALL)                                          \
-    {                                                                                   \
-        Best<C> best;                                                                   \
-        int v, u, d0, d1;                                                               \
-        bool active;                                                                    \
-        for (int bid = blockIdx.x; bid < a.per_xcd * 8; bid += gridDim.x) {             \
-            const int lb = RSLF_XCD_ROW_INTERLEAVE ? xcd_logical_block_rows(bid, a.tiles_per_row * a.groups) \
-                                                   : xcd_logical_block(bid, a.per_xcd); \
-            if (!scan_tile(a, lb, v, u, active))                                        \
-                continue;                                                               \
-            scan_chunk(a, lb % a.groups, d0, d1);                                       \
-            best.init();                                                                \
-            ROWS_CALL;                                                                  \
-            scan_epilogue<C, kEpiDyn>(a, lb, v, u, active, best, epi_lds, epi_stride);  \
-        }                                                                               \
-    }
 #define RSLF_SCAN_KERNEL_BODY_(CHUNK, ROWS_CALL, PACKED_CALL)                           \
     if (a.packed) {                                                                     \
         RSLF_SCAN_PACKED_LOOP_(CHUNK, PACKED_CALL)                                      \

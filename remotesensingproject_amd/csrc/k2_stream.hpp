@@ -584,7 +584,7 @@ __global__ __launch_bounds__(64 * kScanWaves) __attribute__((amdgpu_waves_per_eu
     if constexpr (PACKED) {
         RSLF_SCAN_PACKED_LOOP((scan_stream_body<C, true, false, NRES>(a, v, u, d0, d1, best, otab)))
     } else {
-        RSLF_SCAN_ROW_TILES_STRIDED((scan_stream_rows<C, NRES>(a, v, u, active, d0, d1, best, otab)))
+        RSLF_SCAN_ROW_TILE((scan_stream_rows<C, NRES>(a, v, u, active, d0, d1, best, otab)))
     }
 }
 

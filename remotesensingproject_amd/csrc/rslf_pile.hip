@@ -434,7 +434,7 @@ extern "C" int rslf_depth_epi_scan(rslf_ctx* ctx, const rslf_volume* vol, const 
             ar.v0 = v0;
             ar.logical_blocks = (int)(tiles * ar.groups);
             ar.per_xcd = ((rows + 7) / 8) * ar.tiles_per_row * ar.groups;
-            const dim3 rgrid((unsigned)plan::stream_row_grid(ar.per_xcd * 8));
+            const dim3 rgrid((unsigned)(ar.per_xcd * 8));
             hipError_t rattr = hipSuccess;
             auto launch_rows = [&](auto kernel) {
                 rattr = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -465,7 +465,7 @@ extern "C" int rslf_depth_epi_scan(rslf_ctx* ctx, const rslf_volume* vol, const 
         const long long px_items = sp.px_waves ? ((long long)n * sp.px_waves + kScanWaves - 1) / kScanWaves : 0;
         const dim3 grid(sp.px_waves ? (unsigned)std::min<long long>(px_items, 2048)
                         : packed    ? (unsigned)std::min<long long>(tiles * groups, 1024)
-                                    : (use_stream && !spad && !use_chip) ? (unsigned)plan::stream_row_grid(a.per_xcd * 8) : (unsigned)(a.per_xcd * 8));
+                                    : (unsigned)(a.per_xcd * 8));
         if (spad) {
             rc = launch_scan_reg(spad, vol->C, a, grid, st);
             if (rc)

@@ -570,19 +570,6 @@ inline int stream_park_for(int S, int C, int nres, size_t stream_lds_bytes)
     return park - park % batch;
 }
 
-// Row-tile launches of the streaming kernel: at most kStreamRowGrid workgroups stride over the (tile, group) blocks (a
-// multiple of 8, so a workgroup stays on its XCD) instead of one workgroup per block.  A dense 100-view RGB step is 109 k
-// blocks and a sparse visit's row tiles are mostly empty ones; each workgroup launch claims 80 KiB of LDS.  Same box:
-// dense 47.5 -> 46.0 ms, the MansionLR-like fine-to-coarse run 1.268 -> 1.178 s at 8192 (4096: 1.185, 16384: 1.187,
-// 2048: 1.185, 512: 1.25).  The register kernels LOSE by a fixed stride -- the dispatcher balances their short workgroups
-// better (c1 -17 %, c2 -6 %, c3 -4 % at 4096) -- and keep one workgroup per block (profiles/r04_k2_variants.md section 10).
-#ifndef RSLF_STREAM_GRID_CAP
-#define RSLF_STREAM_GRID_CAP 8192
-#endif
-constexpr int kStreamRowGrid = RSLF_STREAM_GRID_CAP;
-static_assert(kStreamRowGrid == 0 || (kStreamRowGrid >= 8 && kStreamRowGrid % 8 == 0), "whole rounds of the 8 XCDs");
-inline int stream_row_grid(int blocks) { return kStreamRowGrid > 0 && blocks > kStreamRowGrid ? kStreamRowGrid : blocks; }
-
 // Shared taps (63-pixel row tiles, one texel load per sample, the right tap from lane + 1) halve the loads of the samples
 // that are gathered again on EVERY pass -- and cost a lane per tile.  They pay where that tail is long: 109 of 201 views at
 // c5 (+9 %); at 100 views RGB the tail is 8 samples and plain 64-pixel tiles are 6 % faster (47.5 vs 44.7 ms,

@@ -419,8 +419,6 @@ static void test_chip_ladder()
         CHECK(chip_wave_floats(S, r) >= 2 * (64 + 6 * 32));   // the epilogue's block reuses the region's head
     }
     CHECK(kChipMinS == 123 && chip_rung_for(123) == 0 && kChipLadder[0].views() == 127);
-    // the streaming kernel's row-tile grid: one workgroup per block up to the cap, then a grid of whole XCD rounds striding over them
-    CHECK(stream_row_grid(8) == 8 && stream_row_grid(kStreamRowGrid) == kStreamRowGrid && stream_row_grid(109440) == kStreamRowGrid && kStreamRowGrid % 8 == 0);
     CHECK(chip_rung_for(201) == kChipRungs - 1 && chip_rung_for(220) == kChipRungs - 1 && chip_rung_for(200) == kChipRungs - 1);
     CHECK(kChipLadder[chip_rung_for(150)].views() == 151 && kChipLadder[chip_rung_for(152)].views() == 159);
 }

@@ -125,17 +125,16 @@ def test_stream_kernel(rs, oracle_mod, hooks, C_, S, U, kind):
     assert_pile_parity(got, ref, label="stream_C%d_S%d" % (C_, S))
 
 
-def test_stream_kernel_row_tiles_under_a_capped_grid(rs, oracle_mod, hooks):
-    """A dense launch of the streaming kernel with more (tile, group) blocks than plan::kStreamRowGrid (8192): the grid is
-    capped and every workgroup strides over several blocks -- tiles of several scanlines, with the groups' records and
-    tickets of each -- where every other case of this file fits one block per workgroup."""
+def test_stream_kernel_dense_launch_of_many_blocks(rs, oracle_mod, hooks):
+    """A dense launch of the streaming kernel with 9 328 (tile, group) blocks -- tiles of 212 scanlines, four hypothesis
+    groups each with their records and tickets -- where every other case of this file is a few hundred."""
     hooks(force_scan="stream")
-    U, V, S, D = 660, 212, 17, 32               # 11 tiles x 212 scanlines x 4 groups = 9 328 blocks
+    U, V, S, D = 660, 212, 17, 32
     vol = _vol("noise", U, V, S, 3, 4242, -1.0, 1.5)
     ref = oracle_mod.depth1d_pile_run(vol, -1.0, 1.5, D)
     comp, got = _run(rs, vol, -1.0, 1.5, D)
     assert comp.stats.scan_kernel == 2
-    assert_pile_parity(got, ref, label="stream_capped_grid")
+    assert_pile_parity(got, ref, label="stream_many_blocks")
 
 
 def test_stream_kernel_per_pixel_ranges(rs, oracle_mod, hooks):
