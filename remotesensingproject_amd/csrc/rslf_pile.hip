@@ -370,6 +370,8 @@ extern "C" int rslf_depth_epi_scan(rslf_ctx* ctx, const rslf_volume* vol, const 
         rr.ctx_groups = 1;
         rr.precompacted = 1;      // the lists are in place
         rr.force_packed = 0;
+        if (rr.stream_groups <= 0)
+            rr.stream_groups = plan::kStreamGroups;   // (sparse rows: the groups are the launch's parallelism, not the dense rule's few)
         spr = plan::plan_scan(rr, stream_resident_for(vol->S, vol->C));
         a.row_min = ctx->row_split > 1 ? ctx->row_split : plan::kRowSplitMin;   // (hook: 1 = the default threshold, larger = that many pixels)
     }

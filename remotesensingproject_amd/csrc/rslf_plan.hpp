@@ -37,6 +37,7 @@ constexpr size_t kAutoGroupBudget = (size_t)96 << 20;              // ... of whi
 constexpr int kPackedItemTarget = 2048;                            // packed launches: (tile, group) items the device aims for
 constexpr int kSweepGroups = 32;                                   // workgroups sharing a packed tile on a sweep's sparse visits
 constexpr int kStreamGroups = 16;                                  // dense launches of the streaming kernel: workgroups per tile
+constexpr size_t kStreamSmallEpiBytes = (size_t)2 << 20;           // ... 2 or 3 where a scanline's EPI is at most this (half an XCD's L2)
 constexpr int kRowSplitMin = 64;                                   // packed launches of stream-class volumes: rows with at least this many pixels go as row tiles
 constexpr int kChipGroups = 8;                                     // ... of the on-chip kernel: half the records, same speed (profiles/r03_k2_variants.md)
 constexpr size_t kStreamLdsBytes = (size_t)80 << 10;               // dynamic LDS of one streaming workgroup (two per CU)
@@ -592,6 +593,15 @@ inline ScanPlan plan_scan(const ScanRequest& r, int nres, int nres_px = -1)
         const long long tiles = (long long)r.V * ((r.U + 62) / 63);
         if (r.use_chip && r.stream_groups <= 0 && (r.num_cus <= 0 || tiles * kChipGroups >= 8LL * r.num_cus))
             groups = kChipGroups;
+        // The streaming kernel's groups are there for the XCD's L2.  Where one scanline's EPI (all its views) is a small part
+        // of it and the launch has workgroups to spare, two or three groups are enough and every group fewer is a record
+        // not written and merged: 100 views RGB x 1146 px (1.4 MB), 120 hypotheses, dense: 8 groups 44.9 ms, 4 43.4, 3 41.0,
+        // 2 41.6, 1 43.3 (profiles/r04_k2_variants.md section 12).  Three where the hypotheses divide evenly over its 12 waves.
+        if (r.use_stream && r.stream_groups <= 0 && (size_t)r.S * r.U * r.C * sizeof(float) <= kStreamSmallEpiBytes) {
+            const int few = r.dim_d % (3 * kScanWavesPerTile) == 0 ? 3 : 2;
+            if (r.num_cus <= 0 || tiles * few >= 16LL * r.num_cus)
+                groups = few;
+        }
     }
     // A dense launch of a register kernel whose grid is only a few rounds of workgroups pays for its last, partly empty
     // round: sharing each tile's hypotheses among 2-8 workgroups makes the rounds shorter and more numerous -- as long

@@ -272,6 +272,26 @@ static void test_scan_plans()
     p = plan_scan(c5, 68);
     CHECK(p.groups == 16 && p.tile_w == 63 && p.tiles_per_row == 65 && p.rows_per_launch == 126 && p.stream_park == 24);
     CHECK(p.lds_bytes == 4 * 4 * (204 + 24 * 3 * 64) && p.lds_bytes <= kStreamLdsBytes);
+    {   // a small EPI (MansionLR: 100 views x 1146 px RGB = 1.4 MB): three groups where 120 hypotheses divide over 12 waves, else two;
+        // not with few tiles, not on request, not for the sparse rows' launches (which ask for kStreamGroups themselves)
+        ScanRequest m = request(720, 1146, 100, 3, 120);
+        m.spad = 0;
+        m.use_stream = true;
+        m.num_cus = 256;
+        m.stream_lds_bytes = kStreamLdsBytes;
+        CHECK(plan_scan(m, 68).groups == 3);
+        m.dim_d = 128;
+        CHECK(plan_scan(m, 68).groups == 2);
+        m.V = 8;
+        CHECK(plan_scan(m, 68).groups == 16);
+        m.V = 720;
+        m.stream_groups = kStreamGroups;
+        CHECK(plan_scan(m, 68).groups == 16);
+        m.stream_groups = 0;
+        m.S = 201;
+        m.U = 4096;
+        CHECK(plan_scan(m, 68).groups == 16);
+    }
     ScanRequest chip = c5;                                  // the on-chip kernel: the streaming kernel's tiles, half its groups, all of the CU's LDS
     chip.use_stream = false;
     chip.use_chip = true;

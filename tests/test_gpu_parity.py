@@ -125,16 +125,19 @@ def test_stream_kernel(rs, oracle_mod, hooks, C_, S, U, kind):
     assert_pile_parity(got, ref, label="stream_C%d_S%d" % (C_, S))
 
 
-def test_stream_kernel_dense_launch_of_many_blocks(rs, oracle_mod, hooks):
-    """A dense launch of the streaming kernel with 9 328 (tile, group) blocks -- tiles of 212 scanlines, four hypothesis
-    groups each with their records and tickets -- where every other case of this file is a few hundred."""
+@pytest.mark.parametrize("D", [32, 24])
+def test_stream_kernel_dense_launch_of_many_tiles(rs, oracle_mod, hooks, D):
+    """A dense launch of the streaming kernel over 2 332 tiles of a small EPI: the plan gives each tile two workgroups (32
+    hypotheses) or three (24: they divide evenly over twelve waves) instead of the eight to sixteen of a large EPI
+    (plan::kStreamSmallEpiBytes) -- records and tickets of 212 scanlines' tiles, where every other case of this file is a
+    few dozen tiles."""
     hooks(force_scan="stream")
-    U, V, S, D = 660, 212, 17, 32
+    U, V, S = 660, 212, 17
     vol = _vol("noise", U, V, S, 3, 4242, -1.0, 1.5)
     ref = oracle_mod.depth1d_pile_run(vol, -1.0, 1.5, D)
     comp, got = _run(rs, vol, -1.0, 1.5, D)
     assert comp.stats.scan_kernel == 2
-    assert_pile_parity(got, ref, label="stream_many_blocks")
+    assert_pile_parity(got, ref, label="stream_many_tiles_D%d" % D)
 
 
 def test_stream_kernel_per_pixel_ranges(rs, oracle_mod, hooks):
