@@ -1,3 +1,5 @@
+#!/bin/bash
+# The streaming kernel on the MansionLR shape under a few debug hooks (workgroups per tile, LDS share): no rebuild needed.
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 line() { python3 -c "
 import sys, json
